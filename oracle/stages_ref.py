@@ -1,0 +1,542 @@
+"""CPU restatement of the reference's stage solvers.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Follows, for the branches the shipped configs enable:
+
+* ``optim_chamfer``            reference optimization.py:147-285
+* ``optim_markers``            reference optimization.py:288-399  (+ losses/losses.py:43-51)
+* ``compute_nearest_points``   reference optimization.py:402-642  (use_mean, granularity "full")
+* ``find_best_part_fits``      reference markers/markers_utils.py:274-638 (mode "cluster", no reprojection)
+* ``segment_rigid``            reference markers/markers_utils.py:244-271
+* sub-hierarchy enumeration    reference utils/smpl_utils.py:106-188
+* ``multimodal_video_mocap``   reference multimodal.py:38-726 (equal frame rates, offset 0)
+
+Same materialisations as the reference (repeat_interleave of the vertex cloud per marker, dense one-hot
+gather) and the real ``torch.optim.LBFGS`` -- this is also what bench.py times as ``cpu_baseline``
+(kind "port").  Pinned against the reference's own modules by tests/golden (oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .p3d_ref import (axis_angle_to_matrix, chamfer_distance, matrix_to_rotation_6d, rotation_6d_to_matrix)
+
+MARKER_DISTANCE = 0.0095  # reference utils/settings.py:1
+
+
+# ----------------------------------------------------------------------------------------------
+# small helpers (optimization.py:662-724, multimodal.py:34-35, losses/*)
+# ----------------------------------------------------------------------------------------------
+
+def normalize_rot(rot: torch.Tensor) -> torch.Tensor:
+    return rotation_6d_to_matrix(matrix_to_rotation_6d(rot))
+
+
+def compute_root_orient_z(angle: torch.Tensor) -> torch.Tensor:
+    z = torch.zeros(list(angle.shape[:-1]) + [3], device=angle.device)
+    z[..., [2]] = angle
+    return axis_angle_to_matrix(z)
+
+
+def get_marker_mask(markers: torch.Tensor) -> torch.Tensor:
+    return torch.sum(torch.abs(markers), axis=-1) != 0.0
+
+
+def weighted_chamfer_distance(x, y, x_weights, single_directional: bool = False):
+    """losses/chamfer_distance.py:5-21 -- one cloud per marker; the flag argument is ignored there too."""
+    x_flat = torch.reshape(x, (-1, 1, x.shape[2]))
+    y_flat = torch.repeat_interleave(y, repeats=x.shape[1], dim=0)
+    w_flat = torch.flatten(x_weights)
+    return chamfer_distance(x_flat, y_flat, weights=w_flat, single_directional=True)
+
+
+def marker_loss(markers, virtual_markers, marker_weights, marker_distance):
+    """losses/losses.py:43-51."""
+    out = (torch.norm(markers - virtual_markers, dim=-1) - marker_distance) ** 2
+    return out * marker_weights
+
+
+def get_aabb(points: torch.Tensor) -> torch.Tensor:
+    aabb = torch.zeros((points.shape[0], 3, 2), dtype=points.dtype, device=points.device)
+    for a in range(3):
+        aabb[:, a, 0] = torch.min(points[..., a], dim=1)[0]
+        aabb[:, a, 1] = torch.max(points[..., a], dim=1)[0]
+    return aabb
+
+
+def get_aabb_volume(aabb: torch.Tensor) -> torch.Tensor:
+    d = aabb[:, :, 1] - aabb[:, :, 0]
+    return d[:, 0] * d[:, 1] * d[:, 2]
+
+
+def _lbfgs(params, num_iters, config, lr):
+    return torch.optim.LBFGS(
+        params,
+        max_iter=num_iters,
+        tolerance_grad=config["optimizer"]["tolerance_grad"],
+        tolerance_change=config["optimizer"]["tolerance_change"],
+        lr=lr,
+        line_search_fn="strong_wolfe",
+    )
+
+
+def _smpl_repeat_betas(smpl_inference, poses, betas, root_orient, trans):
+    return smpl_inference(
+        poses=poses,
+        betas=torch.repeat_interleave(betas, dim=0, repeats=poses.shape[0]),
+        root_orient=root_orient,
+        trans=trans,
+    )
+
+
+# ----------------------------------------------------------------------------------------------
+# chamfer stage
+# ----------------------------------------------------------------------------------------------
+
+def chamfer_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, z_angle,
+                       smpl_inference, config):
+    """One forward of closure_stage_chamfer (optimization.py:187-256) for the shipped loss keys."""
+    st = config["stages"]["chamfer"]
+    if not st["yaw_lock"]:
+        raise NotImplementedError("yaw_lock False is not a shipped configuration")
+    z_root = compute_root_orient_z(z_angle) @ root_orient
+    out = _smpl_repeat_betas(smpl_inference, normalize_rot(pose_body), betas, normalize_rot(z_root), trans)
+    loss = 0
+    unsupported = set(st["losses"]) - {"full_chamfer", "reg_pose_body", "reg_betas"}
+    if unsupported:
+        raise NotImplementedError("chamfer-stage losses outside the shipped configs: %s" % sorted(unsupported))
+    if "full_chamfer" in st["losses"]:
+        c = weighted_chamfer_distance(markers, out["vertices"], get_marker_mask(markers),
+                                      single_directional=st["single_directional"])[0]
+        loss = loss + c * st["losses"]["full_chamfer"]
+    if "reg_pose_body" in st["losses"]:
+        loss = loss + F.mse_loss(pose_body, o_pose_body) * st["losses"]["reg_pose_body"]
+    if "reg_betas" in st["losses"]:
+        loss = loss + F.mse_loss(betas, o_betas) * st["losses"]["reg_betas"]
+    return loss, out
+
+
+def optim_chamfer(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, smpl_inference, config,
+                  trace: Optional[list] = None):
+    """optimization.py:147-285. Mutates trans/betas/pose_body (L-BFGS) and root_orient (in place)."""
+    z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
+    z_angle.requires_grad_(True)
+    params = [trans, z_angle, betas, pose_body]
+    opt = _lbfgs(params, config["stages"]["chamfer"]["num_iters"], config, lr=0.1)
+    root_orient.requires_grad_(False)
+
+    def closure():
+        opt.zero_grad()
+        loss, _ = chamfer_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
+                                     z_angle, smpl_inference, config)
+        loss.backward()
+        if trace is not None:
+            trace.append(float(loss))
+        return loss
+
+    opt.step(closure)
+    with torch.no_grad():
+        root_orient[:] = compute_root_orient_z(z_angle) @ root_orient
+    root_orient.requires_grad_(True)
+    return z_angle.detach()
+
+
+# ----------------------------------------------------------------------------------------------
+# marker stage
+# ----------------------------------------------------------------------------------------------
+
+def virtual_markers_dense(vertices: torch.Tensor, one_hot: torch.Tensor) -> torch.Tensor:
+    """optimization.py:345-351 -- the dense [F,M,V,3] product the reference materialises."""
+    num_markers = one_hot.shape[0]
+    v = torch.repeat_interleave(torch.unsqueeze(vertices, dim=1), repeats=num_markers, dim=1)
+    bc = torch.unsqueeze(torch.unsqueeze(one_hot, dim=0), dim=-1)
+    bc = torch.repeat_interleave(bc, repeats=v.shape[0], dim=0)
+    bc = torch.repeat_interleave(bc, repeats=3, dim=-1)
+    return torch.sum(v * bc, dim=2)
+
+
+def marker_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
+                      smpl_inference, config):
+    st = config["stages"]["marker"]
+    if st.get("use_sdf"):
+        raise NotImplementedError("use_sdf is off in every shipped config")
+    unsupported = set(st["losses"]) - {"marker", "reg_pose_body", "reg_betas"}
+    if unsupported:
+        raise NotImplementedError("marker-stage losses outside the shipped configs: %s" % sorted(unsupported))
+    out = _smpl_repeat_betas(smpl_inference, normalize_rot(pose_body), betas, normalize_rot(root_orient), trans)
+    vm = virtual_markers_dense(out["vertices"], one_hot)
+    loss = 0
+    if "marker" in st["losses"]:
+        ml = marker_loss(markers, vm, get_marker_mask(markers), MARKER_DISTANCE)
+        loss = loss + torch.mean(ml) * st["losses"]["marker"]
+    if "reg_pose_body" in st["losses"]:
+        loss = loss + F.mse_loss(pose_body, o_pose_body) * st["losses"]["reg_pose_body"]
+    if "reg_betas" in st["losses"]:
+        loss = loss + F.mse_loss(betas, o_betas) * st["losses"]["reg_betas"]
+    return loss, out
+
+
+def optim_markers(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
+                  smpl_inference, config, trace: Optional[list] = None):
+    """optimization.py:288-399."""
+    params = [pose_body, betas, root_orient, trans]
+    opt = _lbfgs(params, config["stages"]["marker"]["num_iters"], config, lr=1.0)
+
+    def closure():
+        opt.zero_grad()
+        loss, _ = marker_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
+                                    one_hot, smpl_inference, config)
+        loss.backward()
+        if trace is not None:
+            trace.append(float(loss))
+        return loss
+
+    opt.step(closure)
+
+
+# ----------------------------------------------------------------------------------------------
+# marker placement
+# ----------------------------------------------------------------------------------------------
+
+def compute_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_inference, img_mask, config,
+                           return_indices: bool = False):
+    """optimization.py:402-642 with compute_locations.use_mean True, granularity "full"."""
+    cl = config["stages"]["compute_locations"]
+    if cl["use_barycentric"] or not cl["use_mean"]:
+        raise NotImplementedError("only the shipped use_mean placement is restated")
+    num_frames, num_markers = markers.shape[0], markers.shape[1]
+    with torch.no_grad():
+        out = smpl_inference(
+            poses=normalize_rot(pose_body),
+            betas=torch.repeat_interleave(torch.mean(betas, dim=0, keepdim=True), dim=0, repeats=betas.shape[0]),
+            root_orient=normalize_rot(root_orient),
+            trans=trans,
+        )
+    vertices = out["vertices"].detach().cpu().numpy()
+    num_verts = vertices.shape[1]
+    dist = np.zeros((num_frames, num_markers, num_verts), dtype=np.float32)
+    valid = torch.where(img_mask == 1)[0].tolist()
+    markers_np = markers.detach().cpu().numpy()
+    for f in range(num_frames):
+        if f not in valid:
+            continue
+        vf = np.repeat(vertices[f][None, :, :], axis=0, repeats=num_markers)
+        mf = np.repeat(markers_np[f][:, None, :], axis=1, repeats=num_verts)
+        dist[f] = np.linalg.norm(vf - mf, axis=-1)
+    mask_np = img_mask.detach().cpu().numpy()
+    reduced = np.mean(dist[np.where(mask_np == 1)], axis=0)
+    vidx = np.argmin(reduced, axis=-1)
+    one_hot = torch.zeros((num_markers, num_verts)).float().to(markers.device)
+    for m in range(num_markers):
+        one_hot[m, vidx[m]] = 1.0
+    if return_indices:
+        return one_hot, vidx
+    return one_hot
+
+
+# ----------------------------------------------------------------------------------------------
+# part stage
+# ----------------------------------------------------------------------------------------------
+
+def segment_rigid(points: np.ndarray) -> List[List[int]]:
+    """markers/markers_utils.py:244-271: std of pairwise distance over time -> average-linkage clusters."""
+    from sklearn.cluster import AgglomerativeClustering
+
+    num_markers = points.shape[1]
+    mat = np.zeros((num_markers, num_markers))
+    for i in range(num_markers):
+        for j in range(num_markers):
+            mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1))
+    labels = AgglomerativeClustering(n_clusters=None, distance_threshold=0.005, metric="precomputed",
+                                     linkage="average").fit(mat).labels_
+    return [np.where(labels == v)[0].tolist() for v in np.unique(labels).tolist()]
+
+
+def get_sub_hierarchies(parents, num_bones: int) -> List[List[int]]:
+    """utils/smpl_utils.py:106-164: connected sub-trees with exactly num_bones nodes, in the
+    reference's enumeration order (children products, nodes visited from the last to the first)."""
+    parents_np = parents if isinstance(parents, np.ndarray) else parents.detach().cpu().numpy()
+    n = parents_np.shape[0]
+    num_bones = min(num_bones, n)
+    children: Dict[int, List[int]] = {i: [] for i in range(n)}
+    for i in range(1, n):
+        children[int(parents_np[i])].append(i)
+    table: Dict[int, List[List[int]]] = {}
+    for node in list(children.keys())[::-1]:
+        table[node] = [[]]
+        for combo in itertools.product(*[table[c] for c in children[node]]):
+            merged: List[int] = []
+            for part in combo:
+                merged = merged + part
+            merged = sorted(merged)
+            if [node] + merged not in table[node]:
+                table[node].append([node] + merged)
+    out = []
+    for node, subtrees in table.items():
+        for st in subtrees:
+            if len(st) == num_bones:
+                out.append(st)
+    return out
+
+
+def remove_approximately_redundant_hierarchies(subtrees, similarity_threshold: float = 0.9):
+    """utils/smpl_utils.py:167-188."""
+    kept = [subtrees[0]]
+    for st in subtrees[1:]:
+        limit = len(st) * similarity_threshold
+        if all(len(set(st) & set(k)) <= limit for k in kept):
+            kept.append(st)
+    return kept
+
+
+def part_stage_loss(markers_subset, pose_body, betas, o_betas, root_orient, trans, z_angle, vertex_indices,
+                    smpl_inference, config):
+    """closure_fit_subtree (markers_utils.py:454-516) for losses {chamfer, reg_betas}."""
+    st = config["stages"]["part"]
+    unsupported = set(st["losses"]) - {"chamfer", "reg_betas"}
+    if unsupported:
+        raise NotImplementedError("part-stage losses outside the shipped configs: %s" % sorted(unsupported))
+    num_frames = pose_body.shape[0]
+    z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
+    out = _smpl_repeat_betas(smpl_inference, pose_body, betas, z_root, trans)
+    verts_sub = out["vertices"][:, vertex_indices]
+    loss = chamfer_distance(markers_subset, verts_sub, single_directional=True)[0] * st["losses"]["chamfer"]
+    if "reg_betas" in st["losses"]:
+        loss = loss + F.mse_loss(betas, o_betas) * st["losses"]["reg_betas"]
+    return loss, out, z_root
+
+
+def find_best_part_fits(markers, pose_body, betas, root_orient, marker_labels, smpl_inference, hierarchy, config,
+                        trace: Optional[dict] = None):
+    """markers/markers_utils.py:274-638, mode "cluster"."""
+    st = config["stages"]["part"]
+    if st["mode"] != "cluster":
+        raise NotImplementedError("part.mode 'network' needs checkpoints the reference does not ship")
+    labels_mode = torch.mode(marker_labels, axis=0)[0]
+    groups = [x.tolist() for x in torch.unique(labels_mode, return_counts=True)]
+    chain = groups[0]
+    final_labels = torch.zeros_like(marker_labels)
+    final_weights = torch.zeros_like(marker_labels, dtype=torch.float)
+    num_frames = markers.shape[0]
+    o_betas = betas
+
+    indices = torch.cat([torch.where(labels_mode == j)[0] for j in chain], dim=0)
+    markers_subset = markers[:, indices]
+    if st.get("use_full_skeleton"):
+        subtrees = [np.arange(0, hierarchy.shape[0]).tolist()]
+    else:
+        subtrees = get_sub_hierarchies(hierarchy, len(chain))
+        if "similarity_threshold" in st:
+            subtrees = remove_approximately_redundant_hierarchies(subtrees, similarity_threshold=0.9)
+
+    weights = smpl_inference.get_lbs_weights()
+    vertex_labels = torch.argmax(weights, dim=-1)
+    best = {"distance": np.inf}
+    subtree_losses = []
+    for subtree in subtrees:
+        z_angle = torch.zeros((1, 1, 1), device=markers.device).requires_grad_(True)
+        trans = torch.median(markers, dim=1)[0].clone().requires_grad_(True)
+        betas_s = o_betas.clone().requires_grad_(True)
+        opt = _lbfgs([z_angle, trans, betas_s], st["num_iters"], config, lr=1.0)
+        vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+        evals = []
+
+        def closure():
+            opt.zero_grad()
+            loss, _, _ = part_stage_loss(markers_subset, pose_body, betas_s, o_betas, root_orient, trans, z_angle,
+                                         vertex_indices, smpl_inference, config)
+            loss.backward()
+            evals.append(float(loss))
+            return loss
+
+        opt.step(closure)
+        with torch.no_grad():
+            _, out, z_root = part_stage_loss(markers_subset, pose_body, betas_s, o_betas, root_orient, trans,
+                                             z_angle, vertex_indices, smpl_inference, config)
+            verts_sub = out["vertices"][:, vertex_indices]
+            distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
+        subtree_losses.append([subtree, distance])
+        if trace is not None:
+            trace.setdefault("evals", []).append(evals)
+            trace.setdefault("distance", []).append(distance)
+        if distance < best["distance"]:
+            best = {
+                "distance": distance, "betas": betas_s.clone(), "markers_subset": markers_subset.clone(),
+                "root_orient": z_root.clone(), "trans": trans.clone(),
+                "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
+            }
+            with torch.no_grad():
+                for i in range(indices.shape[0]):
+                    m_i = indices[i]
+                    d = torch.norm(out["vertices"] - markers_subset[:, [i]], dim=-1)
+                    final_labels[:, m_i] = vertex_labels[torch.argmin(torch.mean(d, dim=0), dim=-1)]
+
+    if len(subtree_losses) > 1:
+        subtree_losses = sorted(subtree_losses, key=lambda x: x[1])
+        for i in range(indices.shape[0]):
+            final_weights[:, indices[i]] = subtree_losses[1][1] / subtree_losses[0][1]
+            if indices.shape[0] == 1:
+                final_weights *= 0
+    final_weights = final_weights / torch.max(final_weights)
+    return {
+        "betas": best["betas"].clone(), "marker_labels": final_labels.clone(),
+        "markers_subset": best["markers_subset"].clone(), "marker_weights": final_weights.clone(),
+        "root_orient": best["root_orient"].clone(), "trans": best["trans"].clone(),
+        "aabb_volume_ratio": best["aabb"].clone(),
+        "chain": np.array(list(subtree_losses[0][0]), dtype=np.int32),
+    }
+
+
+# ----------------------------------------------------------------------------------------------
+# orchestrator
+# ----------------------------------------------------------------------------------------------
+
+def multimodal_video_mocap(img_smpl, mocap_markers, smpl_inference, config, device=torch.device("cpu"),
+                           stats: Optional[dict] = None) -> Dict:
+    """multimodal.py:38-710 for equal mocap/video frame rates, offset 0, reprojection and root stages off."""
+    if mocap_markers.get_frequency() != img_smpl.freq:
+        raise NotImplementedError("frame-rate resampling (multimodal.py:145-182) is outside the restated path")
+    for key in ("reprojection_part", "reprojection_full", "root"):
+        if config["stages"][key]["num_iters"] > 0:
+            raise NotImplementedError("stage %s is disabled in every shipped config" % key)
+    stats = stats if stats is not None else {}
+    o_trans = img_smpl.trans.clone().detach().to(device)
+    o_root_orient = img_smpl.root_orient.clone().detach().to(device)
+    o_pose_body = img_smpl.pose_body.clone().detach().to(device)
+    o_betas = torch.sum(img_smpl.betas, dim=0, keepdim=True).clone().detach().to(device)
+    o_betas = o_betas / torch.sum(img_smpl.img_mask)
+    img_mask = img_smpl.img_mask.to(device)
+
+    trans = o_trans.clone().detach().requires_grad_(True)
+    root_orient = o_root_orient.clone().detach().requires_grad_(True)
+    markers = torch.from_numpy(mocap_markers.get_points()).float().to(device)
+    markers = torch.nan_to_num(markers, nan=0)
+    n = min(markers.shape[0], trans.shape[0])
+    markers, o_trans, o_root_orient, o_pose_body = markers[:n], o_trans[:n], o_root_orient[:n], o_pose_body[:n]
+    trans, root_orient = trans[:n], root_orient[:n]
+    num_frames = n
+
+    with torch.no_grad():
+        groups = segment_rigid(markers.detach().cpu().numpy())
+        seg = torch.zeros((markers.shape[:2]))
+        for gi, g in enumerate(groups):
+            seg[:, g] = gi
+        seg = seg.long().to(device)
+    mean_out = smpl_inference(poses=o_pose_body, betas=o_betas * 0, root_orient=o_root_orient, trans=o_trans * 0)
+    aabb_ratio = torch.median(get_aabb_volume(get_aabb(markers)) / get_aabb_volume(get_aabb(mean_out["vertices"])))
+
+    filter_output = None
+    if config["find_best_part_fits"]:
+        trans = torch.median(markers, dim=1)[0].requires_grad_(True)
+        root_orient = o_root_orient.clone().requires_grad_(True)
+        betas = o_betas.clone().requires_grad_(True)
+        tr = {}
+        filter_output = find_best_part_fits(markers, o_pose_body, o_betas, o_root_orient, seg, smpl_inference,
+                                            smpl_inference.smpl.parents, config, trace=tr)
+        stats["part"] = tr
+        seg = filter_output["marker_labels"].detach().clone()
+        root_orient = filter_output["root_orient"].detach().clone()
+        trans = filter_output["trans"].detach().clone()
+        betas = filter_output["betas"].detach().clone()
+    marker_labels = seg.detach().cpu().numpy()
+    if not config["find_best_part_fits"] or aabb_ratio > 0.4:
+        trans = torch.median(markers, dim=1)[0].requires_grad_(True)
+        root_orient = o_root_orient.clone().requires_grad_(True)
+        betas = o_betas.clone().requires_grad_(True)
+
+    pose_body = o_pose_body.clone().requires_grad_(True)
+    root_orient = root_orient.detach()
+    chamfer_rot, marker_rot = {}, {}
+    angles = torch.arange(0, 2 * np.pi, (2 * np.pi) / config["num_root_orient_angles"]).tolist()
+    run_chamfer = config["stages"]["chamfer"]["num_iters"] > 0
+    run_marker = config["stages"]["marker"]["num_iters"] > 0
+    for angle in angles:
+        a = torch.tensor([[[angle]]]).float().to(device)
+        z_root = compute_root_orient_z(torch.repeat_interleave(a, repeats=root_orient.shape[0], dim=0)) @ \
+            root_orient.clone().detach()
+        z_root = z_root.clone().detach().requires_grad_(True)
+        trans_a = trans.clone().detach().requires_grad_(True)
+        pose_a = pose_body.clone().detach().requires_grad_(True)
+        betas_a = betas.clone().detach().requires_grad_(True)
+        if run_chamfer:
+            tr = []
+            optim_chamfer(markers, pose_a, o_pose_body, betas_a, o_betas, z_root, trans_a, smpl_inference, config,
+                          trace=tr)
+            stats.setdefault("chamfer", []).append(tr)
+        chamfer_rot[angle] = {
+            "trans": trans_a.clone().detach().cpu().numpy(),
+            "root_orient": normalize_rot(z_root).clone().detach().cpu().numpy(),
+            "betas": betas_a[0].clone().detach().cpu().numpy(),
+            "pose_body": normalize_rot(pose_a).clone().detach().cpu().numpy(),
+        }
+        if run_marker:
+            one_hot = compute_nearest_points(markers, pose_a, betas_a, z_root, trans_a, smpl_inference, img_mask,
+                                             config)
+            z_root = z_root.clone().detach().requires_grad_(True)
+            pose_a = pose_a.clone().detach().requires_grad_(True)
+            tr = []
+            optim_markers(markers, pose_a, o_pose_body, betas_a, o_betas, z_root, trans_a, one_hot, smpl_inference,
+                          config, trace=tr)
+            stats.setdefault("marker", []).append(tr)
+        z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
+        pose_a = normalize_rot(pose_a).clone().detach().requires_grad_(True)
+        marker_rot[angle] = {
+            "trans": trans_a.clone().detach().cpu().numpy(),
+            "root_orient": z_root.clone().detach().cpu().numpy(),
+            "betas": betas_a[0].clone().detach().cpu().numpy(),
+            "pose_body": pose_a.clone().detach().cpu().numpy(),
+        }
+
+    best_val, best_angle = np.inf, None
+    yaw_scores = []
+    for angle in angles:
+        r = marker_rot[angle]
+        ab = torch.repeat_interleave(torch.from_numpy(r["betas"]).to(device)[None], dim=0,
+                                     repeats=r["pose_body"].shape[0])
+        with torch.no_grad():
+            verts = smpl_inference(poses=torch.from_numpy(r["pose_body"]).to(device), betas=ab,
+                                   root_orient=torch.from_numpy(r["root_orient"]).to(device),
+                                   trans=torch.from_numpy(r["trans"]).to(device))["vertices"]
+            c = weighted_chamfer_distance(markers, verts, get_marker_mask(markers), single_directional=True)[0]
+        yaw_scores.append(float(c))
+        if c < best_val:
+            best_val, best_angle = c, angle
+    stats["yaw_scores"] = yaw_scores
+    stats["best_angle"] = best_angle
+    smpl_marker = marker_rot[best_angle]
+    root_orient = torch.from_numpy(smpl_marker["root_orient"]).to(device).requires_grad_(True)
+    trans = torch.from_numpy(smpl_marker["trans"]).to(device).requires_grad_(True)
+    pose_body = torch.from_numpy(smpl_marker["pose_body"]).to(device).requires_grad_(True)
+    betas = torch.from_numpy(smpl_marker["betas"][None]).to(device).requires_grad_(True)
+
+    for _ in range(config["stage_repeats"]):
+        pose_stage = torch.clone(pose_body).detach().requires_grad_(False)
+        if run_marker:
+            one_hot = compute_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_inference, img_mask,
+                                             config)
+            root_orient = root_orient.clone().detach().requires_grad_(True)
+            pose_body = pose_body.clone().detach().requires_grad_(True)
+            tr = []
+            optim_markers(markers, pose_body, pose_stage, betas, o_betas, root_orient, trans, one_hot,
+                          smpl_inference, config, trace=tr)
+            stats.setdefault("marker_final", []).append(tr)
+        root_orient = normalize_rot(root_orient).clone().detach().requires_grad_(True)
+        pose_body = normalize_rot(pose_body).clone().detach().requires_grad_(True)
+
+    output = {
+        "trans": trans.detach().cpu(),
+        "root_orient": normalize_rot(root_orient).detach().cpu(),
+        "pose_body": normalize_rot(pose_body).detach().cpu(),
+        "betas": torch.repeat_interleave(torch.mean(betas, dim=0, keepdim=True), dim=0,
+                                         repeats=pose_body.shape[0]).detach().cpu(),
+        "mocap_frame_rate": mocap_markers.get_frequency(),
+        "markers_labels": marker_labels,
+        "stages": {"chamfer": chamfer_rot[best_angle], "marker": smpl_marker},
+    }
+    if filter_output is not None:
+        output["chain"] = filter_output["chain"]
+    return output
