@@ -1,0 +1,154 @@
+/* libuuo_hip.so -- C ABI of the MI355X (gfx950) SMPL-to-marker fitting hot path.
+ *
+ * The reference (NicholasMilef/UUO-Mocap) is pure Python and has no FFI layer; its boundary for this
+ * path is a set of Python callables.  This header is the C-ABI a binding for those
+ * callables sits on: plain pointers and sizes, no torch types.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference checkout).  The Python mirror of the
+ * reference's operator surface (the uuo_mocap_amd package) binds these symbols with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative errno-style code otherwise; the message for the
+ *    calling thread is available from uuo_last_error().
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Nothing synchronises the
+ *    device unless the comment says so; no hidden allocation happens inside the *_eval / kernel-only
+ *    calls (they use the workspace created by uuo_fit_create).
+ *  - pointers named `d_*` are device pointers (HBM), `h_*` host pointers.  All floats are fp32,
+ *    row-major, contiguous.  Rotations are 3x3 row-major (9 floats).
+ *  - the library owns no threads and keeps no global state besides the last-error string.
+ */
+#ifndef UUO_HIP_H
+#define UUO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UUO_NUM_JOINTS 24
+#define UUO_NUM_BETAS 10
+#define UUO_NUM_POSE_FEATS 207
+#define UUO_NUM_EXTRA_JOINTS 21
+
+typedef struct uuo_model uuo_model_t; /* device copies of the SMPL tables */
+typedef struct uuo_fit uuo_fit_t;     /* per-sequence workspace (F frames, M markers) */
+
+const char* uuo_last_error(void);
+int uuo_abi_version(void);
+
+/* ---- model ------------------------------------------------------------------------------------
+ * Replaces smplx.create("./body_models/", model_type="smpl", gender="neutral", batch_size=1) as used
+ * by SmplInference.__init__ (src/video_mocap/utils/smpl.py:22-27).  Host arrays in smplx's layouts:
+ * v_template [V,3], shapedirs [V,3,10], posedirs [207,V*3], J_regressor [24,V], lbs_weights [V,24],
+ * parents [24] (parents[0] ignored), extra_joint_vids [21] (VertexJointSelector ids). */
+int uuo_model_create(const float* h_v_template, const float* h_shapedirs, const float* h_posedirs,
+                     const float* h_J_regressor, const float* h_lbs_weights, const int64_t* h_parents,
+                     const int64_t* h_extra_joint_vids, int num_verts, uuo_model_t** out);
+int uuo_model_destroy(uuo_model_t* model);
+int uuo_model_num_verts(const uuo_model_t* model);
+
+/* ---- SMPL forward (materialising) ---------------------------------------------------------------
+ * Replaces SmplInference.forward (src/video_mocap/utils/smpl.py:29-50) = smplx SMPL.forward with
+ * pose2rot=False: d_poses [F,23,9], d_betas [betas_rows,10] with betas_rows in {1,F}, d_root [F,9],
+ * d_trans [F,3] or NULL.  Outputs d_verts [F,V,3] and d_joints [F,45,3] (either may be NULL). */
+int uuo_smpl_forward(uuo_model_t* model, void* stream, int F, const float* d_poses, const float* d_betas,
+                     int betas_rows, const float* d_root, const float* d_trans, float* d_verts,
+                     float* d_joints);
+
+/* ---- K=1 nearest neighbour ------------------------------------------------------------------------
+ * Replaces pytorch3d.ops.knn_points(K=1) as reached through pytorch3d.loss.chamfer_distance from
+ * weighted_chamfer_distance (src/video_mocap/losses/chamfer_distance.py:5-21) and
+ * markers_utils.py:471-475,575-579: for every query x[n,i] the first index of the minimum of
+ * ((dx*dx)+(dy*dy))+(dz*dz) over y[n,:] (separately rounded, no FMA).  d_x [N,P1,3], d_y [N,P2,3];
+ * d_y_subset (optional, [P2s] int32) restricts/reorders the candidates: candidate c is
+ * y[n, d_y_subset[c]] and the reported index is c.  Outputs d_dist [N,P1], d_idx [N,P1] (int32). */
+int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y,
+                  const int32_t* d_y_subset, int P2s, float* d_dist, int32_t* d_idx, void* d_workspace_u64);
+
+/* ---- marker placement -----------------------------------------------------------------------------
+ * Replaces compute_nearest_points (src/video_mocap/optimization.py:402-642; use_mean, granularity
+ * "full"): idx[m] = argmin_v mean_{f valid} ||verts[f,v]-markers[f,m]||, numpy fp32 semantics
+ * (sequential-in-f accumulation, first index).  d_valid [F] uint8.  Output d_idx [M] int32. */
+int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const float* d_verts, const float* d_markers,
+                           const uint8_t* d_valid, int32_t* d_idx, void* d_workspace_u64);
+
+/* ---- stage problems -------------------------------------------------------------------------------
+ * One closure evaluation (forward + backward) of the three L-BFGS stages, on flat parameter vectors
+ * packed exactly as the reference hands them to torch.optim.LBFGS:
+ *   UUO_STAGE_CHAMFER  closure_stage_chamfer   (optimization.py:187-275)  x = [trans 3F | z F | betas 10 | pose 207F]
+ *   UUO_STAGE_MARKER   closure_stage_marker_pose (optimization.py:329-394) x = [pose 207F | betas 10 | root 9F | trans 3F]
+ *   UUO_STAGE_PART     closure_fit_subtree     (markers/markers_utils.py:454-562) x = [z 1 | trans 3F | betas 10]
+ */
+enum { UUO_STAGE_CHAMFER = 0, UUO_STAGE_MARKER = 1, UUO_STAGE_PART = 2 };
+
+typedef struct {
+  int32_t stage;             /* UUO_STAGE_* */
+  int32_t F, M;              /* frames, markers */
+  const float* d_markers;    /* [F,M,3]; exact zeros = missing (optimization.py:703-715) */
+  const float* d_o_pose;     /* [F,23,9]: prior target (chamfer, marker) / the fixed body pose (part) */
+  const float* d_o_betas;    /* [10] prior target */
+  const float* d_root;       /* [F,9] fixed root orientation (chamfer, part); unused for marker */
+  const int32_t* d_assign;   /* marker stage: [M] vertex id per marker column */
+  const int32_t* d_subset;   /* part stage: [n_subset] vertex ids (candidate order = tie order) */
+  int32_t n_subset;
+  float w_data;              /* full_chamfer / marker / chamfer weight */
+  float w_pose;              /* reg_pose_body weight (0 = term absent) */
+  float w_betas;             /* reg_betas weight (0 = term absent) */
+  float marker_distance;     /* MARKER_DISTANCE, utils/settings.py:1 */
+} uuo_problem_t;
+
+int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out);
+int uuo_fit_destroy(uuo_fit_t* fit);
+/* number of parameters of a stage at (F): 211F+10 / 219F+10 / 3F+11 */
+int uuo_problem_num_params(const uuo_problem_t* p);
+
+/* One closure evaluation at d_x: writes loss to d_loss[0] and the flat gradient to d_grad.
+ * d_nn_idx (optional, [F,M] int32) receives the nearest-vertex assignment of the chamfer/part data term
+ * (vertex ids for chamfer, candidate positions for part).  Asynchronous on `stream`. */
+int uuo_closure_eval(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, float* d_loss,
+                     float* d_grad, int32_t* d_nn_idx);
+
+/* ---- L-BFGS ----------------------------------------------------------------------------------------
+ * Replaces torch.optim.LBFGS(params, max_iter, tolerance_grad, tolerance_change, lr,
+ * line_search_fn="strong_wolfe").step(closure) as constructed at optimization.py:176-183,319-326 and
+ * markers/markers_utils.py:428-435 (history 100, max_eval = max_iter*5/4, c1 1e-4, c2 0.9; torch 2.10
+ * semantics incl. max_ls = max_eval - evals).  d_x is updated in place.  Synchronises `stream`
+ * (one small read-back per closure evaluation). */
+typedef struct {
+  int32_t max_iter;
+  int32_t history_size;     /* 100 */
+  float lr;
+  float tolerance_grad;
+  float tolerance_change;
+  int32_t max_eval;         /* <=0: max_iter*5/4 */
+  int32_t verbose;          /* print "<name> <iteration> <loss>" per closure like the reference's verbose flag */
+} uuo_lbfgs_options_t;
+
+typedef struct {
+  int32_t n_iter;
+  int32_t n_eval;
+  float first_loss;
+  float final_loss;
+  int32_t stop_reason;      /* 0 max_iter, 1 max_eval, 2 grad tol, 3 step tol, 4 loss tol, 5 gtd, 6 initial grad tol */
+  float device_ms;          /* HIP-event time of the whole solve */
+} uuo_lbfgs_stats_t;
+
+/* optional per-closure callback (mirrors iter_fn / verbose prints): called on the host after each
+ * closure evaluation with (user, evaluation index, loss). */
+typedef void (*uuo_eval_callback_t)(void* user, int eval_index, float loss);
+
+int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                    const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
+                    void* cb_user);
+
+/* ---- benchmarking helpers (used by bench.py for the roofline object) -------------------------------
+ * average device milliseconds per closure evaluation over `iters` back-to-back evaluations, measured with
+ * HIP events on `stream`; optionally only the dominant kernel (skin + nearest-neighbour). */
+int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, int iters,
+                     int dominant_kernel_only, float* ms_per_eval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UUO_HIP_H */

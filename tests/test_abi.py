@@ -1,0 +1,94 @@
+"""CPU-side checks of the C-ABI library and the host mirror (no kernels are launched)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from uuo_mocap_amd import _lib
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = _lib.load()
+    names = _lib.header_symbols()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), name
+    assert lib.uuo_abi_version() == 1
+    assert set(_lib._SIGNATURES) == set(names), "ctypes signature table and include/uuo_hip.h disagree"
+
+
+def test_problem_sizes_follow_the_reference_packing():
+    lib = _lib.load()
+    for stage, per_frame, const in ((_lib.UUO_STAGE_CHAMFER, 211, 10), (_lib.UUO_STAGE_MARKER, 219, 10),
+                                    (_lib.UUO_STAGE_PART, 3, 11)):
+        for F in (1, 30, 300):
+            p = _lib.UuoProblem()
+            p.stage, p.F, p.M = stage, F, 50
+            assert lib.uuo_problem_num_params(ctypes.byref(p)) == per_frame * F + const
+    p = _lib.UuoProblem()
+    p.stage, p.F = 7, 10
+    assert lib.uuo_problem_num_params(ctypes.byref(p)) < 0
+
+
+def test_null_arguments_are_rejected_with_a_message():
+    lib = _lib.load()
+    rc = lib.uuo_model_create(None, None, None, None, None, None, None, 6890, ctypes.byref(ctypes.c_void_p()))
+    assert rc != 0
+    assert b"null" in lib.uuo_last_error()
+
+
+def test_no_cpu_fallback():
+    from uuo_mocap_amd.smpl import SmplInference
+
+    with pytest.raises(RuntimeError, match="GPU only"):
+        SmplInference(torch.device("cpu"))
+
+
+def test_product_does_not_import_the_oracle():
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "uuo_mocap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+
+
+def test_pad_and_masks():
+    from uuo_mocap_amd.multimodal import pad
+    from uuo_mocap_amd.optimization import get_marker_mask
+
+    x = torch.arange(12.0).reshape(4, 3)
+    assert pad(x, 0) is x
+    assert torch.equal(pad(x, 2)[:2], x[[0, 0]]) and pad(x, 2).shape[0] == 6
+    assert torch.equal(pad(x, -1)[-1], x[-1]) and pad(x, -1).shape[0] == 5
+    m = torch.tensor([[[0.0, 0, 0], [1, -1, 0]], [[0, 0, 1e-9], [0, 0, 0]]])
+    assert get_marker_mask(m).tolist() == [[False, True], [True, False]]
+
+
+def test_transforms_match_oracle():
+    from oracle import p3d_ref
+    from uuo_mocap_amd import transforms as T
+
+    torch.manual_seed(0)
+    m = torch.randn(7, 3, 3)
+    torch.testing.assert_close(T.normalize_rot(m), p3d_ref.rotation_6d_to_matrix(p3d_ref.matrix_to_rotation_6d(m)))
+    a = torch.tensor([[[0.0]], [[0.7]], [[-2.5]], [[3e-7]]])
+    z = torch.zeros(4, 1, 3)
+    z[..., 2:] = a
+    torch.testing.assert_close(T.compute_root_orient_z(a), p3d_ref.axis_angle_to_matrix(z))
+
+
+def test_segment_rigid_and_subtrees_match_oracle(tables):
+    from oracle import stages_ref
+    from uuo_mocap_amd import markers_utils as MU
+    from uuo_mocap_amd.synthetic import make_sequence
+
+    pts = make_sequence(tables, seed=9, num_frames=20, num_markers=14).markers.get_points()
+    assert MU.segment_rigid(pts) == stages_ref.segment_rigid(pts)
+    for k in (2, 5, 12, 24):
+        assert MU.get_sub_hierachies(tables.parents, k) == stages_ref.get_sub_hierarchies(tables.parents, k)

@@ -1,0 +1,442 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every kernel behind the C ABI against the CPU oracle on the
+same seeded inputs, the golden fixtures captured from the reference's own modules, and size-independent
+properties at the BASELINE size (F=300, M=50)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import p3d_ref, stages_ref  # noqa: E402
+from uuo_mocap_amd.config import packaged_config  # noqa: E402
+from uuo_mocap_amd.synthetic import make_sequence  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def smpl(tables, dev):
+    from uuo_mocap_amd.smpl import SmplInference
+
+    return SmplInference(dev, tables=tables)
+
+
+def _t(x, dev=None):
+    t = torch.from_numpy(np.asarray(x)).clone()
+    return t.to(dev) if dev is not None else t
+
+
+def test_native_library_loaded():
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+    assert lib.uuo_abi_version() == 1
+    assert any("libuuo_hip.so" in line for line in open("/proc/self/maps"))
+
+
+# ------------------------------------------------------------------------------------------------ SMPL forward
+@pytest.mark.parametrize("F,shared_betas", [(8, False), (45, True), (70, False)])
+def test_smpl_forward_matches_oracle(smpl, oracle_smpl, tables, dev, F, shared_betas):
+    """vertices within 1e-4 m (north_star tolerance); observed ~1e-6."""
+    g = torch.Generator().manual_seed(F)
+    rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
+    betas = torch.randn(1 if shared_betas else F, 10, generator=g)
+    trans = torch.randn(F, 3, generator=g)
+    ref = oracle_smpl(rot[:, 1:], betas.expand(F, 10) if shared_betas else betas, rot[:, :1], trans)
+    out = smpl(rot[:, 1:].to(dev), (betas.expand(F, 10) if shared_betas else betas).to(dev), rot[:, :1].to(dev),
+               trans.to(dev))
+    assert out["vertices"].shape == (F, 6890, 3) and out["joints"].shape == (F, 45, 3)
+    dv = (out["vertices"].cpu() - ref["vertices"]).abs().max().item()
+    dj = (out["joints"].cpu() - ref["joints"]).abs().max().item()
+    assert dv < 1e-4 and dj < 1e-4, (dv, dj)
+    assert dv < 2e-5, dv  # fp32 round-off level
+
+
+def test_smpl_forward_golden(smpl, golden, dev):
+    g = golden("smpl_forward.npz")
+    out = smpl(_t(g["hmr_pose_body"], dev), _t(g["hmr_betas"], dev), _t(g["hmr_root_orient"], dev), _t(g["trans0"], dev))
+    np.testing.assert_allclose(out["vertices"].cpu().numpy()[:, ::int(g["vertex_stride"])], g["vertices"], atol=1e-4)
+    np.testing.assert_allclose(out["joints"].cpu().numpy(), g["joints"], atol=1e-4)
+
+
+def test_smpl_forward_rejects_bad_betas(smpl, dev):
+    with pytest.raises(ValueError, match="Betas array must have 10 beta values"):
+        smpl(torch.zeros(2, 23, 3, 3, device=dev), torch.zeros(2, 9, device=dev), torch.zeros(2, 1, 3, 3, device=dev),
+             torch.zeros(2, 3, device=dev))
+
+
+# ------------------------------------------------------------------------------------------------ nearest neighbour
+def test_nn_bit_exact_vs_cpu_loop(smpl, oracle_smpl, dev):
+    """assignment indices and squared distances bit-exact against pytorch3d's CPU loop semantics."""
+    rng = np.random.default_rng(0)
+    seq = make_sequence(smpl.tables, seed=4, num_frames=6, num_markers=50)
+    gt = seq.gt
+    verts = oracle_smpl(_t(gt["rot"][:, 1:]), _t(gt["betas"]).repeat(6, 1), _t(gt["rot"][:, :1]), _t(gt["trans"]))[
+        "vertices"].numpy()
+    x = seq.markers.get_points().astype(np.float32)
+    verts[:, 4000] = verts[:, 17]  # exact duplicate vertices: the first index must win
+    x[:, 3] = verts[:, 17]
+    d_ref, i_ref = p3d_ref.knn1_loop(x, verts)
+    d, i = smpl.device_model.nn_argmin(_t(x, dev), _t(verts, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+    assert (i.cpu().numpy()[:, 3] == 17).all()
+    # ragged sizes: P1 > 64 (several query groups), tiny P2, candidate subset
+    a = rng.standard_normal((3, 130, 3)).astype(np.float32)
+    b = rng.standard_normal((3, 37, 3)).astype(np.float32)
+    d_ref, i_ref = p3d_ref.knn1_loop(a, b)
+    d, i = smpl.device_model.nn_argmin(_t(a, dev), _t(b, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+    sub = rng.permutation(37)[:20].astype(np.int32)
+    d_ref, i_ref = p3d_ref.knn1_loop(a, b[:, sub])
+    d, i = smpl.device_model.nn_argmin(_t(a, dev), _t(b, dev), y_subset=_t(sub, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+
+
+def test_weighted_chamfer_kat_and_backward(dev):
+    from uuo_mocap_amd.losses import weighted_chamfer_distance
+
+    x = torch.arange(0, 16 * 7 * 3).float().reshape(16, 7, 3).to(dev)
+    y = torch.arange(0, 16 * 19 * 3).float().reshape(16, 19, 3).to(dev)
+    w = torch.ones(16, 7, device=dev)
+    w[:, ::2] = 0
+    loss, aux = weighted_chamfer_distance(x, y, w)
+    assert aux is None and loss.item() == 287035.3125
+    xs = torch.randn(4, 9, 3, device=dev, requires_grad=True)
+    ys = torch.randn(4, 50, 3, device=dev, requires_grad=True)
+    ws = (torch.rand(4, 9, device=dev) > 0.3)
+    l, _ = weighted_chamfer_distance(xs, ys, ws)
+    l.backward()
+    xc, yc = xs.detach().cpu().requires_grad_(True), ys.detach().cpu().requires_grad_(True)
+    lr, _ = stages_ref.weighted_chamfer_distance(xc, yc, ws.cpu())
+    lr.backward()
+    np.testing.assert_allclose(l.item(), lr.item(), rtol=1e-6)
+    np.testing.assert_allclose(xs.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ys.grad.cpu().numpy(), yc.grad.numpy(), rtol=1e-5, atol=1e-7)
+    # all-missing markers -> 0 loss, like pytorch3d's weights.sum() == 0 branch
+    z, _ = weighted_chamfer_distance(xs, ys, torch.zeros(4, 9, device=dev))
+    assert z.item() == 0.0
+
+
+def test_marker_placement_bit_exact(smpl, oracle_smpl, dev):
+    """compute_nearest_points: indices bit-exact against the numpy-semantics C restatement, incl. masked frames."""
+    import ctypes
+
+    seq = make_sequence(smpl.tables, seed=6, num_frames=12, num_markers=9)
+    gt = seq.gt
+    verts = oracle_smpl(_t(gt["rot"][:, 1:]), _t(gt["betas"]).repeat(12, 1), _t(gt["rot"][:, :1]), _t(gt["trans"]))[
+        "vertices"].numpy()
+    markers = seq.markers.get_points().astype(np.float32)
+    valid = np.ones(12, dtype=np.uint8)
+    valid[[2, 7]] = 0
+    lib = p3d_ref._load_knn_c()
+    out_idx = np.zeros(9, dtype=np.int64)
+    lib.assign_mean_argmin_cpu.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_void_p] * 2
+    lib.assign_mean_argmin_cpu(verts.ctypes.data, markers.ctypes.data, valid.ctypes.data, 12, 9, 6890,
+                               out_idx.ctypes.data, None)
+    idx = smpl.device_model.assign_mean_argmin(_t(verts, dev), _t(markers, dev), _t(valid.astype(bool), dev))
+    np.testing.assert_array_equal(idx.cpu().numpy(), out_idx)
+
+
+def test_compute_nearest_points_golden(smpl, golden, dev):
+    from uuo_mocap_amd.optimization import compute_nearest_points
+
+    g = golden("marker_stage.npz")
+    cfg = packaged_config("video_mocap")
+    one_hot = compute_nearest_points(
+        markers=_t(g["markers"], dev), pose_body=_t(g["in_pose_body"], dev), betas=_t(g["in_betas"], dev),
+        root_orient=_t(g["in_root_orient"], dev), trans=_t(g["in_trans"], dev), smpl_inference=smpl,
+        marker_labels=None, granularity="full", img_mask=_t(g["img_mask"], dev), device=dev, config=cfg,
+        window_size=1, use_velocity=False)
+    assert one_hot.shape == (g["markers"].shape[1], 6890) and one_hot.dtype == torch.float32
+    np.testing.assert_array_equal(torch.argmax(one_hot, dim=-1).cpu().numpy(), g["place_idx"])
+
+
+# ------------------------------------------------------------------------------------------------ closures
+def _rel_err(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_chamfer_closure_matches_oracle_and_golden(smpl, oracle_smpl, golden, dev):
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    g = golden("chamfer_stage.npz")
+    cfg = packaged_config("video_mocap")
+    F = g["markers"].shape[0]
+    prob = ChamferProblem(smpl, _t(g["markers"], dev), _t(g["hmr_pose_body"], dev), _t(g["o_betas"], dev),
+                          _t(g["hmr_root_orient"], dev), cfg)
+    x = _t(g["first_params"], dev).contiguous()
+    assert x.numel() == prob.n == 211 * F + 10
+    loss, grad, nn = prob.evaluate(x)
+    np.testing.assert_allclose(loss, g["losses"][0], rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), g["first_grad"]) < 2e-4
+    np.testing.assert_allclose(grad.cpu().numpy(), g["first_grad"], rtol=5e-3, atol=2e-6)
+    # perturbed point (non-trivial yaw, shape and pose) against the oracle's autograd
+    gen = torch.Generator().manual_seed(3)
+    xp = x.cpu() + 0.05 * torch.randn(x.numel(), generator=gen)
+    trans, z, betas, pose = (xp[:3 * F].reshape(F, 3), xp[3 * F:4 * F].reshape(F, 1, 1), xp[4 * F:4 * F + 10].reshape(1, 10),
+                             xp[4 * F + 10:].reshape(F, 23, 3, 3))
+    leaves = [t.clone().requires_grad_(True) for t in (trans, z, betas, pose)]
+    lo, out = stages_ref.chamfer_stage_loss(_t(g["markers"]), leaves[3], _t(g["hmr_pose_body"]), leaves[2],
+                                            _t(g["o_betas"]), _t(g["hmr_root_orient"]), leaves[0], leaves[1],
+                                            oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([t.grad.reshape(-1) for t in leaves]).numpy()
+    loss, grad, nn = prob.evaluate(xp.to(dev).contiguous())
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
+    # assignment indices: bit-exact against the CPU loop on the oracle's vertices
+    _, i_ref = p3d_ref.knn1_loop(g["markers"].astype(np.float32), out["vertices"].detach().numpy())
+    flips = int((nn.cpu().numpy() != i_ref).sum())
+    assert flips == 0, "%d of %d assignments differ (near-ties from the MFMA vertex path)" % (flips, i_ref.size)
+
+
+def test_marker_closure_matches_oracle_and_golden(smpl, oracle_smpl, golden, dev):
+    from uuo_mocap_amd.engine import MarkerProblem
+
+    g = golden("marker_stage.npz")
+    cfg = packaged_config("video_mocap")
+    F = g["markers"].shape[0]
+    prob = MarkerProblem(smpl, _t(g["markers"], dev), _t(g["o_pose_body"], dev), _t(g["o_betas"], dev),
+                         _t(g["place_idx"], dev), cfg)
+    x = _t(g["first_params"], dev).contiguous()
+    assert x.numel() == prob.n == 219 * F + 10
+    loss, grad, _ = prob.evaluate(x)
+    np.testing.assert_allclose(loss, g["losses"][0], rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), g["first_grad"]) < 2e-4
+    np.testing.assert_allclose(grad.cpu().numpy(), g["first_grad"], rtol=5e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("tag,cfg_name", [("full", "hmr_full"), ("tree", "hmr_part")])
+def test_part_closure_matches_oracle(smpl, oracle_smpl, golden, dev, tag, cfg_name):
+    from uuo_mocap_amd.engine import PartProblem
+
+    g = golden("part_stage_%s.npz" % tag)
+    cfg = packaged_config(cfg_name)
+    markers = _t(g["markers"])
+    F = markers.shape[0]
+    seg = _t(g["seg"])
+    labels_mode = torch.mode(seg, axis=0)[0]
+    chain = torch.unique(labels_mode).tolist()
+    indices = torch.cat([torch.where(labels_mode == j)[0] for j in chain], dim=0)
+    markers_subset = markers[:, indices]
+    vertex_labels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    if tag == "full":
+        subtree = list(range(24))
+    else:
+        subtree = stages_ref.remove_approximately_redundant_hierarchies(
+            stages_ref.get_sub_hierarchies(smpl.tables.parents, len(chain)))[0]
+    vidx = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+    z = torch.full((1, 1, 1), 0.3, requires_grad=True)
+    trans = (torch.median(markers, dim=1)[0] + 0.01).clone().requires_grad_(True)
+    betas = (_t(g["o_betas"]) + 0.2).clone().requires_grad_(True)
+    lo, out, _ = stages_ref.part_stage_loss(markers_subset, _t(g["hmr_pose_body"]), betas, _t(g["o_betas"]),
+                                            _t(g["hmr_root_orient"]), trans, z, vidx, oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([t.grad.reshape(-1) for t in (z, trans, betas)]).numpy()
+    prob = PartProblem(smpl, markers_subset.to(dev), _t(g["hmr_pose_body"], dev), _t(g["o_betas"], dev),
+                       _t(g["hmr_root_orient"], dev), vidx.to(dev), cfg)
+    x = prob.pack(z.detach().to(dev), trans.detach().to(dev), betas.detach().to(dev))
+    assert prob.n == 3 * F + 11
+    loss, grad, nn = prob.evaluate(x)
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
+    _, i_ref = p3d_ref.knn1_loop(markers_subset.numpy(), out["vertices"][:, vidx].detach().numpy())
+    assert int((nn.cpu().numpy() != i_ref).sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("kind,n,lr", [(0, 300, 1.0), (1, 40, 1.0), (0, 5000, 0.1)])
+def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
+    """device L-BFGS against torch.optim.LBFGS (CPU) on a convex quadratic and chained Rosenbrock."""
+    import ctypes
+
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+
+    def objective(x):
+        if kind == 0:
+            a = 1.0 + 99.0 * torch.arange(n, dtype=torch.float32) / max(n - 1, 1)
+            b = torch.sin(0.37 * torch.arange(n, dtype=torch.float32))
+            return 0.5 * (a * (x - b) ** 2).sum()
+        return (100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2).sum()
+
+    x0 = torch.full((n,), -0.5) if kind == 1 else torch.zeros(n)
+    xt = x0.clone().requires_grad_(True)
+    opt = torch.optim.LBFGS([xt], max_iter=200, tolerance_grad=1e-7, tolerance_change=1e-9, lr=lr,
+                            line_search_fn="strong_wolfe")
+    evals = []
+
+    def closure():
+        opt.zero_grad()
+        l = objective(xt)
+        l.backward()
+        evals.append(float(l))
+        return l
+
+    opt.step(closure)
+    xd = x0.clone().to(dev).contiguous()
+    o = _lib.UuoLbfgsOptions(200, 100, lr, 1e-7, 1e-9, 0, 0)
+    st = _lib.UuoLbfgsStats()
+    _lib.check(lib.uuo_lbfgs_selftest(None, kind, n, ctypes.c_void_p(xd.data_ptr()), ctypes.byref(o), ctypes.byref(st)),
+               "uuo_lbfgs_selftest")
+    f_ref = objective(xt.detach()).item()
+    f_dev = objective(xd.cpu()).item()
+    assert st.first_loss == pytest.approx(evals[0], rel=1e-5)
+    if kind == 0:
+        assert f_dev <= max(f_ref * 10, 1e-6), (f_dev, f_ref)
+        np.testing.assert_allclose(xd.cpu().numpy(), xt.detach().numpy(), atol=2e-3)
+    else:
+        assert f_dev <= max(5 * f_ref, 1e-3), (f_dev, f_ref)
+    # same algorithm -> comparable work
+    assert st.n_eval <= 2 * len(evals) + 10, (st.n_eval, len(evals))
+
+
+def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
+    """optim_chamfer on the golden inputs: the first iterations follow the reference's recorded trajectory and the
+    loss after the same number of iterations is at least as low (up to fp32 round-off)."""
+    from uuo_mocap_amd.optimization import LAST_STATS, optim_chamfer
+
+    g = golden("chamfer_stage.npz")
+    cfg = packaged_config("video_mocap")
+    cfg["stages"]["chamfer"]["num_iters"] = int(g["num_iters"])
+    pose = _t(g["hmr_pose_body"], dev).requires_grad_(True)
+    betas = _t(g["o_betas"], dev).requires_grad_(True)
+    root = _t(g["hmr_root_orient"], dev).requires_grad_(True)
+    trans = _t(g["trans0"], dev).requires_grad_(True)
+    optim_chamfer(_t(g["markers"], dev), pose, _t(g["hmr_pose_body"], dev), betas, _t(g["o_betas"], dev), root, trans,
+                  None, None, smpl, cfg)
+    st = LAST_STATS["chamfer"]
+    assert st["n_iter"] <= int(g["num_iters"])
+    assert abs(st["n_eval"] - len(g["losses"])) <= 5
+    np.testing.assert_allclose(st["first_loss"], g["losses"][0], rtol=2e-5)
+    assert st["final_loss"] <= g["losses"][-1] * 1.02
+    # parameters land where the reference's did (converged quantities, not bitwise trajectories)
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), g["out_trans"], atol=5e-3)
+    np.testing.assert_allclose(betas.detach().cpu().numpy(), g["out_betas"], atol=5e-2)
+    assert root.requires_grad and pose.requires_grad
+
+
+def test_marker_stage_solve_tracks_reference(smpl, golden, dev):
+    from uuo_mocap_amd.optimization import LAST_STATS, optim_markers
+
+    g = golden("marker_stage.npz")
+    cfg = packaged_config("video_mocap")
+    cfg["stages"]["marker"]["num_iters"] = int(g["num_iters"])
+    pose = _t(g["in_pose_body"], dev).requires_grad_(True)
+    betas = _t(g["in_betas"], dev).requires_grad_(True)
+    root = _t(g["in_root_orient"], dev).requires_grad_(True)
+    trans = _t(g["in_trans"], dev).requires_grad_(True)
+    one_hot = torch.zeros(g["markers"].shape[1], 6890, device=dev)
+    one_hot[torch.arange(one_hot.shape[0]), _t(g["place_idx"], dev).long()] = 1.0
+    optim_markers(_t(g["markers"], dev), pose, _t(g["o_pose_body"], dev), betas, _t(g["o_betas"], dev), root, trans,
+                  one_hot, _t(g["img_mask"], dev), smpl, cfg)
+    st = LAST_STATS["marker"]
+    np.testing.assert_allclose(st["first_loss"], g["losses"][0], rtol=2e-5)
+    assert st["final_loss"] <= g["losses"][-1] * 1.05
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), g["out_trans"], atol=5e-3)
+
+
+@pytest.mark.parametrize("tag,cfg_name", [("full", "hmr_full"), ("tree", "hmr_part")])
+def test_find_best_part_fits_matches_reference(smpl, golden, dev, tag, cfg_name):
+    from uuo_mocap_amd.markers_utils import LAST_STATS, find_best_part_fits
+
+    g = golden("part_stage_%s.npz" % tag)
+    cfg = packaged_config(cfg_name)
+    cfg["stages"]["part"]["num_iters"] = int(g["num_iters"])
+    out = find_best_part_fits(
+        markers=_t(g["markers"], dev), pose_body=_t(g["hmr_pose_body"], dev), betas=_t(g["o_betas"], dev),
+        root_orient=_t(g["hmr_root_orient"], dev), marker_labels=_t(g["seg"], dev), smpl_inference=smpl,
+        hierarchy=smpl.smpl.parents, joints_2d_gt=None, focal_length=None, reproject_mask=None, camera_center=None,
+        cam_trans=None, config=cfg)
+    assert len(LAST_STATS["part"]) == int(g["n_subtrees"])
+    np.testing.assert_allclose([s["first_loss"] for s in LAST_STATS["part"]], g["first_losses"], rtol=2e-5)
+    np.testing.assert_array_equal(out["chain"], g["out_chain"])
+    np.testing.assert_array_equal(out["marker_labels"].cpu().numpy(), g["out_marker_labels"])
+    np.testing.assert_allclose(out["trans"].cpu().numpy(), g["out_trans"], atol=5e-3)
+    np.testing.assert_allclose(out["root_orient"].cpu().numpy(), g["out_root_orient"], atol=5e-3)
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=5e-2)
+    np.testing.assert_allclose(out["aabb_volume_ratio"].cpu().numpy(), g["out_aabb"], rtol=1e-4)
+    assert out["marker_weights"].shape == g["out_marker_weights"].shape
+
+
+@pytest.mark.parametrize("tag,cfg_name", [("hmr_full", "hmr_full"), ("default", "video_mocap")])
+def test_end_to_end_matches_reference(smpl, oracle_smpl, golden, dev, tag, cfg_name):
+    """multimodal_video_mocap on the golden inputs: same stage structure, labels, chain, and final vertices close
+    to the reference's (trajectory chaos bounds how close a 15-iteration fit can be: SURVEY.md section 7)."""
+    from uuo_mocap_amd.multimodal import LAST_RUN_STATS, multimodal_video_mocap
+    from uuo_mocap_amd.synthetic import SyntheticImgSmpl, SyntheticMarkers
+
+    g = golden("e2e_%s.npz" % tag)
+    cfg = packaged_config(cfg_name)
+    for k, key in (("part", "part_iters"), ("chamfer", "chamfer_iters"), ("marker", "marker_iters")):
+        if cfg["stages"][k]["num_iters"] > 0:
+            cfg["stages"][k]["num_iters"] = int(g[key])
+    F = g["markers"].shape[0]
+    img = SyntheticImgSmpl(
+        trans=_t(g["hmr_trans"]), root_orient=_t(g["hmr_root_orient"]), hmr_root_orient=_t(g["hmr_root_orient"]),
+        pose_body=_t(g["hmr_pose_body"]), betas=_t(g["hmr_betas"]), foot_contacts=torch.zeros(F, 2),
+        camera_bbox=torch.zeros(F, 3), center=torch.zeros(F, 2), scale=torch.zeros(F, 1), size=torch.zeros(F, 2),
+        img_mask=_t(g["img_mask"]), freq=30.0)
+    out = multimodal_video_mocap(img, SyntheticMarkers(g["markers"].copy(), 30.0), dev, cfg, offset=0,
+                                 print_options=[], save_stages=True, smpl_inference=smpl)
+    n_solves = sum(len(LAST_RUN_STATS[k]) for k in ("part", "chamfer", "marker", "marker_final"))
+    assert n_solves == int(g["n_solves"])
+    assert sorted(out["stages"].keys()) == sorted(str(s) for s in g["stage_keys"])
+    for key, shape in (("trans", (F, 3)), ("root_orient", (F, 1, 3, 3)), ("pose_body", (F, 23, 3, 3)), ("betas", (F, 10))):
+        assert tuple(out[key].shape) == shape and out[key].device.type == "cpu"
+    np.testing.assert_array_equal(out["markers_labels"], g["out_markers_labels"])
+    np.testing.assert_array_equal(out["chain"], g["out_chain"])
+    ref_v = oracle_smpl(_t(g["out_pose_body"]), _t(g["out_betas"]), _t(g["out_root_orient"]), _t(g["out_trans"]))["vertices"]
+    our_v = oracle_smpl(out["pose_body"], out["betas"], out["root_orient"], out["trans"])["vertices"]
+    err = (ref_v - our_v).norm(dim=-1)
+    assert err.mean().item() < 5e-3, err.mean().item()
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE size
+def test_full_size_properties(smpl, dev):
+    """F=300, M=50 (BASELINE metric size): size-independent properties of the closure."""
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    seq = make_sequence(smpl.tables, seed=0, num_frames=300, num_markers=50)
+    cfg = packaged_config("video_mocap")
+    markers = _t(seq.markers.get_points(), dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    trans = torch.median(markers, dim=1)[0]
+    prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, cfg)
+    x = prob.pack(trans, torch.zeros(300, 1, 1, device=dev), o_betas, o_pose)
+    loss, grad, nn = prob.evaluate(x)
+    loss2, grad2, nn2 = prob.evaluate(x)
+    assert loss == loss2 and torch.equal(grad, grad2) and torch.equal(nn, nn2), "closure must be deterministic"
+    assert np.isfinite(loss) and torch.isfinite(grad).all()
+    # the reported nearest vertex really is the nearest: recompute all distances for a sample of frames in torch
+    verts = smpl(o_pose, o_betas.expand(300, 10), root, trans)["vertices"]
+    for f in (0, 137, 299):
+        diff = markers[f][:, None, :] - verts[f][None, :, :]
+        sq = diff * diff
+        d = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+        assert torch.equal(torch.argmin(d, dim=-1).int(), nn[f])
+    # directional derivative: f(x + h u) - f(x - h u) ~ 2 h g.u
+    gen = torch.Generator().manual_seed(0)
+    u = torch.randn(x.numel(), generator=gen).to(dev)
+    u = u / u.norm()
+    h = 1e-3
+    lp, _, _ = prob.evaluate((x + h * u).contiguous())
+    lm, _, _ = prob.evaluate((x - h * u).contiguous())
+    fd = (lp - lm) / (2 * h)
+    an = float((grad * u).sum())
+    assert abs(fd - an) <= 5e-2 * max(abs(an), 1e-3), (fd, an)
+    # a short solve decreases the loss monotonically over accepted iterates
+    st = prob.solve(x, max_iter=10, lr=0.1)
+    assert st["final_loss"] < st["first_loss"]

@@ -1,0 +1,103 @@
+"""ctypes binding of libuuo_hip.so (include/uuo_hip.h).  There is no CPU fallback: if the library is
+missing the import of any operator fails loudly."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuuo_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "uuo_hip.h")
+
+UUO_STAGE_CHAMFER, UUO_STAGE_MARKER, UUO_STAGE_PART = 0, 1, 2
+
+
+class UuoProblem(ctypes.Structure):
+    _fields_ = [
+        ("stage", c_int32), ("F", c_int32), ("M", c_int32),
+        ("d_markers", c_void_p), ("d_o_pose", c_void_p), ("d_o_betas", c_void_p), ("d_root", c_void_p),
+        ("d_assign", c_void_p), ("d_subset", c_void_p), ("n_subset", c_int32),
+        ("w_data", c_float), ("w_pose", c_float), ("w_betas", c_float), ("marker_distance", c_float),
+    ]
+
+
+class UuoLbfgsOptions(ctypes.Structure):
+    _fields_ = [
+        ("max_iter", c_int32), ("history_size", c_int32), ("lr", c_float), ("tolerance_grad", c_float),
+        ("tolerance_change", c_float), ("max_eval", c_int32), ("verbose", c_int32),
+    ]
+
+
+class UuoLbfgsStats(ctypes.Structure):
+    _fields_ = [
+        ("n_iter", c_int32), ("n_eval", c_int32), ("first_loss", c_float), ("final_loss", c_float),
+        ("stop_reason", c_int32), ("device_ms", c_float),
+    ]
+
+
+EVAL_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_float)
+
+_SIGNATURES = {
+    "uuo_last_error": (c_char_p, []),
+    "uuo_abi_version": (c_int, []),
+    "uuo_model_create": (c_int, [c_void_p] * 7 + [c_int, POINTER(c_void_p)]),
+    "uuo_model_destroy": (c_int, [c_void_p]),
+    "uuo_model_num_verts": (c_int, [c_void_p]),
+    "uuo_smpl_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "uuo_nn_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                              c_void_p, c_void_p]),
+    "uuo_assign_mean_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "uuo_fit_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "uuo_fit_destroy": (c_int, [c_void_p]),
+    "uuo_problem_num_params": (c_int, [POINTER(UuoProblem)]),
+    "uuo_closure_eval": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "uuo_lbfgs_solve": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, POINTER(UuoLbfgsOptions),
+                                POINTER(UuoLbfgsStats), c_void_p, c_void_p]),
+    "uuo_time_closure": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_int, c_int,
+                                 POINTER(c_float)]),
+}
+# not in the public header: optimiser self-test hook used by tests/test_lbfgs.py
+_EXTRA_SIGNATURES = {
+    "uuo_lbfgs_selftest": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(UuoLbfgsOptions),
+                                   POINTER(UuoLbfgsStats)]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/uuo_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(uuo_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n != "uuo_eval_callback_t"))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "libuuo_hip.so is missing (%s): run `python __graft_entry__.py` to build the HIP extension. "
+            "There is no CPU fallback for the fitted path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in header_symbols():
+        if not hasattr(lib, name):
+            raise RuntimeError("libuuo_hip.so does not export %s declared in include/uuo_hip.h" % name)
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_EXTRA_SIGNATURES.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().uuo_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what or "libuuo_hip call", rc, msg.decode() if msg else ""))

@@ -1,0 +1,613 @@
+// Stage closures: forward + hand-derived sparse backward of the three L-BFGS problems of the fit
+// (reference optimization.py:187-275 chamfer, :329-394 marker, markers/markers_utils.py:454-562 part).
+// Only the <= M vertices a frame's markers touch carry gradient, so the backward is a gather-LBS over those
+// vertices instead of the reference's dense autograd GEMMs.
+#include <vector>
+
+#include "frame_math.h"
+
+struct BwdArgs {
+  // model
+  const float* PT;
+  const float* ST;
+  const float* vt;
+  const float* Wd;
+  const int* Wi;
+  const float* Ww;
+  const UuoTree* tree;
+  int V;
+  // frame inputs
+  UuoPoseSrc src;
+  int stage, F, M;
+  const float* markers;
+  const float* mask;
+  const unsigned long long* nn;
+  const int* assign;
+  const int* subset;
+  const float* raw_pose;  // optimised raw body rotations (chamfer, marker) or null
+  const float* o_pose;    // prior target
+  const float* raw_root;  // marker stage: optimised raw root
+  float cg;               // 2*w_data / normaliser
+  float cpose;            // 2*w_pose / (F*207)
+  float d0;
+  // outputs
+  float* g_pose;
+  float* g_root;
+  float* g_z;
+  float* g_trans;
+  float* frame_part;  // [F][16]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta
+};
+
+// ----------------------------------------------------------------------------------------------------
+// K_C  one block (4 waves) per frame.  Phase 1: waves stride over the frame's markers; per marker the
+// wave gathers the touched vertex (posedirs rows PT[v] split over lanes), re-skins it, forms dL/dv and
+// accumulates d(pose feature) in registers, dA in wave-private LDS, dbeta/dtrans/loss in registers.
+// Phase 2: joints on lanes -- A -> G, reverse kinematic sweep (parents pull from children in a fixed
+// order, so the result is deterministic), Gram-Schmidt backward, priors, parameter gradients.
+// ----------------------------------------------------------------------------------------------------
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
+  __shared__ FrameLds L;
+  __shared__ float sA[UUO_NUM_JOINTS * 12];
+  __shared__ float spf[UUO_KB];
+  __shared__ float w_dA[4][UUO_NUM_JOINTS * 12];
+  __shared__ float w_dpf[4][UUO_KB];
+  __shared__ float w_red[4][16];
+  __shared__ float sdA[UUO_NUM_JOINTS * 12];
+  __shared__ float sdpf[UUO_KB];
+  __shared__ float red[16];
+  __shared__ float sdGR[UUO_NUM_JOINTS][9], sdGt[UUO_NUM_JOINTS][3], sdJ[UUO_NUM_JOINTS][3], sdR[UUO_NUM_JOINTS][9];
+  __shared__ float spsq[UUO_NUM_JOINTS];
+
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int F = a.F, M = a.M;
+  frame_forward(a.src, a.tree, f, L);
+  if (tid < UUO_NUM_JOINTS) frame_skin_matrix(L, tid, sA + tid * 12);
+  if (tid < UUO_KB) {
+    float v = 0.f;
+    if (tid < UUO_NUM_POSE_FEATS) {
+      const int j = 1 + tid / 9, e = tid % 9;
+      v = L.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+    spf[tid] = v;
+  }
+  for (int i = tid; i < 4 * UUO_NUM_JOINTS * 12; i += 256) (&w_dA[0][0])[i] = 0.f;
+  __syncthreads();
+
+  float tr[3] = {0.f, 0.f, 0.f};
+  if (a.src.trans) {
+    tr[0] = a.src.trans[(size_t)f * 3];
+    tr[1] = a.src.trans[(size_t)f * 3 + 1];
+    tr[2] = a.src.trans[(size_t)f * 3 + 2];
+  }
+  float acc_dpf[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc_db = 0.f, acc_dt = 0.f, acc_loss = 0.f;
+
+  for (int m = wave; m < M; m += 4) {
+    float wgt = 1.f, d2 = 0.f;
+    int vi;
+    if (a.stage == UUO_STAGE_MARKER) {
+      wgt = a.mask[(size_t)f * M + m];
+      vi = a.assign[m];
+    } else {
+      const unsigned long long key = a.nn[(size_t)f * M + m];
+      d2 = __uint_as_float((unsigned)(key >> 32));
+      vi = (int)(unsigned)(key & 0xFFFFFFFFull);
+      if (a.stage == UUO_STAGE_PART) {
+        vi = a.subset[vi];
+      } else {
+        wgt = a.mask[(size_t)f * M + m];
+      }
+    }
+    if (wgt == 0.f) continue;  // wave-uniform
+    const float* px = a.markers + ((size_t)f * M + m) * 3;
+    const float x0 = px[0], x1 = px[1], x2 = px[2];
+
+    // posedirs rows of this vertex over lanes: k = lane + 64 r
+    const float* pt = a.PT + (size_t)vi * 3 * UUO_KB;
+    float p[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) p[c][r] = pt[c * UUO_KB + lane + 64 * r];
+      p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
+    }
+    const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
+                f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
+    float vp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float part = fmaf(p[c][3], f3, fmaf(p[c][2], f2, fmaf(p[c][1], f1, p[c][0] * f0)));
+      const float offs = wave_sum(part);
+      float vs = a.vt[(size_t)vi * 3 + c];
+      float sb = 0.f;
+#pragma unroll
+      for (int l = 0; l < 10; ++l) sb = fmaf(a.ST[((size_t)vi * 3 + c) * 10 + l], L.beta[l], sb);
+      vp[c] = offs + (vs + sb);
+    }
+    // blended skinning matrix
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    int wj[4];
+    float ww[4];
+    if (SPARSE) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        wj[n] = a.Wi[(size_t)vi * 4 + n];
+        ww[n] = a.Ww[(size_t)vi * 4 + n];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
+      }
+    } else {
+      for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
+        const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
+      }
+    }
+    const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
+    const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
+    const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
+    const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
+    float g[3];
+    float loss_item;
+    if (a.stage == UUO_STAGE_MARKER) {
+      const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
+      const float e = rr - a.d0;
+      loss_item = wgt * (e * e);
+      const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
+      g[0] = sc * dx;
+      g[1] = sc * dy;
+      g[2] = sc * dz;
+    } else {
+      loss_item = wgt * d2;
+      const float sc = -a.cg * wgt;
+      g[0] = sc * dx;
+      g[1] = sc * dy;
+      g[2] = sc * dz;
+    }
+    // d v_posed = T_R^T g
+    float dvp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc_dpf[r] += fmaf(p[2][r], dvp[2], fmaf(p[1][r], dvp[1], p[0][r] * dvp[0]));
+    if (lane < 10) {
+      const float* ps = a.ST + (size_t)vi * 30 + lane;
+      acc_db += fmaf(ps[20], dvp[2], fmaf(ps[10], dvp[1], ps[0] * dvp[0]));
+    }
+    if (lane < 12) {
+      const int r = lane >> 2, c = lane & 3;
+      const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
+      const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
+      const float val = gr * pc;
+      if (SPARSE) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
+      } else {
+        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
+          w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
+      }
+    }
+    if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
+    acc_loss += loss_item;
+  }
+
+  // ---- block reduction (fixed order -> deterministic)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) w_dpf[wave][lane + 64 * r] = acc_dpf[r];
+  if (lane < UUO_KB - 192) w_dpf[wave][lane + 192] = acc_dpf[3];
+  if (lane == 0) w_red[wave][0] = acc_loss;
+  if (lane < 3) w_red[wave][1 + lane] = acc_dt;
+  if (lane < 10) w_red[wave][4 + lane] = acc_db;
+  __syncthreads();
+  if (tid < UUO_KB) sdpf[tid] = ((w_dpf[0][tid] + w_dpf[1][tid]) + w_dpf[2][tid]) + w_dpf[3][tid];
+  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += 256) sdA[i] = ((w_dA[0][i] + w_dA[1][i]) + w_dA[2][i]) + w_dA[3][i];
+  if (tid < 14) red[tid] = ((w_red[0][tid] + w_red[1][tid]) + w_red[2][tid]) + w_red[3][tid];
+  __syncthreads();
+
+  // ---- phase 2: joints on lanes
+  const UuoTree* tree = a.tree;
+  const int j = tid;
+  if (j < UUO_NUM_JOINTS) {
+    float dAt[3] = {sdA[j * 12 + 3], sdA[j * 12 + 7], sdA[j * 12 + 11]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sdGR[j][r * 3 + c] = sdA[j * 12 + r * 4 + c] - dAt[r] * L.J[j][c];
+      sdGt[j][r] = dAt[r];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      sdJ[j][c] = -(fmaf(L.GR[j][6 + c], dAt[2], fmaf(L.GR[j][3 + c], dAt[1], L.GR[j][c] * dAt[0])));
+  }
+  __syncthreads();
+  const int my_depth = (j < UUO_NUM_JOINTS) ? tree->depth[j] : -1;
+  for (int d = tree->max_depth - 1; d >= 0; --d) {
+    if (my_depth == d) {
+      const int nch = tree->nchild[j];
+      for (int ci = 0; ci < nch; ++ci) {
+        const int c = tree->child[j][ci];
+        float dGRc[9], dGtc[3], Rc[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          dGRc[e] = sdGR[c][e];
+          Rc[e] = L.R[c][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) dGtc[e] = sdGt[c][e];
+        // dR_c = G_j^R^T dG_c^R
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb)
+            sdR[c][aa * 3 + bb] =
+                fmaf(L.GR[j][6 + aa], dGRc[6 + bb], fmaf(L.GR[j][3 + aa], dGRc[3 + bb], L.GR[j][aa] * dGRc[bb]));
+        const float rel[3] = {L.J[c][0] - L.J[j][0], L.J[c][1] - L.J[j][1], L.J[c][2] - L.J[j][2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int aa = 0; aa < 3; ++aa) {
+            float add = fmaf(dGRc[r * 3 + 2], Rc[aa * 3 + 2], fmaf(dGRc[r * 3 + 1], Rc[aa * 3 + 1], dGRc[r * 3] * Rc[aa * 3]));
+            add = fmaf(dGtc[r], rel[aa], add);
+            sdGR[j][r * 3 + aa] += add;
+          }
+          sdGt[j][r] += dGtc[r];
+        }
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          const float tmp = fmaf(L.GR[j][6 + aa], dGtc[2], fmaf(L.GR[j][3 + aa], dGtc[1], L.GR[j][aa] * dGtc[0]));
+          sdJ[c][aa] += tmp;
+          sdJ[j][aa] -= tmp;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (j == 0) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sdR[0][e] = sdGR[0][e];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sdJ[0][c] += sdGt[0][c];
+  }
+  __syncthreads();
+
+  // shape gradient of this frame: direct (blend shapes) + joint path
+  if (tid < 10) {
+    float acc = red[4 + tid];
+    for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc = fmaf(tree->JS[jj][c][tid], sdJ[jj][c], acc);
+    a.frame_part[(size_t)f * 16 + 4 + tid] = acc;
+  }
+  // body rotations
+  if (j >= 1 && j < UUO_NUM_JOINTS) {
+    float psq = 0.f;
+    if (a.g_pose) {
+      float dR[9], raw[9], gout[9];
+      const float* pr = a.raw_pose + ((size_t)f * 23 + (j - 1)) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        dR[e] = sdR[j][e] + sdpf[(j - 1) * 9 + e];
+        raw[e] = pr[e];
+      }
+      if (a.src.norm_body) {
+        float da[6];
+        gs6d_backward(raw, dR, da);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) gout[e] = da[e];
+        gout[6] = gout[7] = gout[8] = 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gout[e] = dR[e];
+      }
+      if (a.cpose != 0.f) {
+        const float* po = a.o_pose + ((size_t)f * 23 + (j - 1)) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          const float diff = raw[e] - po[e];
+          gout[e] = fmaf(a.cpose, diff, gout[e]);
+          psq = fmaf(diff, diff, psq);
+        }
+      }
+      float* pg = a.g_pose + ((size_t)f * 23 + (j - 1)) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) pg[e] = gout[e];
+    }
+    spsq[j] = psq;
+  }
+  if (j == 0) {
+    spsq[0] = 0.f;
+    // d(Rz(z) root)/dz = [[-s,-c,0],[c,-s,0],[0,0,0]] root
+    const float cz = L.Rz[0], sz = L.Rz[2];
+    if (a.stage == UUO_STAGE_CHAMFER) {
+      float da[6];
+      gs6d_backward(L.Mroot, sdR[0], da);
+      const float* r0 = a.src.root + (size_t)f * 9;
+      float dzv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dzv = fmaf(da[c], (-sz * r0[c] - cz * r0[3 + c]), dzv);
+        dzv = fmaf(da[3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
+      }
+      a.g_z[f] = dzv;
+    } else if (a.stage == UUO_STAGE_MARKER) {
+      float da[6];
+      gs6d_backward(a.raw_root + (size_t)f * 9, sdR[0], da);
+      float* pg = a.g_root + (size_t)f * 9;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) pg[e] = da[e];
+      pg[6] = pg[7] = pg[8] = 0.f;
+    } else {
+      const float* r0 = a.src.root + (size_t)f * 9;
+      float dzv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dzv = fmaf(sdR[0][c], (-sz * r0[c] - cz * r0[3 + c]), dzv);
+        dzv = fmaf(sdR[0][3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
+      }
+      a.frame_part[(size_t)f * 16 + 1] = dzv;
+    }
+  }
+  if (tid < 3 && a.g_trans) a.g_trans[(size_t)f * 3 + tid] = red[1 + tid];
+  __syncthreads();
+  if (tid == 0) {
+    float ps = 0.f;
+    for (int jj = 1; jj < UUO_NUM_JOINTS; ++jj) ps += spsq[jj];
+    a.frame_part[(size_t)f * 16 + 0] = red[0];
+    a.frame_part[(size_t)f * 16 + 2] = ps;
+    if (a.stage != UUO_STAGE_PART) a.frame_part[(size_t)f * 16 + 1] = 0.f;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
+// prior, writes the loss and the shared-parameter gradients (betas; z for the part stage).
+// ----------------------------------------------------------------------------------------------------
+struct FinArgs {
+  int stage, F;
+  const float* frame_part;
+  const float* betas;
+  const float* o_betas;
+  double closs;   // data-term coefficient on the summed per-frame values
+  double cpose;   // w_pose / (F*207)
+  double cbetas;  // w_betas / 10
+  float* g_betas;
+  float* g_z;  // part stage
+  float* loss;
+};
+
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
+  __shared__ double sh[16][16];
+  const int tid = threadIdx.x;
+  const int comp = tid & 15, grp = tid >> 4;  // 16 groups of frames
+  double acc = 0.0;
+  for (int f = grp; f < a.F; f += 16) acc += (double)a.frame_part[(size_t)f * 16 + comp];
+  sh[grp][comp] = acc;
+  __syncthreads();
+  if (tid < 16) {
+    double s = 0.0;
+    for (int g = 0; g < 16; ++g) s += sh[g][tid];
+    sh[0][tid] = s;
+  }
+  __syncthreads();
+  if (tid < 10) {
+    const double diff = (double)a.betas[tid] - (double)a.o_betas[tid];
+    a.g_betas[tid] = (float)(sh[0][4 + tid] + 2.0 * a.cbetas * diff);
+  }
+  if (tid == 0) {
+    double bsq = 0.0;
+    for (int l = 0; l < 10; ++l) {
+      const double diff = (double)a.betas[l] - (double)a.o_betas[l];
+      bsq += diff * diff;
+    }
+    const double loss = a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq;
+    a.loss[0] = (float)loss;
+    if (a.stage == UUO_STAGE_PART) a.g_z[0] = (float)sh[0][1];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------------
+struct StageLayout {
+  int n, off_trans, off_z, off_betas, off_pose, off_root;
+};
+
+static StageLayout stage_layout(int stage, int F) {
+  StageLayout s{0, -1, -1, -1, -1, -1};
+  if (stage == UUO_STAGE_CHAMFER) {
+    s.off_trans = 0;
+    s.off_z = 3 * F;
+    s.off_betas = 4 * F;
+    s.off_pose = 4 * F + 10;
+    s.n = 211 * F + 10;
+  } else if (stage == UUO_STAGE_MARKER) {
+    s.off_pose = 0;
+    s.off_betas = 207 * F;
+    s.off_root = 207 * F + 10;
+    s.off_trans = 216 * F + 10;
+    s.n = 219 * F + 10;
+  } else {
+    s.off_z = 0;
+    s.off_trans = 1;
+    s.off_betas = 3 * F + 1;
+    s.n = 3 * F + 11;
+  }
+  return s;
+}
+
+extern "C" int uuo_problem_num_params(const uuo_problem_t* p) {
+  if (!p || p->F <= 0 || p->stage < 0 || p->stage > 2) return -22;
+  return stage_layout(p->stage, p->F).n;
+}
+
+static int validate_problem(const uuo_fit* fit, const uuo_problem_t* p) {
+  UUO_REQUIRE(fit && p, "closure: null fit/problem");
+  UUO_REQUIRE(p->stage >= 0 && p->stage <= 2, "closure: unknown stage");
+  UUO_REQUIRE(p->F == fit->F && p->M == fit->M, "closure: problem F/M differ from the workspace");
+  UUO_REQUIRE(p->d_markers && p->d_o_pose && p->d_o_betas, "closure: markers / o_pose / o_betas required");
+  if (p->stage != UUO_STAGE_MARKER) UUO_REQUIRE(p->d_root != nullptr, "closure: fixed root orientation required");
+  if (p->stage == UUO_STAGE_MARKER) UUO_REQUIRE(p->d_assign != nullptr, "closure: marker stage needs d_assign");
+  if (p->stage == UUO_STAGE_PART)
+    UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0, "closure: part stage needs a vertex subset");
+  return 0;
+}
+
+// get_marker_mask + its sum; recomputed at every public entry (markers may have changed under the same pointer)
+int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p) {
+  int rc = uuo_launch_mask(s, p->F, p->M, p->d_markers, fit->mask, fit->scalars);
+  if (rc) return rc;
+  UUO_HIP_CHECK(hipMemcpyAsync(&fit->mask_sum, fit->scalars, sizeof(float), hipMemcpyDeviceToHost, s));
+  UUO_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay, const float* x) {
+  UuoPoseSrc src;
+  src.betas = x + lay.off_betas;
+  src.betas_stride = 0;
+  src.trans = x + lay.off_trans;
+  src.z = nullptr;
+  if (p->stage == UUO_STAGE_CHAMFER) {
+    src.body = x + lay.off_pose;
+    src.norm_body = 1;
+    src.root = p->d_root;
+    src.root_mode = UUO_ROOT_Z_GS;
+    src.z = x + lay.off_z;
+  } else if (p->stage == UUO_STAGE_MARKER) {
+    src.body = x + lay.off_pose;
+    src.norm_body = 1;
+    src.root = x + lay.off_root;
+    src.root_mode = UUO_ROOT_GS;
+  } else {
+    src.body = p->d_o_pose;
+    src.norm_body = 0;
+    src.root = p->d_root;
+    src.root_mode = UUO_ROOT_ZSHARED;
+    src.z = x + lay.off_z;
+  }
+  return src;
+}
+
+// forward half shared by uuo_closure_eval and uuo_time_closure
+static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src) {
+  if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
+  const uuo_model* m = fit->model;
+  int rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr);
+  if (rc) return rc;
+  rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts);
+  if (rc) return rc;
+  return uuo_launch_nn(s, p->F, p->M, m->V, p->d_markers, fit->verts, p->d_subset, p->n_subset, fit->nn);
+}
+
+int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return validate_problem(fit, p); }
+
+// closure evaluation proper; the marker mask must be current (uuo_ensure_mask)
+int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
+                          float* d_grad, int32_t* d_nn_idx) {
+  int rc = 0;
+  const uuo_model* m = fit->model;
+  const int F = p->F, M = p->M;
+  const StageLayout lay = stage_layout(p->stage, F);
+  const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
+  rc = closure_forward(fit, s, p, src);
+  if (rc) return rc;
+  if (d_nn_idx && p->stage != UUO_STAGE_MARKER) {
+    rc = uuo_launch_nn_unpack(s, F * M, fit->nn, nullptr, d_nn_idx);
+    if (rc) return rc;
+  }
+
+  double denom;
+  if (p->stage == UUO_STAGE_CHAMFER)
+    denom = (double)fit->mask_sum;  // pytorch3d: div = weights.sum()
+  else
+    denom = (double)F * (double)M;  // mean over frames and markers
+  const double data_c = (denom > 0.0) ? (double)p->w_data / denom : 0.0;
+
+  BwdArgs a;
+  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wd = m->W; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
+  a.src = src;
+  a.stage = p->stage; a.F = F; a.M = M;
+  a.markers = p->d_markers;
+  a.mask = fit->mask;
+  a.nn = fit->nn;
+  a.assign = p->d_assign;
+  a.subset = p->d_subset;
+  a.raw_pose = (p->stage == UUO_STAGE_PART) ? nullptr : d_x + lay.off_pose;
+  a.o_pose = p->d_o_pose;
+  a.raw_root = (p->stage == UUO_STAGE_MARKER) ? d_x + lay.off_root : nullptr;
+  a.cg = (float)(2.0 * data_c);
+  a.cpose = (p->stage == UUO_STAGE_PART) ? 0.f : (float)(2.0 * (double)p->w_pose / ((double)F * 207.0));
+  a.d0 = p->marker_distance;
+  a.g_pose = (p->stage == UUO_STAGE_PART) ? nullptr : d_grad + lay.off_pose;
+  a.g_root = (p->stage == UUO_STAGE_MARKER) ? d_grad + lay.off_root : nullptr;
+  a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + lay.off_z : nullptr;
+  a.g_trans = d_grad + lay.off_trans;
+  a.frame_part = fit->frame_part;
+  if (m->nnz <= 4)
+    hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_bwd<false>, dim3(F), dim3(256), 0, s, a);
+  UUO_HIP_CHECK(hipGetLastError());
+
+  FinArgs fa;
+  fa.stage = p->stage; fa.F = F;
+  fa.frame_part = fit->frame_part;
+  fa.betas = d_x + lay.off_betas;
+  fa.o_betas = p->d_o_betas;
+  fa.closs = data_c;
+  fa.cpose = (p->stage == UUO_STAGE_PART) ? 0.0 : (double)p->w_pose / ((double)F * 207.0);
+  fa.cbetas = (double)p->w_betas / 10.0;
+  fa.g_betas = d_grad + lay.off_betas;
+  fa.g_z = (p->stage == UUO_STAGE_PART) ? d_grad + lay.off_z : nullptr;
+  fa.loss = d_loss;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, fa);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int uuo_closure_eval(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, float* d_loss,
+                                float* d_grad, int32_t* d_nn_idx) {
+  int rc = validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && d_loss && d_grad, "uuo_closure_eval: null x/loss/grad");
+  hipStream_t s = (hipStream_t)stream;
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  return uuo_closure_eval_impl(fit, s, p, d_x, d_loss, d_grad, d_nn_idx);
+}
+
+extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, int iters,
+                                int dominant_only, float* ms_per_eval) {
+  int rc = validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && ms_per_eval && iters > 0, "uuo_time_closure: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const StageLayout lay = stage_layout(p->stage, p->F);
+  float* loss = fit->scalars + 8;
+  float* grad = fit->vecs;  // work vector 0
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
+  // warm-up
+  rc = dominant_only ? closure_forward(fit, s, p, src) : uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr);
+  if (rc) return rc;
+  UUO_HIP_CHECK(hipEventRecord(fit->ev0, s));
+  for (int i = 0; i < iters; ++i) {
+    if (dominant_only) {
+      rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts);
+    } else {
+      rc = uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr);
+    }
+    if (rc) return rc;
+  }
+  UUO_HIP_CHECK(hipEventRecord(fit->ev1, s));
+  UUO_HIP_CHECK(hipEventSynchronize(fit->ev1));
+  float ms = 0.f;
+  UUO_HIP_CHECK(hipEventElapsedTime(&ms, fit->ev0, fit->ev1));
+  *ms_per_eval = ms / (float)iters;
+  return 0;
+}

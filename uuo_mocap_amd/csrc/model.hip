@@ -1,0 +1,145 @@
+// Model tables: host-side re-layout for gfx950 and upload.  Replaces smplx.create(...) as used by
+// SmplInference.__init__ (reference src/video_mocap/utils/smpl.py:22-27).
+#include <cstring>
+#include <vector>
+
+#include "uuo_common.h"
+
+static thread_local std::string g_last_error;
+void uuo_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* uuo_last_error(void) { return g_last_error.c_str(); }
+extern "C" int uuo_abi_version(void) { return 1; }
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+  UUO_HIP_CHECK(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  UUO_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int uuo_model_create(const float* vt, const float* S, const float* P, const float* Jreg, const float* W,
+                                const int64_t* parents, const int64_t* extra, int V, uuo_model_t** out) {
+  UUO_REQUIRE(vt && S && P && Jreg && W && parents && extra && out, "uuo_model_create: null argument");
+  UUO_REQUIRE(V > 0 && V < (1 << 24), "uuo_model_create: bad vertex count");
+  uuo_model* m = new uuo_model();
+  m->V = V;
+  m->VP = ((V + 127) / 128) * 128;
+  const int VP = m->VP;
+
+  // coordinate-planar augmented blend basis  P3[c][k][v]: rows 0..206 posedirs, 207..216 shapedirs, rest zero.
+  // Memory laid out for the skin kernel: a wave reads 32 consecutive v of one (c,k) row -> 128 B segments.
+  std::vector<float> P3((size_t)3 * UUO_KP * VP, 0.f), vt3((size_t)3 * VP, 0.f);
+  for (int k = 0; k < UUO_NUM_POSE_FEATS; ++k)
+    for (int v = 0; v < V; ++v)
+      for (int c = 0; c < 3; ++c) P3[((size_t)c * UUO_KP + k) * VP + v] = P[(size_t)k * V * 3 + v * 3 + c];
+  for (int l = 0; l < UUO_NUM_BETAS; ++l)
+    for (int v = 0; v < V; ++v)
+      for (int c = 0; c < 3; ++c)
+        P3[((size_t)c * UUO_KP + UUO_NUM_POSE_FEATS + l) * VP + v] = S[((size_t)v * 3 + c) * 10 + l];
+  for (int v = 0; v < V; ++v)
+    for (int c = 0; c < 3; ++c) vt3[(size_t)c * VP + v] = vt[v * 3 + c];
+
+  // per-vertex transposed posedirs rows PT[v][c][k] (contiguous 3*208 floats per vertex) for gather-LBS / backward
+  std::vector<float> PT((size_t)V * 3 * UUO_KB, 0.f);
+  for (int k = 0; k < UUO_NUM_POSE_FEATS; ++k)
+    for (int v = 0; v < V; ++v)
+      for (int c = 0; c < 3; ++c) PT[((size_t)v * 3 + c) * UUO_KB + k] = P[(size_t)k * V * 3 + v * 3 + c];
+
+  // sparse skin weights, joints ascending (same summation order as the dense j = 0..23 chain)
+  std::vector<int> Wi((size_t)VP * 4, 0);
+  std::vector<float> Ww((size_t)VP * 4, 0.f);
+  int max_nnz = 0;
+  for (int v = 0; v < V; ++v) {
+    int n = 0;
+    for (int j = 0; j < UUO_NUM_JOINTS; ++j) {
+      float w = W[(size_t)v * UUO_NUM_JOINTS + j];
+      if (w != 0.f) {
+        if (n < 4) {
+          Wi[(size_t)v * 4 + n] = j;
+          Ww[(size_t)v * 4 + n] = w;
+        }
+        ++n;
+      }
+    }
+    if (n > max_nnz) max_nnz = n;
+  }
+  m->nnz = max_nnz;
+
+  // kinematic tree + hoisted joint tables (J = Jt + JS.beta, with Jt = Jreg.v_template, JS = Jreg.shapedirs)
+  UuoTree& t = m->h_tree;
+  std::memset(&t, 0, sizeof(t));
+  for (int j = 0; j < UUO_NUM_JOINTS; ++j) t.parent[j] = (j == 0) ? -1 : (int)parents[j];
+  t.max_depth = 0;
+  for (int j = 0; j < UUO_NUM_JOINTS; ++j) {
+    if (j > 0 && (t.parent[j] < 0 || t.parent[j] >= j)) {
+      delete m;
+      uuo_set_error("uuo_model_create: parents must satisfy 0 <= parents[j] < j");
+      return -22;
+    }
+    t.depth[j] = (j == 0) ? 0 : t.depth[t.parent[j]] + 1;
+    if (t.depth[j] > t.max_depth) t.max_depth = t.depth[j];
+    if (j > 0) {
+      int p = t.parent[j];
+      if (t.nchild[p] >= 4 || t.depth[j] >= UUO_MAX_DEPTH) {
+        delete m;
+        uuo_set_error("uuo_model_create: kinematic tree wider/deeper than supported (4 children, depth 9)");
+        return -22;
+      }
+      t.child[p][t.nchild[p]++] = j;
+    }
+  }
+  for (int j = 0; j < UUO_NUM_JOINTS; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int v = 0; v < V; ++v) acc += (double)Jreg[(size_t)j * V + v] * (double)vt[v * 3 + c];
+      t.Jt[j][c] = (float)acc;
+      for (int l = 0; l < 10; ++l) {
+        double a2 = 0.0;
+        for (int v = 0; v < V; ++v) a2 += (double)Jreg[(size_t)j * V + v] * (double)S[((size_t)v * 3 + c) * 10 + l];
+        t.JS[j][c][l] = (float)a2;
+      }
+    }
+  for (int e = 0; e < UUO_NUM_EXTRA_JOINTS; ++e) {
+    if (extra[e] < 0 || extra[e] >= V) {
+      delete m;
+      uuo_set_error("uuo_model_create: extra joint vertex id out of range");
+      return -22;
+    }
+    t.extra_vids[e] = (int)extra[e];
+  }
+
+  int rc = 0;
+  rc |= upload(&m->P3, P3);
+  rc |= upload(&m->vt3, vt3);
+  rc |= upload(&m->PT, PT);
+  std::vector<float> ST(S, S + (size_t)V * 30), vtv(vt, vt + (size_t)V * 3), Wd(W, W + (size_t)V * UUO_NUM_JOINTS);
+  rc |= upload(&m->ST, ST);
+  rc |= upload(&m->vt, vtv);
+  rc |= upload(&m->W, Wd);
+  rc |= upload(&m->Wi, Wi);
+  rc |= upload(&m->Ww, Ww);
+  if (rc == 0) {
+    if (hipMalloc((void**)&m->tree, sizeof(UuoTree)) != hipSuccess ||
+        hipMemcpy(m->tree, &t, sizeof(UuoTree), hipMemcpyHostToDevice) != hipSuccess) {
+      uuo_set_error("uuo_model_create: tree upload failed");
+      rc = -5;
+    }
+  }
+  if (rc != 0) {
+    uuo_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int uuo_model_destroy(uuo_model_t* m) {
+  if (!m) return 0;
+  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->W, m->Wi, m->Ww, m->tree, m->fwd_pfaT, m->fwd_A, m->fwd_jp};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete m;
+  return 0;
+}
+
+extern "C" int uuo_model_num_verts(const uuo_model_t* m) { return m ? m->V : -22; }

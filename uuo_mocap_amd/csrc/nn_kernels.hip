@@ -1,0 +1,218 @@
+// Nearest-neighbour assignment kernels: K=1 search (chamfer data term) and marker placement.
+#include <cstdlib>
+
+#include "frame_math.h"
+
+#define UUO_INF __builtin_huge_valf()
+
+__device__ __forceinline__ unsigned long long pack_key(float d, unsigned idx) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)idx;
+}
+
+// squared distance exactly as pytorch3d's CPU loop: ((0 + dx*dx) + dy*dy) + dz*dz, every op rounded separately
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K=1 nearest neighbour.  One wave per (cloud n, 64-query group, candidate split).  Lane = query; the
+// candidate tile is staged in LDS (coalesced load, broadcast reads), the running (dist, index) minimum
+// lives in registers, candidates are visited in ascending order with a strict '<' so the first index wins
+// inside a split; splits are merged with a 64-bit atomicMin on (dist bits << 32 | index), which is the
+// same lexicographic order and is exact and order-independent.
+// Replaces pytorch3d knn_points(K=1) behind chamfer_distance (reference losses/chamfer_distance.py:15-20).
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nn(const float* __restrict__ x, const float* __restrict__ y,
+                                            const int* __restrict__ ysub, int P1, int P2, int nc, int S,
+                                            unsigned long long* __restrict__ out) {
+  __shared__ float4 sc[64];
+  const int n = blockIdx.x, qg = blockIdx.y, s = blockIdx.z, lane = threadIdx.x;
+  const int q = qg * 64 + lane;
+  const bool valid = q < P1;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (valid) {
+    const float* px = x + ((size_t)n * P1 + q) * 3;
+    qx = px[0];
+    qy = px[1];
+    qz = px[2];
+  }
+  const int per = (nc + S - 1) / S;
+  const int c0 = s * per;
+  const int c1 = min(nc, c0 + per);
+  float best = UUO_INF;
+  unsigned besti = 0xFFFFFFFFu;
+  for (int base = c0; base < c1; base += 64) {
+    const int c = base + lane;
+    float4 p = make_float4(UUO_INF, UUO_INF, UUO_INF, 0.f);
+    if (c < c1) {
+      const int vi = ysub ? ysub[c] : c;
+      const float* py = y + ((size_t)n * P2 + vi) * 3;
+      p = make_float4(py[0], py[1], py[2], 0.f);
+    }
+    __syncthreads();
+    sc[lane] = p;
+    __syncthreads();
+#pragma unroll 8
+    for (int t = 0; t < 64; ++t) {
+      const float4 cnd = sc[t];
+      const float d = sqdist(qx, qy, qz, cnd.x, cnd.y, cnd.z);
+      if (d < best) {
+        best = d;
+        besti = (unsigned)(base + t);
+      }
+    }
+  }
+  if (valid && besti != 0xFFFFFFFFu) atomicMin(&out[(size_t)n * P1 + q], pack_key(best, besti));
+}
+
+int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub, int P2s,
+                  unsigned long long* packed) {
+  const int nc = ysub ? P2s : P2;
+  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
+  if (nc <= 0 || N <= 0 || P1 <= 0) return 0;
+  const int qgroups = (P1 + 63) / 64;
+  // enough waves to fill the chip: target >= 4096 waves, at least 256 candidates per split
+  int S = 1;
+  const long waves = (long)N * qgroups;
+  if (waves < 4096) S = (int)((4096 + waves - 1) / waves);
+  const int maxS = (nc + 255) / 256;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  hipLaunchKernelGGL(k_nn, dim3(N, qgroups, S), dim3(64), 0, s, x, y, ysub, P1, P2, nc, S, packed);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_nn_unpack(int count, const unsigned long long* __restrict__ packed, float* __restrict__ dist,
+                            int32_t* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned long long k = packed[i];
+  if (dist) dist[i] = __uint_as_float((unsigned)(k >> 32));
+  if (idx) idx[i] = (int32_t)(unsigned)(k & 0xFFFFFFFFull);
+}
+
+int uuo_launch_nn_unpack(hipStream_t s, int count, const unsigned long long* packed, float* dist, int32_t* idx) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_nn_unpack, dim3((count + 255) / 256), dim3(256), 0, s, count, packed, dist, idx);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y,
+                             const int32_t* d_y_subset, int P2s, float* d_dist, int32_t* d_idx, void* d_ws) {
+  UUO_REQUIRE(d_x && d_y && d_ws, "uuo_nn_argmin: null argument (workspace of N*P1 uint64 is required)");
+  UUO_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0, "uuo_nn_argmin: negative size");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = uuo_launch_nn(s, N, P1, P2, d_x, d_y, d_y_subset, P2s, (unsigned long long*)d_ws);
+  if (rc) return rc;
+  return uuo_launch_nn_unpack(s, N * P1, (const unsigned long long*)d_ws, d_dist, d_idx);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Marker placement (reference optimization.py:479-486,595-603): idx[m] = argmin_v mean_f ||v_fv - x_fm||
+// with numpy's fp32 semantics: norm = sqrt((dx*dx + dy*dy) + dz*dz), sum over valid frames sequentially
+// in f, then divide by the count; first index on ties.  Thread = vertex, marker group of 8 in registers
+// so each vertex row is read once per 8 markers.
+// ----------------------------------------------------------------------------------------------------
+#define ASSIGN_MG 8
+__global__ __launch_bounds__(256) void k_assign(int F, int M, int V, const float* __restrict__ verts,
+                                                 const float* __restrict__ markers,
+                                                 const unsigned char* __restrict__ valid, int count,
+                                                 unsigned long long* __restrict__ out) {
+  __shared__ float sm[ASSIGN_MG * 3];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * ASSIGN_MG;
+  float acc[ASSIGN_MG];
+#pragma unroll
+  for (int g = 0; g < ASSIGN_MG; ++g) acc[g] = 0.f;
+  for (int f = 0; f < F; ++f) {
+    if (!valid[f]) continue;  // uniform across the block
+    __syncthreads();
+    if (threadIdx.x < ASSIGN_MG * 3) {
+      const int g = threadIdx.x / 3, c = threadIdx.x % 3;
+      sm[threadIdx.x] = (m0 + g < M) ? markers[((size_t)f * M + m0 + g) * 3 + c] : 0.f;
+    }
+    __syncthreads();
+    if (v < V) {
+      const float* pv = verts + ((size_t)f * V + v) * 3;
+      const float vx = pv[0], vy = pv[1], vz = pv[2];
+#pragma unroll
+      for (int g = 0; g < ASSIGN_MG; ++g) {
+        const float d2 = sqdist(vx, vy, vz, sm[g * 3], sm[g * 3 + 1], sm[g * 3 + 2]);
+        acc[g] = __fadd_rn(acc[g], __fsqrt_rn(d2));
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < ASSIGN_MG; ++g) {
+    if (m0 + g < M) {  // uniform across the block
+      unsigned long long key = ~0ull;
+      if (v < V) key = pack_key(__fdiv_rn(acc[g], (float)count), (unsigned)v);
+      // wave-level lexicographic min (all 64 lanes participate) before the global atomic
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o < key ? o : key;
+      }
+      if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(&out[m0 + g], key);
+    }
+  }
+}
+
+int uuo_launch_assign(hipStream_t s, int F, int M, int V, const float* verts, const float* markers,
+                      const uint8_t* valid, int32_t* idx, unsigned long long* packed) {
+  // count of valid frames is needed on the host for the divide; valid is tiny
+  unsigned char* h = (unsigned char*)malloc(F);
+  if (!h) return -12;
+  hipError_t e = hipMemcpyAsync(h, valid, F, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    free(h);
+    uuo_set_error(std::string("uuo_assign_mean_argmin: ") + hipGetErrorString(e));
+    return -5;
+  }
+  int count = 0;
+  for (int f = 0; f < F; ++f) count += h[f] ? 1 : 0;
+  free(h);
+  UUO_REQUIRE(count > 0, "uuo_assign_mean_argmin: no valid frame");
+  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)M * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_assign, dim3((V + 255) / 256, (M + ASSIGN_MG - 1) / ASSIGN_MG), dim3(256), 0, s, F, M, V, verts,
+                     markers, valid, count, packed);
+  UUO_HIP_CHECK(hipGetLastError());
+  return uuo_launch_nn_unpack(s, M, packed, nullptr, idx);
+}
+
+extern "C" int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const float* d_verts, const float* d_markers,
+                                      const uint8_t* d_valid, int32_t* d_idx, void* d_ws) {
+  UUO_REQUIRE(d_verts && d_markers && d_valid && d_idx && d_ws, "uuo_assign_mean_argmin: null argument");
+  UUO_REQUIRE(F > 0 && M > 0 && V > 0, "uuo_assign_mean_argmin: sizes must be positive");
+  return uuo_launch_assign((hipStream_t)stream, F, M, V, d_verts, d_markers, d_valid, d_idx, (unsigned long long*)d_ws);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// get_marker_mask (reference optimization.py:703-715): sum(|xyz|) != 0, plus the count of set entries
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask(int count, const float* __restrict__ markers, float* __restrict__ mask,
+                                               float* __restrict__ mask_sum) {
+  __shared__ float red[4];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    const float* p = markers + (size_t)i * 3;
+    const float s = fabsf(p[0]) + fabsf(p[1]) + fabsf(p[2]);
+    const float w = (s != 0.0f) ? 1.f : 0.f;
+    mask[i] = w;
+    local += w;
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) mask_sum[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+int uuo_launch_mask(hipStream_t s, int F, int M, const float* markers, float* mask, float* mask_sum_dev) {
+  hipLaunchKernelGGL(k_mask, dim3(1), dim3(256), 0, s, F * M, markers, mask, mask_sum_dev);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,842 @@
+// L-BFGS with strong-Wolfe line search on device-resident vectors.
+// Mirrors torch.optim.LBFGS.step / _strong_wolfe / _cubic_interpolate (torch 2.10 semantics; the reference
+// constructs it at optimization.py:176-183,319-326 and markers/markers_utils.py:428-435): same direction
+// update rule (history push iff y.s > 1e-10, H_diag = y.s / y.y), same first-step length, bracket / zoom
+// logic, termination tests and their order.  What differs is the arithmetic route, not the algorithm:
+//  * the two-loop recursion is evaluated in coefficient space from Gram matrices of the (s, y) history
+//    (two passes over the history per iteration instead of 4*k dependent dot/axpy launches),
+//  * dot products accumulate in fp64, line-search scalars are fp64 on the host,
+//  * one small read-back per closure evaluation is the only host synchronisation.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "frame_math.h"
+
+#define LB_MAXH 128                 // history capacity (slots); history_size <= LB_MAXH - 1
+#define LB_ROWS (2 * LB_MAXH + 1)   // S slots, Y slots, g
+#define LB_CHUNK 2048               // elements per dot block
+#define LB_NVEC 10
+
+struct LbDev {                       // device-resident optimiser state
+  double SY[LB_MAXH * LB_MAXH];      // s_i . y_j by slot
+  double YY[LB_MAXH * LB_MAXH];      // y_i . y_j by slot
+  double cs[LB_MAXH], cy[LB_MAXH];   // direction coefficients by slot
+  double cg;
+  double Hdiag;
+  double gg;
+  int head, count;
+  unsigned dmax_bits;
+  int pad;
+  double out[16];                    // read-back block (see LbOut)
+};
+
+struct LbOut {  // layout of LbDev::out
+  double loss, gtd_new, gmax, g1, gg, gtd_dir, accepted, dmax, ys;
+};
+
+__global__ void k_lb_init(LbDev* st) {
+  st->Hdiag = 1.0;
+  st->cg = 0.0;
+  st->gg = 0.0;
+  st->head = 0;
+  st->count = 0;
+  st->dmax_bits = 0u;
+  for (int i = 0; i < 16; ++i) st->out[i] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------- kernels
+__global__ void k_lb_neg(int n, const float* __restrict__ g, float* __restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = -g[i];
+}
+
+__global__ void k_lb_axpy(int n, const float* __restrict__ x, float t, const float* __restrict__ d,
+                          float* __restrict__ o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = x[i] + t * d[i];  // p.add_(d, alpha=t): one multiply, one add (no contraction)
+}
+
+__global__ void k_lb_form(int n, const float* __restrict__ g, const float* __restrict__ gp,
+                          const float* __restrict__ d, float t, float* __restrict__ s_new, float* __restrict__ y_new) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    y_new[i] = g[i] - gp[i];
+    s_new[i] = d[i] * t;
+  }
+}
+
+// stats of a gradient against the current direction: partial sums per block
+__global__ __launch_bounds__(256) void k_lb_stats(int n, const float* __restrict__ g, const float* __restrict__ d,
+                                                   double* __restrict__ part /* [grid][4] */) {
+  __shared__ double sh[4][4];
+  double dot = 0.0, l1 = 0.0, gg = 0.0;
+  float mx = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float gi = g[i];
+    const float di = d ? d[i] : 0.f;
+    dot += (double)gi * (double)di;
+    l1 += (double)fabsf(gi);
+    gg += (double)gi * (double)gi;
+    mx = fmaxf(mx, fabsf(gi));
+  }
+  dot = wave_sum_d(dot);
+  l1 = wave_sum_d(l1);
+  gg = wave_sum_d(gg);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[w][0] = dot;
+    sh[w][1] = l1;
+    sh[w][2] = gg;
+    sh[w][3] = (double)mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 4 + 0] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    part[blockIdx.x * 4 + 1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+    part[blockIdx.x * 4 + 2] = (sh[0][2] + sh[1][2]) + (sh[2][2] + sh[3][2]);
+    part[blockIdx.x * 4 + 3] = fmax(fmax(sh[0][3], sh[1][3]), fmax(sh[2][3], sh[3][3]));
+  }
+}
+
+__global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* __restrict__ part,
+                                                        const float* __restrict__ loss, LbDev* __restrict__ st) {
+  if (threadIdx.x != 0) return;
+  double dot = 0.0, l1 = 0.0, gg = 0.0, mx = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    dot += part[b * 4];
+    l1 += part[b * 4 + 1];
+    gg += part[b * 4 + 2];
+    mx = fmax(mx, part[b * 4 + 3]);
+  }
+  LbOut* o = reinterpret_cast<LbOut*>(st->out);
+  o->loss = (double)loss[0];
+  o->gtd_new = dot;
+  o->gmax = mx;
+  o->g1 = l1;
+  o->gg = gg;
+  o->dmax = (double)__uint_as_float(st->dmax_bits);
+  st->gg = gg;
+}
+
+// rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
+// grid = (element chunks, row groups of 8); wave w handles rows 2w, 2w+1 of its group.
+__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int count, int cand,
+                                                  const float* __restrict__ S, const float* __restrict__ Y,
+                                                  const float* __restrict__ g, size_t stride,
+                                                  double* __restrict__ part /* [chunks][LB_ROWS][3] */) {
+  const int chunk = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nact = count + 1;  // active slots incl. the candidate
+  const int nrows = 2 * nact + 1;
+  const float* yn = Y + (size_t)cand * stride;
+  const float* sn = S + (size_t)cand * stride;
+  const int e0 = chunk * LB_CHUNK;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = blockIdx.y * 8 + wave * 2 + rr;
+    if (row >= nrows) continue;
+    const float* src;
+    int out_row;
+    if (row < nact) {
+      const int slot = (row < count) ? (head + row) % cap : cand;
+      src = S + (size_t)slot * stride;
+      out_row = slot;
+    } else if (row < 2 * nact) {
+      const int r2 = row - nact;
+      const int slot = (r2 < count) ? (head + r2) % cap : cand;
+      src = Y + (size_t)slot * stride;
+      out_row = LB_MAXH + slot;
+    } else {
+      src = g;
+      out_row = 2 * LB_MAXH;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int i = e0 + lane; i < min(n, e0 + LB_CHUNK); i += 64) {
+      const double v = (double)src[i];
+      a0 += v * (double)yn[i];
+      a1 += v * (double)sn[i];
+      a2 += v * (double)g[i];
+    }
+    a0 = wave_sum_d(a0);
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    if (lane == 0) {
+      double* o = part + ((size_t)chunk * LB_ROWS + out_row) * 3;
+      o[0] = a0;
+      o[1] = a1;
+      o[2] = a2;
+    }
+  }
+}
+
+// one wave: reduce the dot partials, update the Gram matrices and the ring, run the two-loop recursion in
+// coefficient space (torch/optim/lbfgs.py:396-441), write the coefficients of d = cg g + sum cy_j y_j + cs_j s_j.
+__global__ __launch_bounds__(64) void k_lb_small(int nchunks, int cap, int hist, int cand,
+                                                  const double* __restrict__ part, LbDev* __restrict__ st) {
+  __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH];
+  __shared__ double rd[LB_ROWS * 3];
+  const int lane = threadIdx.x;
+  int head = st->head, count = st->count;
+  const int nact = count + 1;
+  // rows needed: active S slots, active Y slots, g
+  for (int e = lane; e < LB_ROWS * 3; e += 64) {
+    double acc = 0.0;
+    for (int c = 0; c < nchunks; ++c) acc += part[(size_t)c * LB_ROWS * 3 + e];
+    rd[e] = acc;
+  }
+  __syncthreads();
+  // candidate row/column of the Gram matrices
+  const double ys = rd[(cand)*3 + 0];              // s_new . y_new
+  const double yy = rd[(LB_MAXH + cand) * 3 + 0];  // y_new . y_new
+  for (int r = lane; r < nact; r += 64) {
+    const int slot = (r < count) ? (head + r) % cap : cand;
+    st->SY[slot * LB_MAXH + cand] = rd[slot * 3 + 0];              // s_slot . y_new
+    st->SY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 1];  // y_slot . s_new = s_new . y_slot
+    st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];  // y_slot . y_new
+    st->YY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 0];
+    Sg[slot] = rd[slot * 3 + 2];
+    Yg[slot] = rd[(LB_MAXH + slot) * 3 + 2];
+  }
+  __syncthreads();
+  const bool accept = ys > 1e-10;
+  double Hdiag = st->Hdiag;
+  if (accept) {
+    if (count == hist) {
+      head = (head + 1) % cap;  // drop the oldest; the candidate slot becomes the newest
+    } else {
+      count += 1;
+    }
+    Hdiag = ys / yy;
+  }
+  const int k = count;
+  // loop 1 (newest -> oldest)
+  for (int i = k - 1; i >= 0; --i) {
+    const int si = (head + i) % cap;
+    double partial = 0.0;
+    for (int j = i + 1 + lane; j < k; j += 64) {
+      const int sj = (head + j) % cap;
+      partial += al[sj] * st->SY[si * LB_MAXH + sj];
+    }
+    partial = wave_sum_d(partial);
+    if (lane == 0) al[si] = (-Sg[si] - partial) / st->SY[si * LB_MAXH + si];
+    __syncthreads();
+  }
+  const double cg = -Hdiag;
+  for (int j = lane; j < k; j += 64) {
+    const int sj = (head + j) % cap;
+    cy_s[sj] = -Hdiag * al[sj];
+    cs_s[sj] = 0.0;
+  }
+  __syncthreads();
+  // loop 2 (oldest -> newest)
+  for (int i = 0; i < k; ++i) {
+    const int si = (head + i) % cap;
+    double partial = 0.0;
+    for (int j = lane; j < k; j += 64) {
+      const int sj = (head + j) % cap;
+      partial += cy_s[sj] * st->YY[si * LB_MAXH + sj];
+      if (j < i) partial += cs_s[sj] * st->SY[sj * LB_MAXH + si];
+    }
+    partial = wave_sum_d(partial);
+    if (lane == 0) {
+      const double yr = cg * Yg[si] + partial;
+      const double be = yr / st->SY[si * LB_MAXH + si];
+      cs_s[si] = al[si] - be;
+    }
+    __syncthreads();
+  }
+  // g . d from the Gram data
+  double gpart = 0.0;
+  for (int j = lane; j < k; j += 64) {
+    const int sj = (head + j) % cap;
+    gpart += cy_s[sj] * Yg[sj] + cs_s[sj] * Sg[sj];
+    st->cy[sj] = cy_s[sj];
+    st->cs[sj] = cs_s[sj];
+  }
+  gpart = wave_sum_d(gpart);
+  if (lane == 0) {
+    const double gg = rd[(2 * LB_MAXH) * 3 + 2];
+    st->cg = cg;
+    st->Hdiag = Hdiag;
+    st->head = head;
+    st->count = count;
+    st->dmax_bits = 0u;
+    LbOut* o = reinterpret_cast<LbOut*>(st->out);
+    o->gtd_dir = cg * gg + gpart;
+    o->accepted = accept ? 1.0 : 0.0;
+    o->ys = ys;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const float* __restrict__ S,
+                                                       const float* __restrict__ Y, const float* __restrict__ g,
+                                                       size_t stride, LbDev* __restrict__ st, float* __restrict__ d) {
+  __shared__ double scy[LB_MAXH], scs[LB_MAXH];
+  __shared__ int sslot[LB_MAXH];
+  const int k = st->count, head = st->head;
+  for (int j = threadIdx.x; j < k; j += 256) {
+    const int sj = (head + j) % cap;
+    sslot[j] = sj;
+    scy[j] = st->cy[sj];
+    scs[j] = st->cs[sj];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float mx = 0.f;
+  if (i < n) {
+    double acc = st->cg * (double)g[i];
+    for (int j = 0; j < k; ++j) {
+      const size_t off = (size_t)sslot[j] * stride + i;
+      acc += scy[j] * (double)Y[off] + scs[j] * (double)S[off];
+    }
+    const float di = (float)acc;
+    d[i] = di;
+    mx = fabsf(di);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&st->dmax_bits, __float_as_uint(mx));
+}
+
+
+// -------------------------------------------------------------------------------------------------- objectives
+struct Objective {
+  int n = 0;
+  virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) = 0;
+  virtual ~Objective() {}
+};
+
+struct StageObjective : Objective {
+  uuo_fit* fit;
+  const uuo_problem_t* p;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) override {
+    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr);
+  }
+};
+
+// test objectives for the optimiser itself (tests/test_lbfgs.py): 0 = convex quadratic with a spread
+// spectrum, 1 = chained Rosenbrock.  loss/grad are computed by one block (n is small in the tests).
+__global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const float* __restrict__ x,
+                                                         float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (kind == 0) {
+      const float a = 1.0f + 99.0f * (float)i / (float)(n > 1 ? n - 1 : 1);
+      const float b = sinf(0.37f * (float)i);
+      const float r = x[i] - b;
+      acc += 0.5 * (double)a * (double)r * (double)r;
+      grad[i] = a * r;
+    } else {
+      float gi = 0.f;
+      if (i + 1 < n) {
+        const float t1 = x[i + 1] - x[i] * x[i];
+        const float t2 = 1.f - x[i];
+        acc += 100.0 * (double)t1 * (double)t1 + (double)t2 * (double)t2;
+        gi += -400.f * x[i] * t1 - 2.f * t2;
+      }
+      if (i > 0) {
+        const float t0 = x[i] - x[i - 1] * x[i - 1];
+        gi += 200.f * t0;
+      }
+      grad[i] = gi;
+    }
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+struct TestObjective : Objective {
+  int kind;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) override {
+    hipLaunchKernelGGL(k_test_objective, dim3(1), dim3(256), 0, s, kind, n, x, loss_dev, grad);
+    UUO_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------- workspace
+struct LbWs {
+  int n_cap = 0, cap = 0;  // vector length capacity, history slots
+  float* S = nullptr;
+  float* Y = nullptr;
+  float* vecs = nullptr;  // LB_NVEC work vectors
+  double* part = nullptr;
+  LbDev* st = nullptr;
+  float* loss_dev = nullptr;
+  double* h_out = nullptr;  // pinned
+  int nchunks = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int lbws_destroy(LbWs* w) {
+  if (!w) return 0;
+  void* ptrs[] = {w->S, w->Y, w->vecs, w->part, w->st, w->loss_dev};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (w->h_out) (void)hipHostFree(w->h_out);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  delete w;
+  return 0;
+}
+
+static int lbws_create(int n, int hist, LbWs** out) {
+  UUO_REQUIRE(hist >= 1 && hist < LB_MAXH, "lbfgs: history_size must be in [1,127]");
+  LbWs* w = new LbWs();
+  w->n_cap = n;
+  w->cap = hist + 1;
+  w->nchunks = (n + LB_CHUNK - 1) / LB_CHUNK;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+  };
+  A((void**)&w->S, (size_t)w->cap * n * sizeof(float));
+  A((void**)&w->Y, (size_t)w->cap * n * sizeof(float));
+  A((void**)&w->vecs, (size_t)LB_NVEC * n * sizeof(float));
+  const size_t part_dots = (size_t)w->nchunks * LB_ROWS * 3;
+  A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
+  A((void**)&w->st, sizeof(LbDev));
+  A((void**)&w->loss_dev, 16 * sizeof(float));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 16 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreate(&w->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&w->ev1);
+  if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
+  if (e != hipSuccess) {
+    lbws_destroy(w);
+    uuo_set_error(std::string("lbfgs workspace: ") + hipGetErrorString(e));
+    return -12;
+  }
+  *out = w;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- driver
+static double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2, bool has_bounds,
+                                double lo, double hi) {
+  double xmin_bound, xmax_bound;
+  if (has_bounds) {
+    xmin_bound = lo;
+    xmax_bound = hi;
+  } else if (x1 <= x2) {
+    xmin_bound = x1;
+    xmax_bound = x2;
+  } else {
+    xmin_bound = x2;
+    xmax_bound = x1;
+  }
+  const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
+  const double d2_square = d1 * d1 - g1 * g2;
+  if (d2_square >= 0.0) {
+    const double d2 = std::sqrt(d2_square);
+    double min_pos;
+    if (x1 <= x2)
+      min_pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2.0 * d2));
+    else
+      min_pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2.0 * d2));
+    return std::fmin(std::fmax(min_pos, xmin_bound), xmax_bound);
+  }
+  return (xmin_bound + xmax_bound) / 2.0;
+}
+
+struct LsPoint {
+  double t = 0, f = 0, gtd = 0;
+  double gmax = 0;
+  int buf = -1;  // index of the work vector holding the gradient
+};
+
+static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
+                     uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
+  const int n = obj.n;
+  UUO_REQUIRE(n > 0 && n <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  UUO_REQUIRE(hist + 1 <= w->cap, "lbfgs: history_size exceeds the workspace");
+  const int cap = hist + 1;
+  const int max_iter = opt->max_iter;
+  const int max_eval = opt->max_eval > 0 ? opt->max_eval : (max_iter * 5) / 4;
+  const double lr = opt->lr, tol_grad = opt->tolerance_grad, tol_change = opt->tolerance_change;
+  const double c1 = 1e-4, c2 = 0.9;
+  const size_t stride = (size_t)w->n_cap;
+  const int nb = (n + 255) / 256;
+  const int nstat = std::min(64, nb);
+  auto vec = [&](int i) { return w->vecs + (size_t)i * stride; };
+  // work vectors: 0 g (gradient at x), 1 d, 2 prev_g, 3 x_trial, 4.. pool for line-search gradients
+  float* g = vec(0);
+  float* d = vec(1);
+  float* prev_g = vec(2);
+  float* xt = vec(3);
+  bool pool_used[LB_NVEC] = {false};
+  auto pool_alloc = [&]() {
+    for (int i = 4; i < LB_NVEC; ++i)
+      if (!pool_used[i]) {
+        pool_used[i] = true;
+        return i;
+      }
+    return -1;
+  };
+  auto pool_free = [&](int i) {
+    if (i >= 4) pool_used[i] = false;
+  };
+  LbOut* ho = reinterpret_cast<LbOut*>(w->h_out);
+  int evals_total = 0;
+
+  // evaluate at x_eval into gradient vector gv; stats against d (or none); read back
+  auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
+    int rc = obj.eval(s, x_eval, w->loss_dev, gv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lb_stats, dim3(nstat), dim3(256), 0, s, n, gv, with_dir ? d : (const float*)nullptr,
+                       w->part);
+    hipLaunchKernelGGL(k_lb_stats_final, dim3(1), dim3(64), 0, s, nstat, w->part, w->loss_dev, w->st);
+    UUO_HIP_CHECK(hipGetLastError());
+    UUO_HIP_CHECK(hipMemcpyAsync(w->h_out, (const char*)w->st + offsetof(LbDev, out), 16 * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+  };
+  auto report = [&](double loss) {
+    if (cb) cb(cb_user, evals_total, (float)loss);
+    if (opt->verbose) std::printf("lbfgs eval %d loss %.9g\n", evals_total, loss);
+    ++evals_total;
+  };
+
+  UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
+  hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, w->st);
+  int rc = evaluate(d_x, g, false);
+  if (rc) return rc;
+  double loss = ho->loss;
+  double gmax = ho->gmax;
+  double g1 = ho->g1;
+  const double gg0 = ho->gg;
+  report(loss);
+  stats->first_loss = (float)loss;
+  int current_evals = 1;
+  int n_iter = 0;
+  int reason = 0;
+  int head = 0, count = 0;
+  double t = 0.0, prev_loss = loss;
+  if (!(gmax > tol_grad)) {
+    reason = 6;
+  } else {
+    while (n_iter < max_iter) {
+      ++n_iter;
+      // ---------------------------------------------------------------- direction
+      int cand = -1;
+      if (n_iter == 1) {
+        hipLaunchKernelGGL(k_lb_neg, dim3(nb), dim3(256), 0, s, n, g, d);
+      } else {
+        cand = (head + count) % cap;
+        float* s_new = w->S + (size_t)cand * stride;
+        float* y_new = w->Y + (size_t)cand * stride;
+        hipLaunchKernelGGL(k_lb_form, dim3(nb), dim3(256), 0, s, n, g, prev_g, d, (float)t, s_new, y_new);
+        const int nrows = 2 * (count + 1) + 1;
+        hipLaunchKernelGGL(k_lb_dots, dim3(w->nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand,
+                           w->S, w->Y, g, stride, w->part);
+        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(64), 0, s, w->nchunks, cap, hist, cand, w->part, w->st);
+        hipLaunchKernelGGL(k_lb_direction, dim3(nb), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st, d);
+      }
+      UUO_HIP_CHECK(hipGetLastError());
+      UUO_HIP_CHECK(hipMemcpyAsync(prev_g, g, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      prev_loss = loss;
+      // ---------------------------------------------------------------- step length guess
+      if (n_iter == 1)
+        t = std::fmin(1.0, 1.0 / g1) * lr;
+      else
+        t = lr;
+      // ---------------------------------------------------------------- first trial (speculative: launched
+      // before g.d is known on the host; discarded if the direction test fails)
+      LsPoint pnew;
+      pnew.buf = pool_alloc();
+      hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)t, d, xt);
+      rc = evaluate(xt, vec(pnew.buf), true);
+      if (rc) return rc;
+      double gtd, d_norm;
+      if (n_iter == 1) {
+        // d = -g: g.d = -g.g, max|d| = max|g|
+        gtd = -gg0;
+        d_norm = gmax;
+      } else {
+        gtd = ho->gtd_dir;
+        d_norm = ho->dmax;
+        if (ho->accepted != 0.0) {
+          if (count == hist)
+            head = (head + 1) % cap;
+          else
+            count += 1;
+        }
+      }
+      if (gtd > -tol_change) {
+        pool_free(pnew.buf);
+        reason = 5;
+        break;
+      }
+      pnew.t = t;
+      pnew.f = ho->loss;
+      pnew.gtd = ho->gtd_new;
+      pnew.gmax = ho->gmax;
+      report(pnew.f);
+      // ---------------------------------------------------------------- strong Wolfe (lbfgs.py:40-209)
+      const int max_ls = max_eval - current_evals;
+      int ls_func_evals = 1;
+      LsPoint p0;  // the point at t = 0
+      p0.t = 0;
+      p0.f = loss;
+      p0.gtd = gtd;
+      p0.gmax = gmax;
+      p0.buf = 0;
+      LsPoint pprev = p0;
+      LsPoint br[2];
+      int nbr = 0;
+      bool done = false;
+      int ls_iter = 0;
+      while (ls_iter < max_ls) {
+        if (pnew.f > (loss + c1 * pnew.t * gtd) || (ls_iter > 1 && pnew.f >= pprev.f)) {
+          br[0] = pprev;
+          br[1] = pnew;
+          nbr = 2;
+          break;
+        }
+        if (std::fabs(pnew.gtd) <= -c2 * gtd) {
+          br[0] = pnew;
+          nbr = 1;
+          done = true;
+          if (pprev.buf != 0) pool_free(pprev.buf);
+          break;
+        }
+        if (pnew.gtd >= 0) {
+          br[0] = pprev;
+          br[1] = pnew;
+          nbr = 2;
+          break;
+        }
+        const double min_step = pnew.t + 0.01 * (pnew.t - pprev.t);
+        const double max_step = pnew.t * 10;
+        const double t_next = cubic_interpolate(pprev.t, pprev.f, pprev.gtd, pnew.t, pnew.f, pnew.gtd, true, min_step,
+                                                max_step);
+        if (pprev.buf != 0) pool_free(pprev.buf);
+        pprev = pnew;
+        pnew = LsPoint();
+        pnew.buf = pool_alloc();
+        UUO_REQUIRE(pnew.buf >= 0, "lbfgs: line-search buffer pool exhausted");
+        pnew.t = t_next;
+        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)pnew.t, d, xt);
+        rc = evaluate(xt, vec(pnew.buf), true);
+        if (rc) return rc;
+        pnew.f = ho->loss;
+        pnew.gtd = ho->gtd_new;
+        pnew.gmax = ho->gmax;
+        report(pnew.f);
+        ++ls_func_evals;
+        ++ls_iter;
+      }
+      if (nbr == 0) {  // ls_iter == max_ls
+        br[0] = p0;
+        br[1] = pnew;
+        nbr = 2;
+        if (pprev.buf != 0 && pprev.buf != pnew.buf) pool_free(pprev.buf);
+      }
+      bool insuf_progress = false;
+      int low_pos, high_pos;
+      if (br[0].f <= br[nbr - 1].f) {
+        low_pos = 0;
+        high_pos = 1;
+      } else {
+        low_pos = 1;
+        high_pos = 0;
+      }
+      while (!done && ls_iter < max_ls) {
+        if (std::fabs(br[1].t - br[0].t) * d_norm < tol_change) break;
+        double tz = cubic_interpolate(br[0].t, br[0].f, br[0].gtd, br[1].t, br[1].f, br[1].gtd, false, 0, 0);
+        const double bmax = std::fmax(br[0].t, br[1].t), bmin = std::fmin(br[0].t, br[1].t);
+        const double eps = 0.1 * (bmax - bmin);
+        if (std::fmin(bmax - tz, tz - bmin) < eps) {
+          if (insuf_progress || tz >= bmax || tz <= bmin) {
+            if (std::fabs(tz - bmax) < std::fabs(tz - bmin))
+              tz = bmax - eps;
+            else
+              tz = bmin + eps;
+            insuf_progress = false;
+          } else {
+            insuf_progress = true;
+          }
+        } else {
+          insuf_progress = false;
+        }
+        LsPoint pz;
+        pz.buf = pool_alloc();
+        UUO_REQUIRE(pz.buf >= 0, "lbfgs: line-search buffer pool exhausted");
+        pz.t = tz;
+        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)pz.t, d, xt);
+        rc = evaluate(xt, vec(pz.buf), true);
+        if (rc) return rc;
+        pz.f = ho->loss;
+        pz.gtd = ho->gtd_new;
+        pz.gmax = ho->gmax;
+        report(pz.f);
+        ++ls_func_evals;
+        ++ls_iter;
+        if (pz.f > (loss + c1 * pz.t * gtd) || pz.f >= br[low_pos].f) {
+          if (br[high_pos].buf != 0) pool_free(br[high_pos].buf);
+          br[high_pos] = pz;
+          if (br[0].f <= br[1].f) {
+            low_pos = 0;
+            high_pos = 1;
+          } else {
+            low_pos = 1;
+            high_pos = 0;
+          }
+        } else {
+          if (std::fabs(pz.gtd) <= -c2 * gtd) {
+            done = true;
+          } else if (pz.gtd * (br[high_pos].t - br[low_pos].t) >= 0) {
+            if (br[high_pos].buf != 0) pool_free(br[high_pos].buf);
+            br[high_pos] = br[low_pos];
+            br[low_pos] = pz;
+            continue;
+          }
+          // new point becomes new low (the old low is dropped unless it was just moved to high)
+          if (br[low_pos].buf != 0) pool_free(br[low_pos].buf);
+          br[low_pos] = pz;
+        }
+      }
+      const LsPoint res = (nbr == 1) ? br[0] : br[low_pos];
+      // ---------------------------------------------------------------- accept
+      t = res.t;
+      loss = res.f;
+      gmax = res.gmax;
+      if (res.buf != 0)
+        UUO_HIP_CHECK(hipMemcpyAsync(g, vec(res.buf), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)t, d, d_x);
+      UUO_HIP_CHECK(hipGetLastError());
+      for (int i = 4; i < LB_NVEC; ++i) pool_used[i] = false;
+      current_evals += ls_func_evals;
+      // ---------------------------------------------------------------- termination (lbfgs.py:511-526)
+      if (n_iter == max_iter) {
+        reason = 0;
+        break;
+      }
+      if (current_evals >= max_eval) {
+        reason = 1;
+        break;
+      }
+      if (gmax <= tol_grad) {
+        reason = 2;
+        break;
+      }
+      if (d_norm * std::fabs(t) <= tol_change) {
+        reason = 3;
+        break;
+      }
+      if (std::fabs(loss - prev_loss) < tol_change) {
+        reason = 4;
+        break;
+      }
+    }
+  }
+  UUO_HIP_CHECK(hipEventRecord(w->ev1, s));
+  UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
+  float ms = 0.f;
+  UUO_HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+  stats->n_iter = n_iter;
+  stats->n_eval = current_evals;
+  stats->final_loss = (float)loss;
+  stats->stop_reason = reason;
+  stats->device_ms = ms;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- fit workspace
+extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out) {
+  UUO_REQUIRE(model && out, "uuo_fit_create: null argument");
+  UUO_REQUIRE(F > 0 && M > 0, "uuo_fit_create: F and M must be positive");
+  uuo_fit* fit = new uuo_fit();
+  fit->model = model;
+  fit->F = F;
+  fit->M = M;
+  fit->nFT = (F + 31) / 32;
+  fit->n_max = 219 * F + 10;
+  const int nFT = fit->nFT;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+    if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+  };
+  A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * 32 * sizeof(float));
+  A((void**)&fit->A, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float));
+  A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
+  A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
+  A((void**)&fit->frame_part, (size_t)F * 16 * sizeof(float));
+  A((void**)&fit->mask, (size_t)F * M * sizeof(float));
+  A((void**)&fit->scalars, 64 * sizeof(float));
+  A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
+  if (e == hipSuccess) e = hipEventCreate(&fit->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&fit->ev1);
+  if (e != hipSuccess) {
+    uuo_set_error(std::string("uuo_fit_create: ") + hipGetErrorString(e));
+    uuo_fit_destroy(fit);
+    return -12;
+  }
+  *out = fit;
+  return 0;
+}
+
+extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
+  if (!fit) return 0;
+  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn, fit->frame_part, fit->mask, fit->scalars, fit->vecs};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (fit->ev0) (void)hipEventDestroy(fit->ev0);
+  if (fit->ev1) (void)hipEventDestroy(fit->ev1);
+  if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);
+  delete fit;
+  return 0;
+}
+
+extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                               const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
+                               void* cb_user) {
+  int rc = uuo_validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && opt && stats, "uuo_lbfgs_solve: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve: max_iter must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = (LbWs*)fit->lbws;
+  if (!w || w->cap < hist + 1) {
+    if (w) lbws_destroy(w);
+    fit->lbws = nullptr;
+    rc = lbws_create(fit->n_max, hist, &w);
+    if (rc) return rc;
+    fit->lbws = w;
+  }
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  StageObjective obj;
+  obj.fit = fit;
+  obj.p = p;
+  obj.n = uuo_problem_num_params(p);
+  std::memset(stats, 0, sizeof(*stats));
+  return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
+}
+
+// optimiser self-test on analytic objectives (tests/test_lbfgs.py compares with torch.optim.LBFGS on the CPU)
+extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, const uuo_lbfgs_options_t* opt,
+                                  uuo_lbfgs_stats_t* stats) {
+  UUO_REQUIRE(d_x && opt && stats && n > 0 && (kind == 0 || kind == 1), "uuo_lbfgs_selftest: bad arguments");
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = nullptr;
+  int rc = lbws_create(n, hist, &w);
+  if (rc) return rc;
+  TestObjective obj;
+  obj.kind = kind;
+  obj.n = n;
+  std::memset(stats, 0, sizeof(*stats));
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, nullptr, nullptr);
+  lbws_destroy(w);
+  return rc;
+}

@@ -1,0 +1,122 @@
+// Shared declarations for libuuo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/uuo_hip.h"
+
+#define UUO_KP 220        // padded K of the augmented blend GEMM: 207 pose features | 10 betas | 3 zero
+#define UUO_KB 208        // padded K of the per-vertex transposed posedirs rows
+#define UUO_FT 32         // frames per MFMA row tile
+#define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
+
+void uuo_set_error(const std::string& msg);
+
+#define UUO_HIP_CHECK(expr)                                                                      \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      uuo_set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" +  \
+                    std::to_string(__LINE__));                                                   \
+      return -5;                                                                                 \
+    }                                                                                            \
+  } while (0)
+
+#define UUO_REQUIRE(cond, msg)        \
+  do {                                \
+    if (!(cond)) {                    \
+      uuo_set_error(msg);             \
+      return -22;                     \
+    }                                 \
+  } while (0)
+
+// Small per-model constant tables read by every frame kernel.
+struct UuoTree {
+  int parent[UUO_NUM_JOINTS];
+  int depth[UUO_NUM_JOINTS];
+  int max_depth;
+  int nchild[UUO_NUM_JOINTS];
+  int child[UUO_NUM_JOINTS][4];  // children in ascending joint order (deterministic backward sweep)
+  float Jt[UUO_NUM_JOINTS][3];      // J_regressor . v_template
+  float JS[UUO_NUM_JOINTS][3][10];  // J_regressor . shapedirs
+  int extra_vids[UUO_NUM_EXTRA_JOINTS];
+};
+
+struct uuo_model {
+  int V = 0;    // vertices
+  int VP = 0;   // padded to a multiple of 128
+  int nnz = 0;  // max non-zero skin weights per vertex (sparse path iff <= 4)
+  // device tables
+  float* P3 = nullptr;    // [3][UUO_KP][VP]   coordinate-planar blend basis: posedirs rows then shapedirs rows
+  float* vt3 = nullptr;   // [3][VP]           template, coordinate-planar
+  float* PT = nullptr;    // [V][3][UUO_KB]    per-vertex posedirs rows (backward / gather-LBS)
+  float* ST = nullptr;    // [V][3][10]        shapedirs
+  float* vt = nullptr;    // [V][3]
+  float* W = nullptr;     // [V][24]           dense skin weights
+  int* Wi = nullptr;      // [VP][4]           sparse joint ids (ascending), -1 padded -> 0 weight
+  float* Ww = nullptr;    // [VP][4]
+  UuoTree* tree = nullptr;  // device copy
+  UuoTree h_tree;
+  // scratch for uuo_smpl_forward (grown on demand)
+  int fwd_cap = 0;
+  float* fwd_pfaT = nullptr;
+  float* fwd_A = nullptr;
+  float* fwd_jp = nullptr;
+};
+
+// How the frame kernels obtain the 24 rotations and the shape for frame f.
+enum { UUO_ROOT_RAW = 0, UUO_ROOT_GS = 1, UUO_ROOT_Z_GS = 2, UUO_ROOT_ZSHARED = 3 };
+
+struct UuoPoseSrc {
+  const float* body;   // [F,23,9]
+  int norm_body;       // Gram-Schmidt (rotation_6d round trip) on the body rotations
+  const float* root;   // [F,9]
+  int root_mode;       // UUO_ROOT_*
+  const float* z;      // [F] (Z_GS) or [1] (ZSHARED)
+  const float* betas;  // [10] or [F,10]
+  int betas_stride;    // 0 or 10
+  const float* trans;  // [F,3] or null
+};
+
+struct uuo_fit {
+  uuo_model* model = nullptr;
+  int F = 0, M = 0, nFT = 0;
+  int n_max = 0;  // 219F+10
+  // closure workspace
+  float* pfaT = nullptr;            // [nFT][UUO_KP][32]
+  float* A = nullptr;               // [nFT*32][24][12]
+  float* verts = nullptr;           // [F][V][3]
+  unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
+  float* frame_part = nullptr;      // [F][16]: loss, dz, dbeta[10], pad
+  float* mask = nullptr;            // [F][M] 0/1
+  float* scalars = nullptr;         // device scalars block (see solver)
+  float* vecs = nullptr;            // one work vector of n_max floats (timing helper gradient)
+  void* lbws = nullptr;             // L-BFGS workspace (solver.hip), created on first solve
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float mask_sum = 0.f;  // host copy of sum(mask) (chamfer normaliser), refreshed by uuo_ensure_mask
+};
+
+// ---- kernel launchers (defined in the .hip files) --------------------------------------------------
+int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
+                         float* joints_posed);
+int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
+                    const float* trans, float* verts);
+int uuo_launch_joints45(const uuo_model* m, hipStream_t s, int F, const float* joints_posed, const float* verts,
+                        float* joints45);
+int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub,
+                  int P2s, unsigned long long* packed);
+int uuo_launch_nn_unpack(hipStream_t s, int count, const unsigned long long* packed, float* dist, int32_t* idx);
+int uuo_launch_assign(hipStream_t s, int F, int M, int V, const float* verts, const float* markers,
+                      const uint8_t* valid, int32_t* idx, unsigned long long* packed);
+int uuo_launch_mask(hipStream_t s, int F, int M, const float* markers, float* mask, float* mask_sum_dev);
+int uuo_launch_bwd(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& p, const UuoPoseSrc& src,
+                   const float* x, float* grad, float inv_count);
+int uuo_launch_finalize(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& p, const float* x, float* grad,
+                        float* loss);
+
+// closure internals shared with the solver (closure.hip)
+int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p);
+int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p);
+int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
+                          float* d_grad, int32_t* d_nn_idx);

@@ -1,0 +1,277 @@
+"""Thin host layer over libuuo_hip.so: device model, per-sequence workspace and the three stage problems.
+
+torch is used for device memory and the current HIP stream only; every numerical step of the fitted path
+is a kernel behind the C ABI (include/uuo_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_float, c_void_p
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EVAL_CALLBACK, UUO_STAGE_CHAMFER, UUO_STAGE_MARKER, UUO_STAGE_PART, UuoLbfgsOptions,
+                   UuoLbfgsStats, UuoProblem, check)
+from .body_model import SmplTables
+
+MARKER_DISTANCE = 0.0095  # reference utils/settings.py:1
+
+STOP_REASONS = ["max_iter", "max_eval", "tolerance_grad", "tolerance_change(step)", "tolerance_change(loss)",
+                "directional_derivative", "initial_tolerance_grad"]
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the fitted path has no CPU implementation" % name)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    _require_cuda(t, name)
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def current_stream(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class DeviceModel:
+    """Owns a uuo_model_t (device copies of the SMPL tables) and the per-(F, M) fit workspaces."""
+
+    def __init__(self, tables: SmplTables, device: torch.device):
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("DeviceModel needs a CUDA/HIP device (got %s); there is no CPU path" % device)
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.tables = tables
+        self.V = int(tables.v_template.shape[0])
+        handle = c_void_p()
+        arrs = [np.ascontiguousarray(tables.v_template, np.float32), np.ascontiguousarray(tables.shapedirs, np.float32),
+                np.ascontiguousarray(tables.posedirs, np.float32), np.ascontiguousarray(tables.J_regressor, np.float32),
+                np.ascontiguousarray(tables.lbs_weights, np.float32), np.ascontiguousarray(tables.parents, np.int64),
+                np.ascontiguousarray(tables.extra_joint_vids, np.int64)]
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_model_create(*[a.ctypes.data for a in arrs], self.V, byref(handle)), "uuo_model_create")
+        self.handle = handle
+        self._fits: Dict = {}
+
+    def fit(self, F: int, M: int) -> c_void_p:
+        key = (int(F), int(M))
+        if key not in self._fits:
+            h = c_void_p()
+            with torch.cuda.device(self.device):
+                check(self.lib.uuo_fit_create(self.handle, key[0], key[1], byref(h)), "uuo_fit_create")
+            self._fits[key] = h
+        return self._fits[key]
+
+    def close(self):
+        for h in self._fits.values():
+            self.lib.uuo_fit_destroy(h)
+        self._fits = {}
+        if self.handle:
+            self.lib.uuo_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- operators -------------------------------------------------------------------------------
+    def smpl_forward(self, poses, betas, root_orient, trans, want_joints: bool = True):
+        """uuo_smpl_forward: poses [F,23,3,3], betas [1|F,10], root_orient [F,1,3,3], trans [F,3]|None."""
+        poses = _f32(poses, "poses")
+        betas = _f32(betas, "betas")
+        root = _f32(root_orient, "root_orient")
+        F = poses.shape[0]
+        tr = _f32(trans, "trans") if trans is not None else None
+        verts = torch.empty((F, self.V, 3), dtype=torch.float32, device=self.device)
+        joints = torch.empty((F, 45, 3), dtype=torch.float32, device=self.device) if want_joints else None
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_smpl_forward(self.handle, current_stream(self.device), F, _ptr(poses), _ptr(betas),
+                                            int(betas.shape[0]), _ptr(root), _ptr(tr), _ptr(verts), _ptr(joints)),
+                  "uuo_smpl_forward")
+        return verts, joints
+
+    def nn_argmin(self, x, y, y_subset=None):
+        """uuo_nn_argmin: x [N,P1,3], y [N,P2,3] -> (dist [N,P1] fp32, idx [N,P1] int32)."""
+        x = _f32(x, "x")
+        y = _f32(y, "y")
+        N, P1, P2 = x.shape[0], x.shape[1], y.shape[1]
+        sub = y_subset.to(torch.int32).contiguous() if y_subset is not None else None
+        dist = torch.empty((N, P1), dtype=torch.float32, device=self.device)
+        idx = torch.empty((N, P1), dtype=torch.int32, device=self.device)
+        ws = torch.empty((max(N * P1, 1),), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_nn_argmin(current_stream(self.device), N, P1, P2, _ptr(x), _ptr(y), _ptr(sub),
+                                         int(sub.numel()) if sub is not None else 0, _ptr(dist), _ptr(idx), _ptr(ws)),
+                  "uuo_nn_argmin")
+        return dist, idx
+
+    def assign_mean_argmin(self, verts, markers, valid):
+        """uuo_assign_mean_argmin -> idx [M] int32."""
+        verts = _f32(verts, "verts")
+        markers = _f32(markers, "markers")
+        valid_u8 = valid.to(device=self.device, dtype=torch.uint8).contiguous()
+        F, V, M = verts.shape[0], verts.shape[1], markers.shape[1]
+        idx = torch.empty((M,), dtype=torch.int32, device=self.device)
+        ws = torch.empty((M,), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_assign_mean_argmin(current_stream(self.device), F, M, V, _ptr(verts), _ptr(markers),
+                                                  _ptr(valid_u8), _ptr(idx), _ptr(ws)), "uuo_assign_mean_argmin")
+        return idx
+
+
+class _StageProblem:
+    """One L-BFGS problem of the fit on a flat device vector in the reference's parameter packing."""
+
+    stage = -1
+
+    def __init__(self, model: DeviceModel, markers, o_pose, o_betas, root, w_data, w_pose, w_betas,
+                 assign=None, subset=None):
+        self.model = model
+        self.lib = model.lib
+        self.device = model.device
+        self.markers = _f32(markers, "markers")
+        self.F, self.M = int(self.markers.shape[0]), int(self.markers.shape[1])
+        self.o_pose = _f32(o_pose, "o_pose_body").reshape(self.F, 23, 9)
+        self.o_betas = _f32(o_betas, "o_betas").reshape(-1)[:10].contiguous()
+        self.root = _f32(root, "root_orient").reshape(self.F, 9) if root is not None else None
+        self.assign = assign.to(device=self.device, dtype=torch.int32).contiguous() if assign is not None else None
+        self.subset = subset.to(device=self.device, dtype=torch.int32).contiguous() if subset is not None else None
+        self.fit = model.fit(self.F, self.M)
+        p = UuoProblem()
+        p.stage, p.F, p.M = self.stage, self.F, self.M
+        p.d_markers = self.markers.data_ptr()
+        p.d_o_pose = self.o_pose.data_ptr()
+        p.d_o_betas = self.o_betas.data_ptr()
+        p.d_root = self.root.data_ptr() if self.root is not None else None
+        p.d_assign = self.assign.data_ptr() if self.assign is not None else None
+        p.d_subset = self.subset.data_ptr() if self.subset is not None else None
+        p.n_subset = int(self.subset.numel()) if self.subset is not None else 0
+        p.w_data, p.w_pose, p.w_betas = float(w_data), float(w_pose), float(w_betas)
+        p.marker_distance = MARKER_DISTANCE
+        self.problem = p
+        self.n = int(self.lib.uuo_problem_num_params(byref(p)))
+
+    def evaluate(self, x: torch.Tensor, want_nn: bool = True):
+        """One closure evaluation: (loss, flat grad, nn index [F,M] int32 | None)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        loss = torch.empty((1,), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.n,), dtype=torch.float32, device=self.device)
+        nn = None
+        if want_nn and self.stage != UUO_STAGE_MARKER:
+            nn = torch.empty((self.F, self.M), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_closure_eval(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
+                                            _ptr(loss), _ptr(grad), _ptr(nn)), "uuo_closure_eval")
+        return float(loss.item()), grad, nn
+
+    def solve(self, x: torch.Tensor, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
+              tolerance_change: float = 1e-9, history_size: int = 100,
+              callback: Optional[Callable[[int, float], None]] = None) -> Dict:
+        """torch.optim.LBFGS(..., line_search_fn="strong_wolfe").step(closure) on the device; x updated in place."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
+                              float(tolerance_change), 0, 0)
+        stats = UuoLbfgsStats()
+        cb = EVAL_CALLBACK(lambda user, i, loss: callback(i, loss)) if callback is not None else None
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_lbfgs_solve(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
+                                           byref(opt), byref(stats), ctypes.cast(cb, c_void_p) if cb else None, None),
+                  "uuo_lbfgs_solve")
+        return {"n_iter": stats.n_iter, "n_eval": stats.n_eval, "first_loss": stats.first_loss,
+                "final_loss": stats.final_loss, "stop_reason": STOP_REASONS[stats.stop_reason],
+                "device_ms": stats.device_ms}
+
+    def time_closure(self, x: torch.Tensor, iters: int = 20, dominant_only: bool = False) -> float:
+        ms = c_float(0.0)
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_time_closure(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
+                                            int(iters), int(dominant_only), byref(ms)), "uuo_time_closure")
+        return float(ms.value)
+
+
+def _cfg_weights(losses: Dict, data_key: str):
+    return (float(losses.get(data_key, 0.0)), float(losses.get("reg_pose_body", 0.0)),
+            float(losses.get("reg_betas", 0.0)))
+
+
+class ChamferProblem(_StageProblem):
+    """closure_stage_chamfer (reference optimization.py:187-275); x = [trans 3F | z F | betas 10 | pose 207F]."""
+
+    stage = UUO_STAGE_CHAMFER
+
+    def __init__(self, smpl_inference, markers, o_pose_body, o_betas, root_orient, config):
+        losses = config["stages"]["chamfer"]["losses"]
+        unsupported = set(losses) - {"full_chamfer", "reg_pose_body", "reg_betas"}
+        if unsupported:
+            raise NotImplementedError("chamfer-stage losses outside the shipped configs: %s" % sorted(unsupported))
+        if not config["stages"]["chamfer"]["yaw_lock"]:
+            raise NotImplementedError("stages.chamfer.yaw_lock False is not a shipped configuration")
+        wd, wp, wb = _cfg_weights(losses, "full_chamfer")
+        super().__init__(smpl_inference.device_model, markers, o_pose_body, o_betas, root_orient, wd, wp, wb)
+
+    def pack(self, trans, z_angle, betas, pose_body):
+        return torch.cat([_f32(trans, "trans").reshape(-1), _f32(z_angle, "z").reshape(-1),
+                          _f32(betas, "betas").reshape(-1), _f32(pose_body, "pose").reshape(-1)]).contiguous()
+
+    def unpack(self, x):
+        F = self.F
+        return (x[:3 * F].reshape(F, 3), x[3 * F:4 * F].reshape(F, 1, 1), x[4 * F:4 * F + 10].reshape(1, 10),
+                x[4 * F + 10:].reshape(F, 23, 3, 3))
+
+
+class MarkerProblem(_StageProblem):
+    """closure_stage_marker_pose (reference optimization.py:329-394); x = [pose 207F | betas 10 | root 9F | trans 3F]."""
+
+    stage = UUO_STAGE_MARKER
+
+    def __init__(self, smpl_inference, markers, o_pose_body, o_betas, assign, config):
+        st = config["stages"]["marker"]
+        unsupported = set(st["losses"]) - {"marker", "reg_pose_body", "reg_betas"}
+        if unsupported:
+            raise NotImplementedError("marker-stage losses outside the shipped configs: %s" % sorted(unsupported))
+        if st.get("use_sdf"):
+            raise NotImplementedError("stages.marker.use_sdf is off in every shipped config")
+        wd, wp, wb = _cfg_weights(st["losses"], "marker")
+        super().__init__(smpl_inference.device_model, markers, o_pose_body, o_betas, None, wd, wp, wb, assign=assign)
+
+    def pack(self, pose_body, betas, root_orient, trans):
+        return torch.cat([_f32(pose_body, "pose").reshape(-1), _f32(betas, "betas").reshape(-1),
+                          _f32(root_orient, "root").reshape(-1), _f32(trans, "trans").reshape(-1)]).contiguous()
+
+    def unpack(self, x):
+        F = self.F
+        return (x[:207 * F].reshape(F, 23, 3, 3), x[207 * F:207 * F + 10].reshape(1, 10),
+                x[207 * F + 10:216 * F + 10].reshape(F, 1, 3, 3), x[216 * F + 10:].reshape(F, 3))
+
+
+class PartProblem(_StageProblem):
+    """closure_fit_subtree (reference markers/markers_utils.py:454-562); x = [z 1 | trans 3F | betas 10]."""
+
+    stage = UUO_STAGE_PART
+
+    def __init__(self, smpl_inference, markers, pose_body, o_betas, root_orient, vertex_indices, config):
+        losses = config["stages"]["part"]["losses"]
+        unsupported = set(losses) - {"chamfer", "reg_betas"}
+        if unsupported:
+            raise NotImplementedError("part-stage losses outside the shipped configs: %s" % sorted(unsupported))
+        super().__init__(smpl_inference.device_model, markers, pose_body, o_betas, root_orient,
+                         float(losses.get("chamfer", 0.0)), 0.0, float(losses.get("reg_betas", 0.0)),
+                         subset=vertex_indices)
+
+    def pack(self, z_angle, trans, betas):
+        return torch.cat([_f32(z_angle, "z").reshape(-1), _f32(trans, "trans").reshape(-1),
+                          _f32(betas, "betas").reshape(-1)]).contiguous()
+
+    def unpack(self, x):
+        F = self.F
+        return x[:1].reshape(1, 1, 1), x[1:3 * F + 1].reshape(F, 3), x[3 * F + 1:].reshape(1, 10)

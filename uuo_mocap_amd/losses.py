@@ -1,0 +1,83 @@
+"""Loss operators with the reference's signatures (reference src/video_mocap/losses/chamfer_distance.py:5-21,
+losses/losses.py:43-51)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .engine import _f32, _ptr, check, current_stream
+
+
+class _Knn1(torch.autograd.Function):
+    """K=1 nearest neighbour on the GPU (uuo_nn_argmin).  Backward = pytorch3d's knn backward:
+    g = 2*grad*(x - y[idx]); +g to x, -g scattered to y[idx]."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        xd, yd = _f32(x, "x"), _f32(y, "y")
+        N, P1, P2 = xd.shape[0], xd.shape[1], yd.shape[1]
+        dist = torch.empty((N, P1), dtype=torch.float32, device=xd.device)
+        idx = torch.empty((N, P1), dtype=torch.int32, device=xd.device)
+        ws = torch.empty((max(N * P1, 1),), dtype=torch.int64, device=xd.device)
+        with torch.cuda.device(xd.device):
+            check(lib.uuo_nn_argmin(current_stream(xd.device), N, P1, P2, _ptr(xd), _ptr(yd), None, 0, _ptr(dist),
+                                    _ptr(idx), _ptr(ws)), "uuo_nn_argmin")
+        idx64 = idx.long()
+        ctx.save_for_backward(xd, yd, idx64)
+        ctx.mark_non_differentiable(idx64)
+        return dist, idx64
+
+    @staticmethod
+    def backward(ctx, grad_dist, _):
+        x, y, idx = ctx.saved_tensors
+        gidx = idx[..., None].expand(-1, -1, 3)
+        g = 2.0 * grad_dist[..., None] * (x - torch.gather(y, 1, gidx))
+        gy = torch.zeros_like(y)
+        gy.scatter_add_(1, gidx, -g)
+        return g, gy
+
+
+def knn_points_k1(x: torch.Tensor, y: torch.Tensor):
+    """(squared distances [N,P1], indices [N,P1] int64) of each x point's nearest y point (first index on ties)."""
+    return _Knn1.apply(x, y)
+
+
+def chamfer_distance(x, y, weights=None, single_directional: bool = False):
+    """pytorch3d.loss.chamfer_distance with its defaults (mean/mean, squared L2), as the reference calls it at
+    markers/markers_utils.py:471-475,575-579."""
+    N = x.shape[0]
+
+    def one_way(a, b):
+        d, _ = knn_points_k1(a, b)
+        if weights is not None:
+            if weights.sum() == 0.0:
+                return (a.sum((1, 2)) * weights).sum() * 0.0
+            d = d * weights.view(N, 1)
+        d = d.sum(1) / float(max(a.shape[1], 1))
+        div = weights.sum() if weights is not None else max(N, 1)
+        return d.sum() / div
+
+    cham = one_way(x, y)
+    if not single_directional:
+        cham = cham + one_way(y, x)
+    return cham, None
+
+
+def weighted_chamfer_distance(x: torch.Tensor, y: torch.Tensor, x_weights: torch.Tensor,
+                              single_directional: bool = False):
+    """sum_{n,i} w[n,i] * min_j |x[n,i]-y[n,j]|^2 / sum(w)  (the reference flattens to one cloud per marker and
+    repeats y per marker -- 1.24 GB at F=300, M=50; here y is read in place).  Like the reference
+    (chamfer_distance.py:19) the `single_directional` argument is ignored: always marker -> vertex."""
+    d, _ = knn_points_k1(x, y)
+    w = x_weights.to(d.dtype) if x_weights.dtype != d.dtype else x_weights
+    wsum = x_weights.sum()
+    if wsum == 0.0:
+        return (x.sum() * 0.0), None
+    return (d * w).sum() / wsum, None
+
+
+def MarkerLoss(markers, virtual_markers, marker_weights, marker_distance):
+    """[F,M] squared deviation of the marker-to-skin distance from `marker_distance`, masked."""
+    gap = torch.norm(markers - virtual_markers, dim=-1) - marker_distance
+    return gap ** 2 * marker_weights

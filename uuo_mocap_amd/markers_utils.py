@@ -1,0 +1,186 @@
+"""Part stage with the reference's interface: rigid marker clustering, SMPL sub-hierarchy enumeration and
+``find_best_part_fits`` (reference src/video_mocap/markers/markers_utils.py:244-271,274-638 and
+utils/smpl_utils.py:106-188, utils/aabb.py:5-25).  Host logic stays Python; every L-BFGS solve and every
+nearest-neighbour query runs on the GPU through libuuo_hip.so."""
+from __future__ import annotations
+
+import itertools
+from collections.abc import Callable
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from .body_model import SMPL_JOINT_NAMES
+from .engine import PartProblem
+from .losses import chamfer_distance
+from .transforms import compute_root_orient_z
+
+LAST_STATS: Dict[str, list] = {}
+
+
+def get_joint_name(joint_id: int) -> str:
+    return SMPL_JOINT_NAMES[joint_id]
+
+
+def get_joint_id(joint_name: str) -> int:
+    return SMPL_JOINT_NAMES.index(joint_name)
+
+
+def get_aabb(points: torch.Tensor) -> torch.Tensor:
+    """[F, P, 3] -> [F, 3, 2] (min, max) per axis."""
+    lo = torch.min(points, dim=1)[0]
+    hi = torch.max(points, dim=1)[0]
+    return torch.stack([lo, hi], dim=-1)
+
+
+def get_aabb_volume(aabb: torch.Tensor) -> torch.Tensor:
+    d = aabb[:, :, 1] - aabb[:, :, 0]
+    return d[:, 0] * d[:, 1] * d[:, 2]
+
+
+def segment_rigid(points: np.ndarray) -> List[List[int]]:
+    """Clusters markers that keep their mutual distance over time (std of the pairwise distance, average-linkage
+    agglomerative clustering cut at 5 mm).  points [F, M, 3] -> list of marker-id lists."""
+    from sklearn.cluster import AgglomerativeClustering
+
+    num_markers = points.shape[1]
+    mat = np.zeros((num_markers, num_markers))
+    for i in range(num_markers):  # per-pair 1-D reductions, so the fp32 values match the reference's exactly
+        for j in range(num_markers):
+            mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1))
+    labels = AgglomerativeClustering(n_clusters=None, distance_threshold=0.005, metric="precomputed",
+                                     linkage="average").fit(mat).labels_
+    return [np.where(labels == v)[0].tolist() for v in np.unique(labels).tolist()]
+
+
+def get_sub_hierachies(parents, num_bones: int) -> List[List[int]]:
+    """All connected sub-trees of the kinematic tree with exactly `num_bones` joints, enumerated in the reference's
+    order (it decides which candidate wins ties).  Name keeps the reference's spelling."""
+    parents_np = parents if isinstance(parents, np.ndarray) else parents.detach().cpu().numpy()
+    n = int(parents_np.shape[0])
+    num_bones = min(num_bones, n)
+    kids: Dict[int, List[int]] = {i: [] for i in range(n)}
+    for i in range(1, n):
+        kids[int(parents_np[i])].append(i)
+    rooted: Dict[int, List[List[int]]] = {}
+    for node in reversed(range(n)):  # children carry larger ids, so they are finished first
+        options = [[]]
+        for pick in itertools.product(*[rooted[c] for c in kids[node]]):
+            merged = sorted(j for part in pick for j in part)
+            cand = [node] + merged
+            if cand not in options:
+                options.append(cand)
+        rooted[node] = options
+    return [st for node in reversed(range(n)) for st in rooted[node] if len(st) == num_bones]
+
+
+def remove_approximately_redundant_hierarchies(subtrees_list: List[List[int]], similarity_threshold: float = 0.9):
+    kept = [subtrees_list[0]]
+    for st in subtrees_list[1:]:
+        limit = len(st) * similarity_threshold
+        if all(len(set(st) & set(k)) <= limit for k in kept):
+            kept.append(st)
+    print("Retained", str(len(kept)) + "/" + str(len(subtrees_list)), "elements")
+    return kept
+
+
+def find_best_part_fits(
+    markers: torch.Tensor,  # [F, M, 3]
+    pose_body: torch.Tensor,  # [F, J-1, 3, 3]
+    betas: torch.Tensor,  # [1, 10]
+    root_orient: torch.Tensor,  # [F, 1, 3, 3]
+    marker_labels: torch.Tensor,  # [F, M]
+    smpl_inference,
+    hierarchy: torch.Tensor,  # [J]
+    joints_2d_gt: torch.Tensor,
+    focal_length: torch.Tensor,
+    reproject_mask: torch.Tensor,
+    camera_center: torch.Tensor,
+    cam_trans: torch.Tensor,
+    config: Dict,
+    foot_contacts: torch.Tensor = None,
+    visualize_fn=None,
+    iter_fn: Callable = None,
+):
+    """Rigidly aligns the HMR body to the marker cloud for every candidate body part (yaw about z, translation,
+    shape) and keeps the best by two-directional chamfer distance.  Returns the reference's dict."""
+    st = config["stages"]["part"]
+    if st["mode"] != "cluster":
+        raise NotImplementedError("stages.part.mode 'network' needs segmenter checkpoints the reference does not ship")
+    if "reproject" in st["losses"]:
+        raise NotImplementedError("the part-stage reprojection loss is disabled in every shipped config")
+    if iter_fn is not None or visualize_fn is not None:
+        raise NotImplementedError("iter_fn / visualize_fn are visualisation hooks, not built")
+    device = markers.device
+    num_frames = markers.shape[0]
+    labels_mode = torch.mode(marker_labels, axis=0)[0]  # [M]
+    chain = torch.unique(labels_mode).tolist()
+    print("Found sequence with length", str(len(chain)))
+    final_marker_labels = torch.zeros_like(marker_labels)
+    final_marker_weights = torch.zeros_like(marker_labels, dtype=torch.float)
+    o_betas = betas
+
+    indices = torch.cat([torch.where(labels_mode == j)[0] for j in chain], dim=0)
+    markers_subset = markers[:, indices].contiguous()
+    if st.get("use_full_skeleton"):
+        subtrees = [np.arange(0, hierarchy.shape[0]).tolist()]
+    else:
+        subtrees = get_sub_hierachies(hierarchy, len(chain))
+        if "similarity_threshold" in st:
+            subtrees = remove_approximately_redundant_hierarchies(subtrees, similarity_threshold=0.9)
+
+    vertex_labels = torch.argmax(smpl_inference.get_lbs_weights(), dim=-1)
+    trans0 = torch.median(markers, dim=1)[0]
+    best = None
+    best_distance = np.inf
+    subtree_losses = []
+    LAST_STATS["part"] = []
+    for subtree in subtrees:
+        vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+        prob = PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vertex_indices, config)
+        x = prob.pack(torch.zeros((1, 1, 1), device=device), trans0, o_betas)
+        stats = prob.solve(x, max_iter=st["num_iters"], lr=1.0,
+                           tolerance_grad=config["optimizer"]["tolerance_grad"],
+                           tolerance_change=config["optimizer"]["tolerance_change"])
+        LAST_STATS["part"].append(stats)
+        z_angle, trans, betas_s = prob.unpack(x)
+        with torch.no_grad():
+            z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
+            verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
+                                   root_orient=z_root, trans=trans)["vertices"]
+            verts_sub = verts[:, vertex_indices].contiguous()
+            distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
+        subtree_losses.append([subtree, distance])
+        if distance < best_distance:
+            best_distance = distance
+            best = {
+                "betas": betas_s.clone(), "markers_subset": markers_subset.clone(), "root_orient": z_root.clone(),
+                "trans": trans.clone(),
+                "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
+            }
+            # label of marker i = dominant joint of argmin_v mean_f |v - x_i| over ALL vertices (:592-597)
+            valid = torch.ones(num_frames, dtype=torch.bool, device=device)
+            near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
+            final_marker_labels[:, indices] = vertex_labels[near][None, :].to(final_marker_labels.dtype)
+
+    if len(subtree_losses) > 1:
+        subtree_losses = sorted(subtree_losses, key=lambda e: e[1])
+        final_marker_weights[:, indices] = subtree_losses[1][1] / subtree_losses[0][1]
+        if indices.shape[0] == 1:
+            final_marker_weights *= 0
+    for k in range(min(len(subtree_losses), 3)):
+        print(", ".join(get_joint_name(j) for j in subtree_losses[k][0]), "{:.6f}".format(subtree_losses[k][1]))
+    print("--------------------")
+    final_marker_weights = final_marker_weights / torch.max(final_marker_weights)
+
+    return {
+        "betas": best["betas"].clone(),
+        "marker_labels": final_marker_labels.clone(),
+        "markers_subset": best["markers_subset"].clone(),
+        "marker_weights": final_marker_weights.clone(),
+        "root_orient": best["root_orient"].clone(),
+        "trans": best["trans"].clone(),
+        "aabb_volume_ratio": best["aabb"].clone(),
+        "chain": np.array(list(subtree_losses[0][0]), dtype=np.int32),
+    }

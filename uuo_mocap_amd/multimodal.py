@@ -1,0 +1,270 @@
+"""``multimodal_video_mocap`` with the reference's signature, stage order and output dictionary
+(reference src/video_mocap/multimodal.py:38-726): HMR prior + unlabeled markers -> SMPL parameters.
+
+Stages (reference :217-677): rigid marker clustering -> part fit (yaw/translation/shape per candidate body
+part) -> for each of `num_root_orient_angles` yaw hypotheses { chamfer L-BFGS -> marker placement -> marker
+L-BFGS } -> best hypothesis by chamfer distance -> final placement + marker L-BFGS.  The reprojection and
+root stages are disabled in every shipped config and are not built."""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import markers_utils, optimization
+from .markers_utils import find_best_part_fits, get_aabb, get_aabb_volume, segment_rigid
+from .optimization import (compute_marker_labels_from_coords, compute_nearest_points, get_marker_mask,
+                           optim_chamfer, optim_markers, weighted_chamfer_distance)
+from .smpl import SmplInference
+from .transforms import compute_root_orient_z, normalize_rot
+
+#: per-stage solver statistics of the most recent call (n_iter / n_eval / device ms per solve)
+LAST_RUN_STATS: Dict = {}
+
+
+def pad(sequence, offset):
+    """Repeats the first (offset > 0) or last (offset < 0) frame |offset| times (reference multimodal.py:713-726)."""
+    if offset == 0:
+        return sequence
+    edge = sequence[[0]] if offset > 0 else sequence[[-1]]
+    padding = torch.repeat_interleave(edge, repeats=abs(offset), dim=0)
+    return torch.cat((sequence, padding), dim=0) if offset < 0 else torch.cat((padding, sequence), dim=0)
+
+
+def _np(t):
+    return t.clone().detach().cpu().numpy()
+
+
+def multimodal_video_mocap(
+    img_smpl,
+    mocap_markers,
+    device: torch.device,
+    config: Dict,
+    offset: int = None,
+    print_options=[],
+    save_stages: bool = False,
+    save_iterations: bool = False,
+    visualize_fits: bool = False,
+    smpl_inference: SmplInference = None,
+) -> Dict:
+    """See the reference docstring (multimodal.py:49-84) for the meaning of the inputs and output keys.
+    `smpl_inference` (extension) lets callers reuse one model/workspace across sequences."""
+    if save_iterations or visualize_fits:
+        raise NotImplementedError("save_iterations / visualize_fits are visualisation features, not built")
+    for key in ("reprojection_part", "reprojection_full", "root"):
+        if config["stages"][key]["num_iters"] > 0:
+            raise NotImplementedError("stage '%s' is disabled in every shipped config and is not built" % key)
+    if mocap_markers.get_frequency() != img_smpl.freq:
+        raise NotImplementedError("mocap/video frame-rate resampling (reference multimodal.py:145-182) is not built: "
+                                  "resample the HMR track to the mocap rate first")
+    device = torch.device(device)
+    if smpl_inference is None:
+        smpl_inference = SmplInference(device)
+    stats: Dict = {"part": [], "chamfer": [], "marker": [], "marker_final": []}
+    verbose = "loss" in print_options
+
+    o_trans = img_smpl.trans.clone().detach().to(device)
+    o_root_orient = img_smpl.root_orient.clone().detach().to(device)
+    o_pose_body = img_smpl.pose_body.clone().detach().to(device)
+    o_betas = torch.sum(img_smpl.betas, dim=0, keepdim=True).clone().detach().to(device)
+    o_betas = o_betas / torch.sum(img_smpl.img_mask)
+    img_mask = img_smpl.img_mask.to(device)
+
+    trans = o_trans.clone().detach().requires_grad_(True)
+    root_orient = o_root_orient.clone().detach().requires_grad_(True)
+    markers = torch.from_numpy(mocap_markers.get_points()).float().to(device)
+    markers = torch.nan_to_num(markers, nan=0)
+
+    min_frames = min(markers.shape[0], trans.shape[0])
+    markers = markers[:min_frames]
+    o_trans, o_root_orient, o_pose_body = o_trans[:min_frames], o_root_orient[:min_frames], o_pose_body[:min_frames]
+    trans, root_orient = trans[:min_frames], root_orient[:min_frames]
+
+    if "progress" in print_options:
+        print("Stage: computing temporal alignment...")
+    if offset is None:
+        offset = 0
+    o_pose_body = pad(o_pose_body, offset).detach()
+    o_betas = o_betas.detach()
+    o_root_orient = pad(o_root_orient, offset).detach()
+    o_trans = pad(o_trans, offset).detach()
+    markers = pad(markers, -offset).detach().contiguous()
+    num_frames = trans.shape[0]
+
+    # ---- marker segmentation
+    print("Stage: computing marker segmentation...")
+    with torch.no_grad():
+        if config["stages"]["part"]["mode"] != "cluster":
+            raise NotImplementedError("stages.part.mode 'network' is not built")
+        segmented_markers = torch.zeros((markers.shape[:2]))
+        for group_index, group in enumerate(segment_rigid(markers.detach().cpu().numpy())):
+            segmented_markers[:, group] = group_index
+        segmented_markers = segmented_markers.long().to(device)
+        mean_out = smpl_inference(poses=o_pose_body, betas=o_betas * 0, root_orient=o_root_orient, trans=o_trans * 0)
+        aabb_volume_ratio = torch.median(get_aabb_volume(get_aabb(markers)) /
+                                         get_aabb_volume(get_aabb(mean_out["vertices"])))
+
+    filter_output = None
+    smpl_part = None
+    if config["find_best_part_fits"]:
+        filter_output = find_best_part_fits(
+            markers=markers, pose_body=o_pose_body, betas=o_betas, root_orient=o_root_orient,
+            marker_labels=segmented_markers, smpl_inference=smpl_inference, hierarchy=smpl_inference.smpl.parents,
+            joints_2d_gt=None, focal_length=None, reproject_mask=None, cam_trans=None, camera_center=None,
+            config=config, foot_contacts=None)
+        stats["part"] = list(markers_utils.LAST_STATS.get("part", []))
+        segmented_markers = filter_output["marker_labels"].detach().clone()
+        root_orient = filter_output["root_orient"].detach().clone()
+        trans = filter_output["trans"].detach().clone()
+        betas = filter_output["betas"].detach().clone()
+        smpl_part = {"trans": _np(trans), "root_orient": _np(normalize_rot(root_orient)), "betas": _np(betas[0]),
+                     "pose_body": _np(normalize_rot(o_pose_body))}
+    marker_labels = segmented_markers.detach().cpu().numpy()
+
+    if not config["find_best_part_fits"] or aabb_volume_ratio > 0.4:
+        trans = torch.median(markers, dim=1)[0].requires_grad_(True)
+        root_orient = o_root_orient.clone().requires_grad_(True)
+        betas = o_betas.clone().requires_grad_(True)
+
+    if "progress" in print_options:
+        print("Stage [root]: optimizing root...")
+    pose_body = o_pose_body.clone().requires_grad_(True)
+    root_orient = root_orient.detach()
+
+    smpl_chamfer_rotations, smpl_marker_rotations = {}, {}
+    run_chamfer = config["stages"]["chamfer"]["num_iters"] > 0
+    run_marker = config["stages"]["marker"]["num_iters"] > 0
+    root_orient_angles = torch.arange(0, 2 * np.pi, (2 * np.pi) / config["num_root_orient_angles"]).tolist()
+    for root_orient_angle in root_orient_angles:
+        angle_t = torch.tensor([[[root_orient_angle]]]).float().to(device)
+        z_root = compute_root_orient_z(torch.repeat_interleave(angle_t, repeats=root_orient.shape[0], dim=0)) @ \
+            root_orient.clone().detach()
+        z_root = z_root.clone().detach().requires_grad_(True)
+        trans_angle = trans.clone().detach().requires_grad_(True)
+        pose_angle = pose_body.clone().detach().requires_grad_(True)
+        betas_angle = betas.clone().detach().requires_grad_(True)
+
+        if "progress" in print_options:
+            print("Stage [pose]: optimizing poses and shapes...")
+        if run_chamfer:
+            optim_chamfer(markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle, o_betas=o_betas,
+                          root_orient=z_root, trans=trans_angle, marker_labels=None, img_mask=img_mask,
+                          smpl_inference=smpl_inference, initial_angle=root_orient_angle, repeat=0, config=config,
+                          verbose=verbose)
+            stats["chamfer"].append(optimization.LAST_STATS["chamfer"])
+        smpl_chamfer_rotations[root_orient_angle] = {
+            "trans": _np(trans_angle), "root_orient": _np(normalize_rot(z_root)), "betas": _np(betas_angle[0]),
+            "pose_body": _np(normalize_rot(pose_angle))}
+
+        if "progress" in print_options:
+            print("Stage: computing marker placement... [{}/{}]".format(1, config["stage_repeats"]))
+        if run_marker:
+            one_hot = compute_nearest_points(
+                markers=markers, pose_body=pose_angle, betas=betas_angle, root_orient=z_root, trans=trans_angle,
+                smpl_inference=smpl_inference, marker_labels=marker_labels,
+                granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
+                config=config, o_pose_body=o_pose_body, window_size=1,
+                use_velocity=config["stages"]["compute_locations"]["use_velocity"])
+            if config["recompute_marker_labels"]:
+                marker_labels = compute_marker_labels_from_coords(smpl_inference, one_hot, num_frames).cpu().numpy()
+                if config["stages"]["segment"]["rigid_filter"]:
+                    raise NotImplementedError("segment.rigid_filter is off in every shipped config")
+            if "progress" in print_options:
+                print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(1, config["stage_repeats"]))
+            z_root = z_root.clone().detach().requires_grad_(True)
+            pose_angle = pose_angle.clone().detach().requires_grad_(True)
+            optim_markers(markers=markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
+                          o_betas=o_betas, root_orient=z_root, trans=trans_angle,
+                          barycentric_coords_one_hot=one_hot, img_mask=img_mask, smpl_inference=smpl_inference,
+                          config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose)
+            stats["marker"].append(optimization.LAST_STATS["marker"])
+        z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
+        pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
+        smpl_marker_rotations[root_orient_angle] = {
+            "trans": _np(trans_angle), "root_orient": _np(z_root), "betas": _np(betas_angle[0]),
+            "pose_body": _np(pose_angle)}
+
+    # ---- best yaw hypothesis by masked chamfer distance (first minimum wins)
+    best_angle_chamfer, best_angle = np.inf, None
+    yaw_scores = []
+    for root_orient_angle in root_orient_angles:
+        r = smpl_marker_rotations[root_orient_angle]
+        angle_betas = torch.repeat_interleave(torch.from_numpy(r["betas"]).to(device)[None], dim=0,
+                                              repeats=r["pose_body"].shape[0])
+        with torch.no_grad():
+            vertices = smpl_inference(
+                poses=torch.from_numpy(r["pose_body"]).to(device), betas=angle_betas,
+                root_orient=torch.from_numpy(r["root_orient"]).to(device),
+                trans=torch.from_numpy(r["trans"]).to(device))["vertices"]
+            score = weighted_chamfer_distance(x=markers, y=vertices, x_weights=get_marker_mask(markers),
+                                              single_directional=True)[0]
+        yaw_scores.append(float(score))
+        if score < best_angle_chamfer:
+            best_angle_chamfer, best_angle = score, root_orient_angle
+    stats["yaw_scores"] = yaw_scores
+    stats["best_angle"] = best_angle
+
+    smpl_chamfer = smpl_chamfer_rotations[best_angle]
+    smpl_marker = smpl_marker_rotations[best_angle]
+    root_orient = torch.from_numpy(smpl_marker["root_orient"]).to(device).requires_grad_(True)
+    trans = torch.from_numpy(smpl_marker["trans"]).to(device).requires_grad_(True)
+    pose_body = torch.from_numpy(smpl_marker["pose_body"]).to(device).requires_grad_(True)
+    betas = torch.from_numpy(smpl_marker["betas"][None]).to(device).requires_grad_(True)
+
+    print("Final marker optimization")
+    smpl_marker_final = None
+    for stage_i in range(config["stage_repeats"]):
+        pose_body_stage = torch.clone(pose_body).detach().requires_grad_(False)
+        if "progress" in print_options:
+            print("Stage: computing marker placement... [{}/{}]".format(stage_i + 1, config["stage_repeats"]))
+        if run_marker:
+            one_hot = compute_nearest_points(
+                markers=markers, pose_body=pose_body, betas=betas, root_orient=root_orient, trans=trans,
+                smpl_inference=smpl_inference, marker_labels=marker_labels,
+                granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
+                config=config, o_pose_body=pose_body_stage, window_size=1,
+                use_velocity=config["stages"]["compute_locations"]["use_velocity"])
+            if config["recompute_marker_labels"]:
+                marker_labels = compute_marker_labels_from_coords(smpl_inference, one_hot, num_frames).cpu().numpy()
+            if "progress" in print_options:
+                print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(stage_i + 1,
+                                                                                      config["stage_repeats"]))
+            root_orient = root_orient.clone().detach().requires_grad_(True)
+            pose_body = pose_body.clone().detach().requires_grad_(True)
+            optim_markers(markers=markers, pose_body=pose_body, o_pose_body=pose_body_stage, betas=betas,
+                          o_betas=o_betas, root_orient=root_orient, trans=trans, barycentric_coords_one_hot=one_hot,
+                          img_mask=img_mask, smpl_inference=smpl_inference, config=config, initial_angle=0, repeat=1,
+                          verbose=verbose)
+            stats["marker_final"].append(optimization.LAST_STATS["marker"])
+        root_orient = normalize_rot(root_orient).clone().detach().requires_grad_(True)
+        pose_body = normalize_rot(pose_body).clone().detach().requires_grad_(True)
+        smpl_marker_final = {"trans": _np(trans), "root_orient": _np(root_orient), "betas": _np(betas[0]),
+                             "pose_body": _np(pose_body)}
+
+    output = {
+        "trans": trans.detach().cpu(),
+        "root_orient": normalize_rot(root_orient).detach().cpu(),
+        "pose_body": normalize_rot(pose_body).detach().cpu(),
+        "betas": torch.repeat_interleave(torch.mean(betas, dim=0, keepdim=True), dim=0,
+                                         repeats=pose_body.shape[0]).detach().cpu(),
+        "mocap_frame_rate": mocap_markers.get_frequency(),
+    }
+    mocap_markers.set_points(markers.detach().cpu().numpy())
+    output["mocap_markers"] = mocap_markers
+    output["markers_labels"] = marker_labels
+    if save_stages:
+        output["stages"] = {}
+        if config["find_best_part_fits"]:
+            output["stages"]["part"] = smpl_part
+        if run_chamfer:
+            output["stages"]["chamfer"] = smpl_chamfer
+        if run_marker:
+            output["stages"]["marker"] = smpl_marker
+        if config["stage_repeats"] > 0:
+            output["stages"]["marker_final"] = smpl_marker_final
+    if filter_output is not None:
+        output["chain"] = filter_output["chain"]
+    LAST_RUN_STATS.clear()
+    LAST_RUN_STATS.update(stats)
+    return output
