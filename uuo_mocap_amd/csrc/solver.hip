@@ -14,7 +14,7 @@
 
 #include "frame_math.h"
 
-#define LB_MAXH 128                 // history capacity (slots); history_size <= LB_MAXH - 1
+#define LB_MAXH 104                 // history capacity (slots); history_size <= LB_MAXH - 4
 #define LB_ROWS (2 * LB_MAXH + 1)   // S slots, Y slots, g
 #define LB_CHUNK 2048               // elements per dot block
 #define LB_NVEC 10
@@ -104,22 +104,29 @@ __global__ __launch_bounds__(256) void k_lb_stats(int n, const float* __restrict
 
 __global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* __restrict__ part,
                                                         const float* __restrict__ loss, LbDev* __restrict__ st) {
-  if (threadIdx.x != 0) return;
+  const int lane = threadIdx.x;  // nblk <= 64: one partial block per lane, fixed butterfly order
   double dot = 0.0, l1 = 0.0, gg = 0.0, mx = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    dot += part[b * 4];
-    l1 += part[b * 4 + 1];
-    gg += part[b * 4 + 2];
-    mx = fmax(mx, part[b * 4 + 3]);
+  if (lane < nblk) {
+    dot = part[lane * 4];
+    l1 = part[lane * 4 + 1];
+    gg = part[lane * 4 + 2];
+    mx = part[lane * 4 + 3];
   }
-  LbOut* o = reinterpret_cast<LbOut*>(st->out);
-  o->loss = (double)loss[0];
-  o->gtd_new = dot;
-  o->gmax = mx;
-  o->g1 = l1;
-  o->gg = gg;
-  o->dmax = (double)__uint_as_float(st->dmax_bits);
-  st->gg = gg;
+  dot = wave_sum_d(dot);
+  l1 = wave_sum_d(l1);
+  gg = wave_sum_d(gg);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) {
+    LbOut* o = reinterpret_cast<LbOut*>(st->out);
+    o->loss = (double)loss[0];
+    o->gtd_new = dot;
+    o->gmax = mx;
+    o->g1 = l1;
+    o->gg = gg;
+    o->dmax = (double)__uint_as_float(st->dmax_bits);
+    st->gg = gg;
+  }
 }
 
 // rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
@@ -173,92 +180,127 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
   }
 }
 
-// one wave: reduce the dot partials, update the Gram matrices and the ring, run the two-loop recursion in
-// coefficient space (torch/optim/lbfgs.py:396-441), write the coefficients of d = cg g + sum cy_j y_j + cs_j s_j.
-__global__ __launch_bounds__(64) void k_lb_small(int nchunks, int cap, int hist, int cand,
-                                                  const double* __restrict__ part, LbDev* __restrict__ st) {
-  __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH];
+// One block: reduce the dot partials, update the Gram matrices and the ring, then run the two-loop recursion of
+// torch/optim/lbfgs.py:396-441 in coefficient space and write the coefficients of
+//   d = cg g + sum_j cy_j y_j + cs_j s_j .
+// Both loops are triangular recurrences over U = upper triangle of S.Y^T (logical order, oldest first):
+//   loop 1 (i = k-1..0):  al_i = (-s_i.g - sum_{j>i} al_j U_ij) / U_ii
+//   loop 2 (i = 0..k-1):  cs_i = al_i - (cg y_i.g + (YY cy)_i + sum_{j<i} cs_j U_ji) / U_ii ,  cy = -Hdiag al
+// U (<= 43 KB of fp64) is staged in LDS so each of the 2k dependent steps costs an LDS read + a wave reduction
+// instead of an L2 round trip; YY cy has no dependency chain and is a parallel mat-vec over all 256 threads.
+#define LB_TRI (LB_MAXH * (LB_MAXH + 1) / 2)
+__device__ __forceinline__ int tri_index(int i, int j, int k) {  // j >= i, row-major packed upper triangle of k x k
+  return i * k - (i * (i - 1)) / 2 + (j - i);
+}
+
+__global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist, int cand,
+                                                   const double* __restrict__ part, LbDev* __restrict__ st) {
+  __shared__ double U[LB_TRI];
+  __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH];
   __shared__ double rd[LB_ROWS * 3];
-  const int lane = threadIdx.x;
+  __shared__ int slot_of[LB_MAXH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int head = st->head, count = st->count;
   const int nact = count + 1;
-  // rows needed: active S slots, active Y slots, g
-  for (int e = lane; e < LB_ROWS * 3; e += 64) {
+  // ---- reduce the partial dots of the active rows (fixed chunk order -> deterministic)
+  for (int e = tid; e < LB_ROWS * 3; e += 256) {
+    const int row = e / 3;
+    const int slot = (row < LB_MAXH) ? row : row - LB_MAXH;
+    bool active = (row == 2 * LB_MAXH);
+    if (!active && slot < cap) {
+      const int rel = (slot - head + cap) % cap;
+      active = (rel < count) || (slot == cand);
+    }
     double acc = 0.0;
-    for (int c = 0; c < nchunks; ++c) acc += part[(size_t)c * LB_ROWS * 3 + e];
+    if (active)
+      for (int c = 0; c < nchunks; ++c) acc += part[(size_t)c * LB_ROWS * 3 + e];
     rd[e] = acc;
   }
   __syncthreads();
-  // candidate row/column of the Gram matrices
-  const double ys = rd[(cand)*3 + 0];              // s_new . y_new
+  // ---- candidate row / column of the Gram matrices
+  const double ys = rd[cand * 3 + 0];              // s_new . y_new
   const double yy = rd[(LB_MAXH + cand) * 3 + 0];  // y_new . y_new
-  for (int r = lane; r < nact; r += 64) {
+  for (int r = tid; r < nact; r += 256) {
     const int slot = (r < count) ? (head + r) % cap : cand;
     st->SY[slot * LB_MAXH + cand] = rd[slot * 3 + 0];              // s_slot . y_new
-    st->SY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 1];  // y_slot . s_new = s_new . y_slot
-    st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];  // y_slot . y_new
+    st->SY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 1];  // s_new . y_slot
+    st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];
     st->YY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 0];
     Sg[slot] = rd[slot * 3 + 2];
     Yg[slot] = rd[(LB_MAXH + slot) * 3 + 2];
   }
+  __threadfence_block();
   __syncthreads();
   const bool accept = ys > 1e-10;
   double Hdiag = st->Hdiag;
   if (accept) {
-    if (count == hist) {
+    if (count == hist)
       head = (head + 1) % cap;  // drop the oldest; the candidate slot becomes the newest
-    } else {
+    else
       count += 1;
-    }
     Hdiag = ys / yy;
   }
   const int k = count;
-  // loop 1 (newest -> oldest)
-  for (int i = k - 1; i >= 0; --i) {
-    const int si = (head + i) % cap;
-    double partial = 0.0;
-    for (int j = i + 1 + lane; j < k; j += 64) {
-      const int sj = (head + j) % cap;
-      partial += al[sj] * st->SY[si * LB_MAXH + sj];
-    }
-    partial = wave_sum_d(partial);
-    if (lane == 0) al[si] = (-Sg[si] - partial) / st->SY[si * LB_MAXH + si];
-    __syncthreads();
-  }
-  const double cg = -Hdiag;
-  for (int j = lane; j < k; j += 64) {
-    const int sj = (head + j) % cap;
-    cy_s[sj] = -Hdiag * al[sj];
-    cs_s[sj] = 0.0;
+  for (int j = tid; j < k; j += 256) slot_of[j] = (head + j) % cap;
+  __syncthreads();
+  // ---- stage U in LDS (logical order)
+  for (int i = wave; i < k; i += 4) {
+    const int si = slot_of[i];
+    for (int j = i + lane; j < k; j += 64) U[tri_index(i, j, k)] = st->SY[si * LB_MAXH + slot_of[j]];
   }
   __syncthreads();
-  // loop 2 (oldest -> newest)
-  for (int i = 0; i < k; ++i) {
-    const int si = (head + i) % cap;
-    double partial = 0.0;
-    for (int j = lane; j < k; j += 64) {
-      const int sj = (head + j) % cap;
-      partial += cy_s[sj] * st->YY[si * LB_MAXH + sj];
-      if (j < i) partial += cs_s[sj] * st->SY[sj * LB_MAXH + si];
+  // ---- loop 1 (newest -> oldest), wave 0
+  if (wave == 0) {
+    for (int i = k - 1; i >= 0; --i) {
+      double partial = 0.0;
+      for (int j = i + 1 + lane; j < k; j += 64) partial += al[j] * U[tri_index(i, j, k)];
+      partial = wave_sum_d(partial);
+      if (lane == 0) al[i] = (-Sg[slot_of[i]] - partial) / U[tri_index(i, i, k)];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS write of al[i] is visible to the wave's next reads
     }
-    partial = wave_sum_d(partial);
-    if (lane == 0) {
-      const double yr = cg * Yg[si] + partial;
-      const double be = yr / st->SY[si * LB_MAXH + si];
-      cs_s[si] = al[si] - be;
-    }
-    __syncthreads();
   }
-  // g . d from the Gram data
+  __syncthreads();
+  const double cg = -Hdiag;
+  for (int j = tid; j < k; j += 256) cy_s[j] = -Hdiag * al[j];
+  __syncthreads();
+  // ---- w = YY cy (no dependency chain): one row per wave pass
+  for (int i = wave; i < k; i += 4) {
+    const int si = slot_of[i];
+    double partial = 0.0;
+    for (int j = lane; j < k; j += 64) partial += cy_s[j] * st->YY[si * LB_MAXH + slot_of[j]];
+    partial = wave_sum_d(partial);
+    if (lane == 0) wv[i] = partial;
+  }
+  __syncthreads();
+  // ---- loop 2 (oldest -> newest), wave 0
+  if (wave == 0) {
+    for (int i = 0; i < k; ++i) {
+      double partial = 0.0;
+      for (int j = lane; j < i; j += 64) partial += cs_s[j] * U[tri_index(j, i, k)];
+      partial = wave_sum_d(partial);
+      if (lane == 0) {
+        const double yr = cg * Yg[slot_of[i]] + wv[i] + partial;
+        cs_s[i] = al[i] - yr / U[tri_index(i, i, k)];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+  }
+  __syncthreads();
+  // ---- publish: coefficients by slot, g.d from the Gram data
   double gpart = 0.0;
-  for (int j = lane; j < k; j += 64) {
-    const int sj = (head + j) % cap;
-    gpart += cy_s[sj] * Yg[sj] + cs_s[sj] * Sg[sj];
-    st->cy[sj] = cy_s[sj];
-    st->cs[sj] = cs_s[sj];
+  for (int j = tid; j < k; j += 256) {
+    const int sj = slot_of[j];
+    gpart += cy_s[j] * Yg[sj] + cs_s[j] * Sg[sj];
+    st->cy[sj] = cy_s[j];
+    st->cs[sj] = cs_s[j];
   }
   gpart = wave_sum_d(gpart);
-  if (lane == 0) {
+  if (lane == 0) wv[LB_MAXH - 4 + wave] = gpart;  // k <= hist <= LB_MAXH - 4 leaves these free
+  __syncthreads();
+  if (tid == 0) {
+    const double gsum = (wv[LB_MAXH - 4] + wv[LB_MAXH - 3]) + (wv[LB_MAXH - 2] + wv[LB_MAXH - 1]);
     const double gg = rd[(2 * LB_MAXH) * 3 + 2];
     st->cg = cg;
     st->Hdiag = Hdiag;
@@ -266,7 +308,7 @@ __global__ __launch_bounds__(64) void k_lb_small(int nchunks, int cap, int hist,
     st->count = count;
     st->dmax_bits = 0u;
     LbOut* o = reinterpret_cast<LbOut*>(st->out);
-    o->gtd_dir = cg * gg + gpart;
+    o->gtd_dir = cg * gg + gsum;
     o->accepted = accept ? 1.0 : 0.0;
     o->ys = ys;
   }
@@ -388,7 +430,7 @@ static int lbws_destroy(LbWs* w) {
 }
 
 static int lbws_create(int n, int hist, LbWs** out) {
-  UUO_REQUIRE(hist >= 1 && hist < LB_MAXH, "lbfgs: history_size must be in [1,127]");
+  UUO_REQUIRE(hist >= 1 && hist <= LB_MAXH - 4, "lbfgs: history_size must be in [1,100]");
   LbWs* w = new LbWs();
   w->n_cap = n;
   w->cap = hist + 1;
@@ -537,7 +579,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         const int nrows = 2 * (count + 1) + 1;
         hipLaunchKernelGGL(k_lb_dots, dim3(w->nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand,
                            w->S, w->Y, g, stride, w->part);
-        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(64), 0, s, w->nchunks, cap, hist, cand, w->part, w->st);
+        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, w->nchunks, cap, hist, cand, w->part, w->st);
         hipLaunchKernelGGL(k_lb_direction, dim3(nb), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st, d);
       }
       UUO_HIP_CHECK(hipGetLastError());
