@@ -135,9 +135,14 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
 
 extern "C" int uuo_model_destroy(uuo_model_t* m) {
   if (!m) return 0;
-  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->W, m->Wi, m->Ww, m->tree, m->fwd_pfaT, m->fwd_A, m->fwd_jp};
+  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->W, m->Wi, m->Ww, m->tree};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& kv : m->fwd) {
+    if (kv.second.pfaT) (void)hipFree(kv.second.pfaT);
+    if (kv.second.A) (void)hipFree(kv.second.A);
+    if (kv.second.jp) (void)hipFree(kv.second.jp);
+  }
   delete m;
   return 0;
 }

@@ -237,18 +237,23 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   UUO_REQUIRE(d_verts != nullptr, "uuo_smpl_forward: d_verts is required (joints 24..44 are picked from it)");
   hipStream_t s = (hipStream_t)stream;
   const int nFT = (F + 31) / 32;
-  if (m->fwd_cap < nFT) {
-    if (m->fwd_pfaT) (void)hipFree(m->fwd_pfaT);
-    if (m->fwd_A) (void)hipFree(m->fwd_A);
-    if (m->fwd_jp) (void)hipFree(m->fwd_jp);
-    m->fwd_pfaT = m->fwd_A = m->fwd_jp = nullptr;
-    m->fwd_cap = 0;
-    UUO_HIP_CHECK(hipMalloc((void**)&m->fwd_pfaT, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
-    UUO_HIP_CHECK(hipMalloc((void**)&m->fwd_A, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
-    UUO_HIP_CHECK(hipMalloc((void**)&m->fwd_jp, (size_t)nFT * 32 * UUO_NUM_JOINTS * 3 * sizeof(float)));
-    UUO_HIP_CHECK(hipMemset(m->fwd_pfaT, 0, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
-    UUO_HIP_CHECK(hipMemset(m->fwd_A, 0, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
-    m->fwd_cap = nFT;
+  uuo_model::FwdScratch sc;
+  {
+    std::lock_guard<std::mutex> lock(m->fwd_mutex);
+    uuo_model::FwdScratch& ref = m->fwd[s];
+    if (ref.cap < nFT) {
+      if (ref.pfaT) (void)hipFree(ref.pfaT);
+      if (ref.A) (void)hipFree(ref.A);
+      if (ref.jp) (void)hipFree(ref.jp);
+      ref = uuo_model::FwdScratch();
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.pfaT, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.A, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.jp, (size_t)nFT * 32 * UUO_NUM_JOINTS * 3 * sizeof(float)));
+      UUO_HIP_CHECK(hipMemset(ref.pfaT, 0, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
+      UUO_HIP_CHECK(hipMemset(ref.A, 0, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      ref.cap = nFT;
+    }
+    sc = ref;
   }
   UuoPoseSrc src;
   src.body = d_poses;
@@ -259,10 +264,10 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   src.betas = d_betas;
   src.betas_stride = (betas_rows == 1) ? 0 : 10;
   src.trans = d_trans;
-  int rc = uuo_launch_pose_prep(m, s, F, src, m->fwd_pfaT, m->fwd_A, m->fwd_jp);
+  int rc = uuo_launch_pose_prep(m, s, F, src, sc.pfaT, sc.A, sc.jp);
   if (rc) return rc;
-  rc = uuo_launch_skin(m, s, F, m->fwd_pfaT, m->fwd_A, d_trans, d_verts);
+  rc = uuo_launch_skin(m, s, F, sc.pfaT, sc.A, d_trans, d_verts);
   if (rc) return rc;
-  if (d_joints) rc = uuo_launch_joints45(m, s, F, m->fwd_jp, d_verts, d_joints);
+  if (d_joints) rc = uuo_launch_joints45(m, s, F, sc.jp, d_verts, d_joints);
   return rc;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include <string>
 
 #include "../../include/uuo_hip.h"
@@ -58,11 +60,15 @@ struct uuo_model {
   float* Ww = nullptr;    // [VP][4]
   UuoTree* tree = nullptr;  // device copy
   UuoTree h_tree;
-  // scratch for uuo_smpl_forward (grown on demand)
-  int fwd_cap = 0;
-  float* fwd_pfaT = nullptr;
-  float* fwd_A = nullptr;
-  float* fwd_jp = nullptr;
+  // scratch of uuo_smpl_forward, one set per stream so concurrent callers (one host thread per stream) never share
+  struct FwdScratch {
+    int cap = 0;
+    float* pfaT = nullptr;
+    float* A = nullptr;
+    float* jp = nullptr;
+  };
+  std::map<hipStream_t, FwdScratch> fwd;
+  std::mutex fwd_mutex;
 };
 
 // How the frame kernels obtain the 24 rotations and the shape for frame f.

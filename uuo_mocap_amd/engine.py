@@ -6,6 +6,7 @@ is a kernel behind the C ABI (include/uuo_hip.h).
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import byref, c_float, c_void_p
 from typing import Callable, Dict, Optional
 
@@ -21,6 +22,20 @@ MARKER_DISTANCE = 0.0095  # reference utils/settings.py:1
 
 STOP_REASONS = ["max_iter", "max_eval", "tolerance_grad", "tolerance_change(step)", "tolerance_change(loss)",
                 "directional_derivative", "initial_tolerance_grad"]
+
+
+_tls = threading.local()
+
+
+def set_workspace_slot(slot: int):
+    """Selects which per-(F, M) workspace the calling thread uses.  Independent solves that run concurrently
+    (one host thread + one HIP stream each, e.g. the yaw hypotheses of multimodal_video_mocap) must use
+    different slots; a workspace is never shared by two solves in flight."""
+    _tls.slot = int(slot)
+
+
+def workspace_slot() -> int:
+    return getattr(_tls, "slot", 0)
 
 
 def _require_cuda(t: torch.Tensor, name: str):
@@ -60,15 +75,17 @@ class DeviceModel:
             check(self.lib.uuo_model_create(*[a.ctypes.data for a in arrs], self.V, byref(handle)), "uuo_model_create")
         self.handle = handle
         self._fits: Dict = {}
+        self._fits_lock = threading.Lock()
 
     def fit(self, F: int, M: int) -> c_void_p:
-        key = (int(F), int(M))
-        if key not in self._fits:
-            h = c_void_p()
-            with torch.cuda.device(self.device):
-                check(self.lib.uuo_fit_create(self.handle, key[0], key[1], byref(h)), "uuo_fit_create")
-            self._fits[key] = h
-        return self._fits[key]
+        key = (int(F), int(M), workspace_slot())
+        with self._fits_lock:
+            if key not in self._fits:
+                h = c_void_p()
+                with torch.cuda.device(self.device):
+                    check(self.lib.uuo_fit_create(self.handle, key[0], key[1], byref(h)), "uuo_fit_create")
+                self._fits[key] = h
+            return self._fits[key]
 
     def close(self):
         for h in self._fits.values():

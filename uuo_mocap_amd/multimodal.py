@@ -7,12 +7,16 @@ L-BFGS } -> best hypothesis by chamfer distance -> final placement + marker L-BF
 root stages are disabled in every shipped config and are not built."""
 from __future__ import annotations
 
+import contextlib
+import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict
 
 import numpy as np
 import torch
 
 from . import markers_utils, optimization
+from .engine import set_workspace_slot
 from .markers_utils import find_best_part_fits, get_aabb, get_aabb_volume, segment_rigid
 from .optimization import (compute_marker_labels_from_coords, compute_nearest_points, get_marker_mask,
                            optim_chamfer, optim_markers, weighted_chamfer_distance)
@@ -136,54 +140,82 @@ def multimodal_video_mocap(
     run_chamfer = config["stages"]["chamfer"]["num_iters"] > 0
     run_marker = config["stages"]["marker"]["num_iters"] > 0
     root_orient_angles = torch.arange(0, 2 * np.pi, (2 * np.pi) / config["num_root_orient_angles"]).tolist()
-    for root_orient_angle in root_orient_angles:
-        angle_t = torch.tensor([[[root_orient_angle]]]).float().to(device)
-        z_root = compute_root_orient_z(torch.repeat_interleave(angle_t, repeats=root_orient.shape[0], dim=0)) @ \
-            root_orient.clone().detach()
-        z_root = z_root.clone().detach().requires_grad_(True)
-        trans_angle = trans.clone().detach().requires_grad_(True)
-        pose_angle = pose_body.clone().detach().requires_grad_(True)
-        betas_angle = betas.clone().detach().requires_grad_(True)
+    if config["recompute_marker_labels"] and run_marker:
+        raise NotImplementedError("recompute_marker_labels is False in every shipped config")
 
-        if "progress" in print_options:
-            print("Stage [pose]: optimizing poses and shapes...")
-        if run_chamfer:
-            optim_chamfer(markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle, o_betas=o_betas,
-                          root_orient=z_root, trans=trans_angle, marker_labels=None, img_mask=img_mask,
-                          smpl_inference=smpl_inference, initial_angle=root_orient_angle, repeat=0, config=config,
-                          verbose=verbose)
-            stats["chamfer"].append(optimization.LAST_STATS["chamfer"])
-        smpl_chamfer_rotations[root_orient_angle] = {
-            "trans": _np(trans_angle), "root_orient": _np(normalize_rot(z_root)), "betas": _np(betas_angle[0]),
-            "pose_body": _np(normalize_rot(pose_angle))}
-
-        if "progress" in print_options:
-            print("Stage: computing marker placement... [{}/{}]".format(1, config["stage_repeats"]))
-        if run_marker:
-            one_hot = compute_nearest_points(
-                markers=markers, pose_body=pose_angle, betas=betas_angle, root_orient=z_root, trans=trans_angle,
-                smpl_inference=smpl_inference, marker_labels=marker_labels,
-                granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
-                config=config, o_pose_body=o_pose_body, window_size=1,
-                use_velocity=config["stages"]["compute_locations"]["use_velocity"])
-            if config["recompute_marker_labels"]:
-                marker_labels = compute_marker_labels_from_coords(smpl_inference, one_hot, num_frames).cpu().numpy()
-                if config["stages"]["segment"]["rigid_filter"]:
-                    raise NotImplementedError("segment.rigid_filter is off in every shipped config")
-            if "progress" in print_options:
-                print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(1, config["stage_repeats"]))
+    def fit_hypothesis(index: int, root_orient_angle: float, stream):
+        """One yaw hypothesis (reference multimodal.py:463-574): chamfer L-BFGS -> placement -> marker L-BFGS.
+        Hypotheses are independent, so each runs on its own host thread, HIP stream and solver workspace."""
+        set_workspace_slot(index)
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        local = {}
+        with ctx:
+            angle_t = torch.tensor([[[root_orient_angle]]]).float().to(device)
+            z_root = compute_root_orient_z(torch.repeat_interleave(angle_t, repeats=root_orient.shape[0], dim=0)) @ \
+                root_orient.clone().detach()
             z_root = z_root.clone().detach().requires_grad_(True)
-            pose_angle = pose_angle.clone().detach().requires_grad_(True)
-            optim_markers(markers=markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
-                          o_betas=o_betas, root_orient=z_root, trans=trans_angle,
-                          barycentric_coords_one_hot=one_hot, img_mask=img_mask, smpl_inference=smpl_inference,
-                          config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose)
-            stats["marker"].append(optimization.LAST_STATS["marker"])
-        z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
-        pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
-        smpl_marker_rotations[root_orient_angle] = {
-            "trans": _np(trans_angle), "root_orient": _np(z_root), "betas": _np(betas_angle[0]),
-            "pose_body": _np(pose_angle)}
+            trans_angle = trans.clone().detach().requires_grad_(True)
+            pose_angle = pose_body.clone().detach().requires_grad_(True)
+            betas_angle = betas.clone().detach().requires_grad_(True)
+            if "progress" in print_options:
+                print("Stage [pose]: optimizing poses and shapes...")
+            if run_chamfer:
+                optim_chamfer(markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
+                              o_betas=o_betas, root_orient=z_root, trans=trans_angle, marker_labels=None,
+                              img_mask=img_mask, smpl_inference=smpl_inference, initial_angle=root_orient_angle,
+                              repeat=0, config=config, verbose=verbose)
+                local["chamfer_stats"] = optimization.last_stats("chamfer")
+            local["chamfer"] = {
+                "trans": _np(trans_angle), "root_orient": _np(normalize_rot(z_root)), "betas": _np(betas_angle[0]),
+                "pose_body": _np(normalize_rot(pose_angle))}
+            if "progress" in print_options:
+                print("Stage: computing marker placement... [{}/{}]".format(1, config["stage_repeats"]))
+            if run_marker:
+                one_hot = compute_nearest_points(
+                    markers=markers, pose_body=pose_angle, betas=betas_angle, root_orient=z_root, trans=trans_angle,
+                    smpl_inference=smpl_inference, marker_labels=marker_labels,
+                    granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
+                    config=config, o_pose_body=o_pose_body, window_size=1,
+                    use_velocity=config["stages"]["compute_locations"]["use_velocity"])
+                if "progress" in print_options:
+                    print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(1, config["stage_repeats"]))
+                z_root = z_root.clone().detach().requires_grad_(True)
+                pose_angle = pose_angle.clone().detach().requires_grad_(True)
+                optim_markers(markers=markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
+                              o_betas=o_betas, root_orient=z_root, trans=trans_angle,
+                              barycentric_coords_one_hot=one_hot, img_mask=img_mask, smpl_inference=smpl_inference,
+                              config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose)
+                local["marker_stats"] = optimization.last_stats("marker")
+            z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
+            pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
+            local["marker"] = {
+                "trans": _np(trans_angle), "root_orient": _np(z_root), "betas": _np(betas_angle[0]),
+                "pose_body": _np(pose_angle)}
+            if stream is not None:
+                stream.synchronize()
+        return local
+
+    n_threads = min(len(root_orient_angles), int(os.environ.get("UUO_HYPOTHESIS_THREADS", "4")))
+    if n_threads > 1 and device.type == "cuda":
+        main_stream = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device=device) for _ in root_orient_angles]
+        for st_ in streams:
+            st_.wait_stream(main_stream)
+        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            futures = [pool.submit(fit_hypothesis, i, a, streams[i]) for i, a in enumerate(root_orient_angles)]
+            results = [f.result() for f in futures]
+        for st_ in streams:
+            main_stream.wait_stream(st_)
+    else:
+        results = [fit_hypothesis(0, a, None) for a in root_orient_angles]
+    set_workspace_slot(0)
+    for root_orient_angle, local in zip(root_orient_angles, results):
+        smpl_chamfer_rotations[root_orient_angle] = local["chamfer"]
+        smpl_marker_rotations[root_orient_angle] = local["marker"]
+        if "chamfer_stats" in local:
+            stats["chamfer"].append(local["chamfer_stats"])
+        if "marker_stats" in local:
+            stats["marker"].append(local["marker_stats"])
 
     # ---- best yaw hypothesis by masked chamfer distance (first minimum wins)
     best_angle_chamfer, best_angle = np.inf, None

@@ -3,6 +3,7 @@
 device-resident L-BFGS of libuuo_hip.so instead of a Python closure driven by torch.optim.LBFGS."""
 from __future__ import annotations
 
+import threading
 from collections.abc import Callable
 from typing import Dict, Optional
 
@@ -17,6 +18,11 @@ from .transforms import compute_root_orient_y, compute_root_orient_z, normalize_
 
 #: per-solve statistics of the most recent calls (n_iter, n_eval, losses, device ms) -- bench.py and tests read it
 LAST_STATS: Dict[str, Dict] = {}
+_tls_stats = threading.local()  # same, per calling thread (concurrent yaw hypotheses)
+
+
+def last_stats(kind: str) -> Dict:
+    return getattr(_tls_stats, kind)
 
 
 def _printer(tag: str, verbose: bool):
@@ -74,6 +80,7 @@ def optim_chamfer(
         root_orient[:] = compute_root_orient_z(new_z) @ root_orient
     root_orient.requires_grad_(True)
     LAST_STATS["chamfer"] = stats
+    _tls_stats.chamfer = stats
     return None
 
 
@@ -116,6 +123,7 @@ def optim_markers(
         root_orient.copy_(new_root)
         trans.copy_(new_trans)
     LAST_STATS["marker"] = stats
+    _tls_stats.marker = stats
     return None
 
 
