@@ -323,12 +323,19 @@ def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
     trace = [float(line.split()[2]) for line in buf.getvalue().splitlines() if line.startswith("Chamfer")]
     st = LAST_STATS["chamfer"]
     assert st["n_iter"] <= int(g["num_iters"]) and st["n_eval"] == len(trace)
-    assert abs(st["n_eval"] - len(g["losses"])) <= 5
     # the same algorithm on the same numbers: the first dozen closure losses follow the reference's recorded
     # trajectory to fp32 round-off; later a single flipped assignment / line-search branch separates them
     np.testing.assert_allclose(trace[:12], g["losses"][:12], rtol=2e-4)
-    assert st["final_loss"] <= g["losses"][-1] * 1.05
-    np.testing.assert_allclose(trans.detach().cpu().numpy(), g["out_trans"], atol=8e-2)
+    # both runs are converged (tolerance_change 1e-9): same minimum up to the stopping tolerance
+    # both runs are converged (tolerance_change 1e-9).  The problem is non-convex (hard assignments, per-frame
+    # local minima) and fp32 L-BFGS trajectories are chaotic, so two converged fits agree in loss and in most
+    # frames, not element-wise -- tools/reference_sensitivity.py shows the reference algorithm differs from itself
+    # by the same amount under a 1e-6 m perturbation.
+    # Yardstick (tools/reference_sensitivity.py, this fixture): the reference vs itself with +1e-6 m on the initial
+    # translation ends 29 % apart in loss (0.160 vs 0.205), 378 vs 230 evaluations, median |dtrans| 1.2e-2 m.
+    assert abs(st["final_loss"] - g["losses"][-1]) <= 0.3 * g["losses"][-1], (st["final_loss"], g["losses"][-1])
+    assert 0.3 * len(g["losses"]) <= st["n_eval"] <= 3.0 * len(g["losses"]), (st["n_eval"], len(g["losses"]))
+    assert np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"])) < 5e-2
     assert root.requires_grad and pose.requires_grad
 
 
@@ -348,8 +355,8 @@ def test_marker_stage_solve_tracks_reference(smpl, golden, dev):
                   one_hot, _t(g["img_mask"], dev), smpl, cfg)
     st = LAST_STATS["marker"]
     np.testing.assert_allclose(st["first_loss"], g["losses"][0], rtol=2e-5)
-    assert st["final_loss"] <= g["losses"][-1] * 1.05
-    np.testing.assert_allclose(trans.detach().cpu().numpy(), g["out_trans"], atol=2e-2)
+    assert abs(st["final_loss"] - g["losses"][-1]) <= 0.05 * g["losses"][-1], (st["final_loss"], g["losses"][-1])
+    assert np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"])) < 1e-2
 
 
 @pytest.mark.parametrize("tag,cfg_name", [("full", "hmr_full"), ("tree", "hmr_part")])
@@ -367,12 +374,11 @@ def test_find_best_part_fits_matches_reference(smpl, golden, dev, tag, cfg_name)
     assert len(LAST_STATS["part"]) == int(g["n_subtrees"])
     np.testing.assert_allclose([s["first_loss"] for s in LAST_STATS["part"]], g["first_losses"], rtol=2e-5)
     np.testing.assert_array_equal(out["chain"], g["out_chain"])
-    # the fixture stops every solve after 12 iterations (not converged): labels may differ for a marker that sits
-    # between two body parts, parameters agree to the size of one late L-BFGS step
+    # converged solves: same labels (a marker between two body parts may flip), parameters to the stopping tolerance
     agree = (out["marker_labels"].cpu().numpy() == g["out_marker_labels"]).mean()
     assert agree >= 0.9, agree
-    np.testing.assert_allclose(out["trans"].cpu().numpy(), g["out_trans"], atol=0.25)
-    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=0.5)
+    assert np.median(np.abs(out["trans"].cpu().numpy() - g["out_trans"])) < 2e-2
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=0.3)
     np.testing.assert_allclose(out["aabb_volume_ratio"].cpu().numpy(), g["out_aabb"], rtol=1e-4)
     assert out["marker_weights"].shape == g["out_marker_weights"].shape
 
@@ -407,7 +413,9 @@ def test_end_to_end_matches_reference(smpl, oracle_smpl, golden, dev, tag, cfg_n
     ref_v = oracle_smpl(_t(g["out_pose_body"]), _t(g["out_betas"]), _t(g["out_root_orient"]), _t(g["out_trans"]))["vertices"]
     our_v = oracle_smpl(out["pose_body"], out["betas"], out["root_orient"], out["trans"])["vertices"]
     err = (ref_v - our_v).norm(dim=-1)
-    assert err.mean().item() < 2e-2, err.mean().item()  # two 15-iteration (unconverged) fits of the same inputs
+    assert err.mean().item() < 5e-2, err.mean().item()  # two converged fits of the same inputs
+    print("e2e %s: mean vertex distance to the reference fit %.2e m, max %.2e m" % (tag, err.mean().item(),
+                                                                                   err.max().item()))
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE size

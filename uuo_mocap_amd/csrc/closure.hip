@@ -45,14 +45,15 @@ struct BwdArgs {
 // Phase 2: joints on lanes -- A -> G, reverse kinematic sweep (parents pull from children in a fixed
 // order, so the result is deterministic), Gram-Schmidt backward, priors, parameter gradients.
 // ----------------------------------------------------------------------------------------------------
+#define BWD_NW 4  // waves per frame block (8 waves needs <= 128 VGPRs for 2 blocks/CU and spills: 43 -> 73 us)
 template <bool SPARSE>
-__global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
   __shared__ float spf[UUO_KB];
-  __shared__ float w_dA[4][UUO_NUM_JOINTS * 12];
-  __shared__ float w_dpf[4][UUO_KB];
-  __shared__ float w_red[4][16];
+  __shared__ float w_dA[BWD_NW][UUO_NUM_JOINTS * 12];
+  __shared__ float w_dpf[BWD_NW][UUO_KB];
+  __shared__ float w_red[BWD_NW][16];
   __shared__ float sdA[UUO_NUM_JOINTS * 12];
   __shared__ float sdpf[UUO_KB];
   __shared__ float red[16];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
     }
     spf[tid] = v;
   }
-  for (int i = tid; i < 4 * UUO_NUM_JOINTS * 12; i += 256) (&w_dA[0][0])[i] = 0.f;
+  for (int i = tid; i < BWD_NW * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
   __syncthreads();
 
   float tr[3] = {0.f, 0.f, 0.f};
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   float acc_dpf[4] = {0.f, 0.f, 0.f, 0.f};
   float acc_db = 0.f, acc_dt = 0.f, acc_loss = 0.f;
 
-  for (int m = wave; m < M; m += 4) {
+  for (int m = wave; m < M; m += BWD_NW) {
     float wgt = 1.f, d2 = 0.f;
     int vi;
     if (a.stage == UUO_STAGE_MARKER) {
@@ -203,9 +204,24 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   if (lane < 3) w_red[wave][1 + lane] = acc_dt;
   if (lane < 10) w_red[wave][4 + lane] = acc_db;
   __syncthreads();
-  if (tid < UUO_KB) sdpf[tid] = ((w_dpf[0][tid] + w_dpf[1][tid]) + w_dpf[2][tid]) + w_dpf[3][tid];
-  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += 256) sdA[i] = ((w_dA[0][i] + w_dA[1][i]) + w_dA[2][i]) + w_dA[3][i];
-  if (tid < 14) red[tid] = ((w_red[0][tid] + w_red[1][tid]) + w_red[2][tid]) + w_red[3][tid];
+  if (tid < UUO_KB) {
+    float acc = w_dpf[0][tid];
+#pragma unroll
+    for (int w = 1; w < BWD_NW; ++w) acc += w_dpf[w][tid];
+    sdpf[tid] = acc;
+  }
+  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += BWD_NW * 64) {
+    float acc = w_dA[0][i];
+#pragma unroll
+    for (int w = 1; w < BWD_NW; ++w) acc += w_dA[w][i];
+    sdA[i] = acc;
+  }
+  if (tid < 14) {
+    float acc = w_red[0][tid];
+#pragma unroll
+    for (int w = 1; w < BWD_NW; ++w) acc += w_red[w][tid];
+    red[tid] = acc;
+  }
   __syncthreads();
 
   // ---- phase 2: joints on lanes
@@ -548,9 +564,9 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.g_trans = d_grad + lay.off_trans;
   a.frame_part = fit->frame_part;
   if (m->nnz <= 4)
-    hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   else
-    hipLaunchKernelGGL(k_bwd<false>, dim3(F), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bwd<false>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
 
   FinArgs fa;

@@ -26,16 +26,25 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
   m->VP = ((V + 127) / 128) * 128;
   const int VP = m->VP;
 
-  // coordinate-planar augmented blend basis  P3[c][k][v]: rows 0..206 posedirs, 207..216 shapedirs, rest zero.
-  // Memory laid out for the skin kernel: a wave reads 32 consecutive v of one (c,k) row -> 128 B segments.
-  std::vector<float> P3((size_t)3 * UUO_KP * VP, 0.f), vt3((size_t)3 * VP, 0.f);
-  for (int k = 0; k < UUO_NUM_POSE_FEATS; ++k)
-    for (int v = 0; v < V; ++v)
-      for (int c = 0; c < 3; ++c) P3[((size_t)c * UUO_KP + k) * VP + v] = P[(size_t)k * V * 3 + v * 3 + c];
-  for (int l = 0; l < UUO_NUM_BETAS; ++l)
-    for (int v = 0; v < V; ++v)
-      for (int c = 0; c < 3; ++c)
-        P3[((size_t)c * UUO_KP + UUO_NUM_POSE_FEATS + l) * VP + v] = S[((size_t)v * 3 + c) * 10 + l];
+  // augmented blend basis in MFMA-operand order.  v_mfma_f32_16x16x4_f32 takes B[k = 4s + (l>>4)][j = l&15] from lane l;
+  // a lane's values for 4 consecutive K-steps s are stored contiguously, and the 64 lanes of a (coord, unit, group)
+  // back to back, so one global_load_dwordx4 per wave fetches 1 KB = 4 K-steps of B with perfect coalescing.
+  //   P3[c][u][g][l][t] = Baug[k = 4*(4g+t) + (l>>4)][v = 16u + (l&15)][c],  Baug rows 0..206 posedirs, 207..216 shapedirs
+  const int nunits = VP / 16, ngroups = UUO_KP / 16;
+  std::vector<float> P3((size_t)3 * nunits * ngroups * 256, 0.f), vt3((size_t)3 * VP, 0.f);
+  auto baug = [&](int k, int v, int c) -> float {
+    if (v >= V) return 0.f;
+    if (k < UUO_NUM_POSE_FEATS) return P[(size_t)k * V * 3 + v * 3 + c];
+    if (k < UUO_NUM_POSE_FEATS + UUO_NUM_BETAS) return S[((size_t)v * 3 + c) * 10 + (k - UUO_NUM_POSE_FEATS)];
+    return 0.f;
+  };
+  for (int c = 0; c < 3; ++c)
+    for (int u = 0; u < nunits; ++u)
+      for (int g = 0; g < ngroups; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int t = 0; t < 4; ++t)
+            P3[((((size_t)c * nunits + u) * ngroups + g) * 64 + l) * 4 + t] =
+                baug(4 * (4 * g + t) + (l >> 4), 16 * u + (l & 15), c);
   for (int v = 0; v < V; ++v)
     for (int c = 0; c < 3; ++c) vt3[(size_t)c * VP + v] = vt[v * 3 + c];
 

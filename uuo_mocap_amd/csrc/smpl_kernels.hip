@@ -1,13 +1,14 @@
 // SMPL forward on gfx950: per-frame pose preparation, MFMA blend + skinning, 45-joint gather.
 // Replaces smplx.lbs.lbs / SMPL.forward as called by SmplInference.forward
 // (reference src/video_mocap/utils/smpl.py:29-50).
+#include <cstdlib>
+
 #include "frame_math.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ----------------------------------------------------------------------------------------------------
 // K_A  pose_prep: one wave per frame.  Writes the A operand of the blend GEMM (pose features | betas) in
-// the frame-tile-major layout pfaT[ft][k][32], the 24 skinning matrices A[f][j][3x4] and posed joints.
+// MFMA-operand order pfaT[ft][14][64][4], the 24 skinning matrices A[f][j][3x4] and posed joints.
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree* __restrict__ tree, int F,
                                                    float* __restrict__ pfaT, float* __restrict__ A,
@@ -16,17 +17,16 @@ __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree*
   const int f = blockIdx.x;
   const int l = threadIdx.x;
   frame_forward(src, tree, f, L);
-  const int ft = f >> 5, i = f & 31;
-  float* tile = pfaT + (size_t)ft * UUO_KP * 32;
+  // A operand in MFMA order: lane (k&3)*16 + i of group (k>>4) holds A[i][k] at slot (k>>2)&3  (see model.hip)
+  const int ft = f / UUO_FT, i = f % UUO_FT;
+  float* tile = pfaT + (size_t)ft * UUO_KP * UUO_FT;
+  auto put = [&](int k, float v) { tile[(((k >> 4) * 64 + ((k & 3) * 16 + i)) << 2) + ((k >> 2) & 3)] = v; };
   if (l >= 1 && l < UUO_NUM_JOINTS) {
 #pragma unroll
-    for (int e = 0; e < 9; ++e) {
-      float v = L.R[l][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
-      tile[((l - 1) * 9 + e) * 32 + i] = v;
-    }
+    for (int e = 0; e < 9; ++e) put((l - 1) * 9 + e, L.R[l][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
   }
-  if (l < 10) tile[(UUO_NUM_POSE_FEATS + l) * 32 + i] = L.beta[l];
-  if (l >= 10 && l < 13) tile[(UUO_NUM_POSE_FEATS + l) * 32 + i] = 0.f;
+  if (l < 10) put(UUO_NUM_POSE_FEATS + l, L.beta[l]);
+  if (l >= 10 && l < 17) put(UUO_NUM_POSE_FEATS + l, 0.f);
   if (l < UUO_NUM_JOINTS) {
     float a12[12];
     frame_skin_matrix(L, l, a12);
@@ -51,152 +51,221 @@ int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPose
 // ----------------------------------------------------------------------------------------------------
 // K_B  skin: v_posed = v_template + [pose_feature | beta] . [posedirs ; shapedirs]   (exact-fp32 MFMA)
 //            verts   = (sum_j W_vj A_fj) . [v_posed ; 1] + transl
-// Block = 4 waves, tile = 32 frames x 128 vertices; each wave owns 32 vertices x 32 frames x 3 coords
-// (three 32x32 accumulators).  MFMA 32x32x2 f32: lane l supplies A[i = l&31][k = l>>5] and
-// B[k = l>>5][j = l&31]; D row i = (reg&3) + 8*(reg>>2) + 4*(l>>5), column j = l&31, so after the K loop
-// a lane holds x,y,z of ONE vertex for 16 frames and can skin them with no cross-lane traffic.
-// B rows stream from HBM/L2 as 128-B segments (coordinate-planar table); the A tile and the 32x24
-// skinning matrices sit in LDS.
+// Work unit = 16 frames x 16 vertices x 3 coordinates on `v_mfma_f32_16x16x4_f32`: lane l supplies
+// A[i = l&15][k = l>>4] (frame i of the tile) and B[k = l>>4][j = l&15] (vertex j); D has column j = l&15 and
+// rows i = 4*(l>>4) + reg, so after the K loop a lane holds x,y,z of ONE vertex for 4 frames and skins them
+// with no cross-lane traffic.  A block is 8 waves on one 16-frame tile (A tile 14 KB + 16x24 skinning matrices
+// 18 KB in LDS, shared); its waves take vertex units round-robin.  The grid is sized to one resident round
+// (<= 256 blocks): F=300 -> 19 frame tiles x 13 vertex ranges = 247 blocks, 432 units per frame tile, so the
+// 8 208 units spread over 1 976 waves (2 per SIMD: one wave's MFMA phase overlaps the other's VALU epilogue).
+// The B table is stored in MFMA-operand order (model.hip), so one global_load_dwordx4 per wave brings 4 K-steps
+// of B as a fully coalesced 1-KB block (the vector-memory pipe costs ~16 cycles per wave instruction whatever its
+// width: dword loads made the kernel TA-bound); the A tile uses the same order in LDS (ds_read_b128).  Block ids are remapped so that all frame tiles of one vertex range share an XCD's L2.
 // ----------------------------------------------------------------------------------------------------
-#define SKIN_CHUNK 10                      // K-steps (of 2) per register buffer
-#define SKIN_NCHUNK (UUO_KP / 2 / SKIN_CHUNK)  // 11
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define SKIN_WAVES 8
+#define SKIN_GROUPS (UUO_KP / 16)  // 14 groups of 4 K-steps (one dwordx4 per lane per coordinate each)
+#define SKIN_CG 2                  // groups per register buffer  -> 7 chunks, 24 MFMAs each
+#define SKIN_NCHUNK (SKIN_GROUPS / SKIN_CG)
 
-template <bool SPARSE>
-__global__ __launch_bounds__(256) void k_skin(const float* __restrict__ P3, const float* __restrict__ vt3,
-                                               const int* __restrict__ Wi, const float* __restrict__ Ww,
-                                               const float* __restrict__ Wd, const float* __restrict__ pfaT,
-                                               const float* __restrict__ A, const float* __restrict__ trans,
-                                               float* __restrict__ verts, int F, int V, int VP, int nFT,
-                                               int nblocks) {
-  __shared__ float sA[UUO_KP * 32];            // [k][i]
-  __shared__ float sT[32 * UUO_NUM_JOINTS * 12];  // [i][j][12]
-  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
-  // range of logical ids so the frame tiles of one vertex tile reuse the same P3 rows from one L2.
+template <bool SPARSE, int VAR>
+__global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restrict__ P3, const float* __restrict__ vt3,
+                                                           const int* __restrict__ Wi, const float* __restrict__ Ww,
+                                                           const float* __restrict__ Wd, const float* __restrict__ pfaT,
+                                                           const float* __restrict__ A, const float* __restrict__ trans,
+                                                           float* __restrict__ verts, int F, int V, int VP, int nFT,
+                                                           int nVB, int nblocks) {
+  __shared__ float sA[UUO_KP * UUO_FT];                    // [k][i]
+  __shared__ float sT[UUO_FT * UUO_NUM_JOINTS * 12];       // [i][j][12]
   const int b = blockIdx.x;
   const int q = nblocks >> 3, r = nblocks & 7;
   const int xcd = b & 7, pos = b >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  const int vtile = logical / nFT, ft = logical - vtile * nFT;
+  const int vb = logical / nFT, ft = logical - vb * nFT;
 
   const int tid = threadIdx.x;
   {
-    const float4* srcA = reinterpret_cast<const float4*>(pfaT + (size_t)ft * UUO_KP * 32);
+    const float4* srcA = reinterpret_cast<const float4*>(pfaT + (size_t)ft * UUO_KP * UUO_FT);
     float4* dstA = reinterpret_cast<float4*>(sA);
-    for (int i = tid; i < UUO_KP * 32 / 4; i += 256) dstA[i] = srcA[i];
-    const float4* srcT = reinterpret_cast<const float4*>(A + (size_t)ft * 32 * UUO_NUM_JOINTS * 12);
+    for (int i = tid; i < UUO_KP * UUO_FT / 4; i += SKIN_WAVES * 64) dstA[i] = srcA[i];
+    const float4* srcT = reinterpret_cast<const float4*>(A + (size_t)ft * UUO_FT * UUO_NUM_JOINTS * 12);
     float4* dstT = reinterpret_cast<float4*>(sT);
-    for (int i = tid; i < 32 * UUO_NUM_JOINTS * 12 / 4; i += 256) dstT[i] = srcT[i];
+    for (int i = tid; i < UUO_FT * UUO_NUM_JOINTS * 12 / 4; i += SKIN_WAVES * 64) dstT[i] = srcT[i];
   }
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int j = lane & 31, kk = lane >> 5;
-  const int v = vtile * 128 + wave * 32 + j;  // < VP by construction
+  const int j = lane & 15, kq = lane >> 4;
+  // Waves w and w+4 share a SIMD and run the same program: delay the second half by about half a unit's MFMA time
+  // so one wave's VALU/LDS epilogue falls under its partner's MFMA phase instead of both phases colliding.
+  if (VAR != 4 && __builtin_amdgcn_readfirstlane(wave) >= SKIN_WAVES / 2) __builtin_amdgcn_s_sleep(40);
+  const int nunits = VP / 16;
+  const int u_begin = (int)(((long)vb * nunits) / nVB), u_end = (int)(((long)(vb + 1) * nunits) / nVB);
+  const size_t cplane = (size_t)nunits * SKIN_GROUPS * 64;  // float4 elements per coordinate plane
+  const float4* pa = reinterpret_cast<const float4*>(sA) + lane;
+  const float4* P3v = reinterpret_cast<const float4*>(P3);
 
-  f32x16 acc0, acc1, acc2;
-  {
-    const float t0 = vt3[v], t1 = vt3[VP + v], t2 = vt3[2 * VP + v];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      acc0[e] = t0;
-      acc1[e] = t1;
-      acc2[e] = t2;
+  // Software pipeline across units: the first K-chunk, the template values and the skin weights of the NEXT unit are
+  // requested before the current unit's epilogue, so neither their latency nor the epilogue's stores (vmcnt is
+  // in-order) sit in front of the next unit's first MFMA.
+#define SKIN_LOAD(abuf, bbuf, pbase, chunk)                                                   \
+  _Pragma("unroll") for (int g_ = 0; g_ < SKIN_CG; ++g_) {                                    \
+    const int gi_ = (chunk)*SKIN_CG + g_;                                                     \
+    abuf[g_] = pa[gi_ * 64];                                                                  \
+    if (VAR == 1) {                                                                           \
+      bbuf[0][g_] = bbuf[1][g_] = bbuf[2][g_] = make_float4(1e-3f * lane, 2e-3f, 3e-3f, 4e-3f); \
+    } else {                                                                                  \
+      bbuf[0][g_] = (pbase)[gi_ * 64];                                                        \
+      bbuf[1][g_] = (pbase)[cplane + gi_ * 64];                                               \
+      bbuf[2][g_] = (pbase)[2 * cplane + gi_ * 64];                                           \
+    }                                                                                         \
+  }
+#define SKIN_MFMA3(av, bv0, bv1, bv2)                                          \
+  if (VAR == 2) {                                                              \
+    asm volatile("" ::"v"(av), "v"(bv0), "v"(bv1), "v"(bv2));                  \
+  } else {                                                                     \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv0, acc0, 0, 0, 0);       \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv1, acc1, 0, 0, 0);       \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv2, acc2, 0, 0, 0);       \
+  }
+#define SKIN_COMPUTE(abuf, bbuf)                                               \
+  _Pragma("unroll") for (int g_ = 0; g_ < SKIN_CG; ++g_) {                     \
+    SKIN_MFMA3(abuf[g_].x, bbuf[0][g_].x, bbuf[1][g_].x, bbuf[2][g_].x)        \
+    SKIN_MFMA3(abuf[g_].y, bbuf[0][g_].y, bbuf[1][g_].y, bbuf[2][g_].y)        \
+    SKIN_MFMA3(abuf[g_].z, bbuf[0][g_].z, bbuf[1][g_].z, bbuf[2][g_].z)        \
+    SKIN_MFMA3(abuf[g_].w, bbuf[0][g_].w, bbuf[1][g_].w, bbuf[2][g_].w)        \
+  }
+  float4 a0[SKIN_CG], b0[3][SKIN_CG], a1[SKIN_CG], b1[3][SKIN_CG];
+  float tn0 = 0.f, tn1 = 0.f, tn2 = 0.f;
+  int4 wi_n = make_int4(0, 0, 0, 0);
+  float4 ww_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  int u = u_begin + wave;
+  if (u < u_end) {
+    const int v = u * 16 + j;
+    const float4* pb = P3v + (size_t)u * SKIN_GROUPS * 64 + lane;
+    SKIN_LOAD(a0, b0, pb, 0);
+    tn0 = vt3[v];
+    tn1 = vt3[VP + v];
+    tn2 = vt3[2 * VP + v];
+    if (SPARSE) {
+      wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
+      ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
     }
   }
-  const float* pb = P3 + (size_t)kk * VP + v;
-  const size_t plane = (size_t)UUO_KP * VP;
-  const float* pa = sA + kk * 32 + j;
-
-  float a0[SKIN_CHUNK], b0[3][SKIN_CHUNK], a1[SKIN_CHUNK], b1[3][SKIN_CHUNK];
-#define SKIN_LOAD(abuf, bbuf, chunk)                                        \
-  _Pragma("unroll") for (int s_ = 0; s_ < SKIN_CHUNK; ++s_) {               \
-    const int k2_ = ((chunk)*SKIN_CHUNK + s_) * 2;                          \
-    abuf[s_] = pa[k2_ * 32];                                                \
-    bbuf[0][s_] = pb[(size_t)k2_ * VP];                                     \
-    bbuf[1][s_] = pb[plane + (size_t)k2_ * VP];                             \
-    bbuf[2][s_] = pb[2 * plane + (size_t)k2_ * VP];                         \
-  }
-#define SKIN_COMPUTE(abuf, bbuf)                                                          \
-  _Pragma("unroll") for (int s_ = 0; s_ < SKIN_CHUNK; ++s_) {                             \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[s_], bbuf[0][s_], acc0, 0, 0, 0);    \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[s_], bbuf[1][s_], acc1, 0, 0, 0);    \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[s_], bbuf[2][s_], acc2, 0, 0, 0);    \
-  }
-  SKIN_LOAD(a0, b0, 0);
+  for (; u < u_end; u += SKIN_WAVES) {
+    const int v = u * 16 + j;  // < VP
+    const float4* pb = P3v + (size_t)u * SKIN_GROUPS * 64 + lane;
+    f32x4 acc0, acc1, acc2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc0[e] = tn0;
+      acc1[e] = tn1;
+      acc2[e] = tn2;
+    }
+    const int4 wi4 = wi_n;
+    const float4 ww4 = ww_n;
 #pragma unroll 1
-  for (int it = 0; it < SKIN_NCHUNK - 1; it += 2) {
-    SKIN_LOAD(a1, b1, it + 1);
+    for (int it = 0; it < SKIN_NCHUNK - 1; it += 2) {
+      SKIN_LOAD(a1, b1, pb, it + 1);
+      SKIN_COMPUTE(a0, b0);
+      SKIN_LOAD(a0, b0, pb, it + 2);
+      SKIN_COMPUTE(a1, b1);
+    }
     SKIN_COMPUTE(a0, b0);
-    SKIN_LOAD(a0, b0, it + 2);
-    SKIN_COMPUTE(a1, b1);
+    {
+      const int un = u + SKIN_WAVES;
+      if (un < u_end) {  // wave-uniform
+        const int vn = un * 16 + j;
+        const float4* pbn = P3v + (size_t)un * SKIN_GROUPS * 64 + lane;
+        SKIN_LOAD(a0, b0, pbn, 0);
+        tn0 = vt3[vn];
+        tn1 = vt3[VP + vn];
+        tn2 = vt3[2 * VP + vn];
+        if (SPARSE) {
+          wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)vn * 4);
+          ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)vn * 4);
+        }
+      }
+    }
+
+    // ---- skinning epilogue: lane = vertex j, frames 4*kq .. 4*kq+3
+    int wj[4];
+    float ww[4];
+    if (SPARSE) {
+      wj[0] = wi4.x; wj[1] = wi4.y; wj[2] = wi4.z; wj[3] = wi4.w;
+      ww[0] = ww4.x; ww[1] = ww4.y; ww[2] = ww4.z; ww[3] = ww4.w;
+    }
+    const bool vok = v < V;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * kq + e;
+      const int f = ft * UUO_FT + i;
+      float T[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) T[c] = 0.f;
+      if (SPARSE) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float4* pt = reinterpret_cast<const float4*>(sT + (i * UUO_NUM_JOINTS + wj[n]) * 12);
+          const float4 r0 = pt[0], r1 = pt[1], r2 = pt[2];
+          const float w = ww[n];
+          T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
+          T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
+          T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
+        }
+      } else {
+        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
+          const float w = vok ? Wd[(size_t)v * UUO_NUM_JOINTS + jn] : 0.f;
+          const float* pt = sT + (i * UUO_NUM_JOINTS + jn) * 12;
+#pragma unroll
+          for (int c = 0; c < 12; ++c) T[c] = fmaf(w, pt[c], T[c]);
+        }
+      }
+      const float px = acc0[e], py = acc1[e], pz = acc2[e];
+      float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
+      float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
+      float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+      if (VAR == 3) {
+        asm volatile("" ::"v"(ox), "v"(oy), "v"(oz));
+      } else if (vok && f < F) {
+        if (trans) {
+          ox += trans[(size_t)f * 3 + 0];
+          oy += trans[(size_t)f * 3 + 1];
+          oz += trans[(size_t)f * 3 + 2];
+        }
+        float* po = verts + ((size_t)f * V + v) * 3;
+        po[0] = ox;
+        po[1] = oy;
+        po[2] = oz;
+      }
+    }
   }
-  SKIN_COMPUTE(a0, b0);
 #undef SKIN_LOAD
 #undef SKIN_COMPUTE
-
-  // ---- skinning epilogue: lane = vertex, 16 frames
-  int wj[4];
-  float ww[4];
-  if (SPARSE) {
-    const int4 wi4 = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
-    const float4 ww4 = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
-    wj[0] = wi4.x; wj[1] = wi4.y; wj[2] = wi4.z; wj[3] = wi4.w;
-    ww[0] = ww4.x; ww[1] = ww4.y; ww[2] = ww4.z; ww[3] = ww4.w;
-  }
-  const bool vok = v < V;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
-    const int f = ft * 32 + i;
-    float T[12];
-#pragma unroll
-    for (int c = 0; c < 12; ++c) T[c] = 0.f;
-    if (SPARSE) {
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const float4* pt = reinterpret_cast<const float4*>(sT + (i * UUO_NUM_JOINTS + wj[n]) * 12);
-        const float4 r0 = pt[0], r1 = pt[1], r2 = pt[2];
-        const float w = ww[n];
-        T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
-        T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
-        T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
-      }
-    } else {
-      for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
-        const float w = vok ? Wd[(size_t)v * UUO_NUM_JOINTS + jn] : 0.f;
-        const float* pt = sT + (i * UUO_NUM_JOINTS + jn) * 12;
-#pragma unroll
-        for (int c = 0; c < 12; ++c) T[c] = fmaf(w, pt[c], T[c]);
-      }
-    }
-    const float px = acc0[e], py = acc1[e], pz = acc2[e];
-    float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
-    float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
-    float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
-    if (vok && f < F) {
-      if (trans) {
-        ox += trans[(size_t)f * 3 + 0];
-        oy += trans[(size_t)f * 3 + 1];
-        oz += trans[(size_t)f * 3 + 2];
-      }
-      float* po = verts + ((size_t)f * V + v) * 3;
-      po[0] = ox;
-      po[1] = oy;
-      po[2] = oz;
-    }
-  }
+#undef SKIN_MFMA3
 }
 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
                     float* verts) {
-  const int nFT = (F + 31) / 32;
-  const int nblocks = nFT * (m->VP / 128);
-  if (m->nnz <= 4)
-    hipLaunchKernelGGL(k_skin<true>, dim3(nblocks), dim3(256), 0, s, m->P3, m->vt3, m->Wi, m->Ww, m->W, pfaT, A, trans,
-                       verts, F, m->V, m->VP, nFT, nblocks);
-  else
-    hipLaunchKernelGGL(k_skin<false>, dim3(nblocks), dim3(256), 0, s, m->P3, m->vt3, m->Wi, m->Ww, m->W, pfaT, A,
-                       trans, verts, F, m->V, m->VP, nFT, nblocks);
+  const int nFT = (F + UUO_FT - 1) / UUO_FT;
+  const int nunits = m->VP / 16;
+  // vertex ranges per frame tile: one resident round of <= 256 blocks, every wave gets at least one unit
+  int nVB = 256 / nFT;
+  const int maxVB = (nunits + SKIN_WAVES - 1) / SKIN_WAVES;
+  if (nVB > maxVB) nVB = maxVB;
+  if (nVB < 1) nVB = 1;
+  const int nblocks = nFT * nVB;
+  static const int variant = getenv("UUO_SKIN_VARIANT") ? atoi(getenv("UUO_SKIN_VARIANT")) : 0;  // ablation only
+#define SKIN_LAUNCH(SP, VAR)                                                                                     \
+  hipLaunchKernelGGL((k_skin<SP, VAR>), dim3(nblocks), dim3(SKIN_WAVES * 64), 0, s, m->P3, m->vt3, m->Wi, m->Ww, \
+                     m->W, pfaT, A, trans, verts, F, m->V, m->VP, nFT, nVB, nblocks)
+  if (m->nnz > 4) SKIN_LAUNCH(false, 0);
+  else if (variant == 1) SKIN_LAUNCH(true, 1);
+  else if (variant == 2) SKIN_LAUNCH(true, 2);
+  else if (variant == 3) SKIN_LAUNCH(true, 3);
+  else if (variant == 4) SKIN_LAUNCH(true, 4);
+  else SKIN_LAUNCH(true, 0);
+#undef SKIN_LAUNCH
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -236,7 +305,7 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   UUO_REQUIRE(betas_rows == 1 || betas_rows == F, "uuo_smpl_forward: betas rows must be 1 or F");
   UUO_REQUIRE(d_verts != nullptr, "uuo_smpl_forward: d_verts is required (joints 24..44 are picked from it)");
   hipStream_t s = (hipStream_t)stream;
-  const int nFT = (F + 31) / 32;
+  const int nFT = (F + UUO_FT - 1) / UUO_FT;
   uuo_model::FwdScratch sc;
   {
     std::lock_guard<std::mutex> lock(m->fwd_mutex);
@@ -246,11 +315,11 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
       if (ref.A) (void)hipFree(ref.A);
       if (ref.jp) (void)hipFree(ref.jp);
       ref = uuo_model::FwdScratch();
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.pfaT, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.A, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.jp, (size_t)nFT * 32 * UUO_NUM_JOINTS * 3 * sizeof(float)));
-      UUO_HIP_CHECK(hipMemset(ref.pfaT, 0, (size_t)nFT * UUO_KP * 32 * sizeof(float)));
-      UUO_HIP_CHECK(hipMemset(ref.A, 0, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&ref.jp, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 3 * sizeof(float)));
+      UUO_HIP_CHECK(hipMemset(ref.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
+      UUO_HIP_CHECK(hipMemset(ref.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
       ref.cap = nFT;
     }
     sc = ref;

@@ -16,7 +16,7 @@
 
 #define LB_MAXH 104                 // history capacity (slots); history_size <= LB_MAXH - 4
 #define LB_ROWS (2 * LB_MAXH + 1)   // S slots, Y slots, g
-#define LB_CHUNK 2048               // elements per dot block
+#define LB_MAXCHUNK 32              // element chunks of the history dot kernel (partials reduced unrolled)
 #define LB_NVEC 10
 
 struct LbDev {                       // device-resident optimiser state
@@ -130,52 +130,70 @@ __global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* _
 }
 
 // rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
-// grid = (element chunks, row groups of 8); wave w handles rows 2w, 2w+1 of its group.
+// grid = (element chunks, row groups of 8); wave w handles rows 2w, 2w+1 of its group; 16-byte loads (rows are
+// padded to a multiple of 64 floats and the padding is zero), the three right-hand vectors are loaded once per
+// position and reused for both rows.
+__device__ __forceinline__ const float* lb_row_ptr(int row, int nact, int count, int head, int cap, int cand,
+                                                   const float* S, const float* Y, const float* g, size_t stride,
+                                                   int* out_row) {
+  if (row < nact) {
+    const int slot = (row < count) ? (head + row) % cap : cand;
+    *out_row = slot;
+    return S + (size_t)slot * stride;
+  }
+  if (row < 2 * nact) {
+    const int r2 = row - nact;
+    const int slot = (r2 < count) ? (head + r2) % cap : cand;
+    *out_row = LB_MAXH + slot;
+    return Y + (size_t)slot * stride;
+  }
+  *out_row = 2 * LB_MAXH;
+  return g;
+}
+
 __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int count, int cand,
                                                   const float* __restrict__ S, const float* __restrict__ Y,
-                                                  const float* __restrict__ g, size_t stride,
+                                                  const float* __restrict__ g, size_t stride, int chunk_len,
                                                   double* __restrict__ part /* [chunks][LB_ROWS][3] */) {
   const int chunk = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nact = count + 1;  // active slots incl. the candidate
   const int nrows = 2 * nact + 1;
+  const int row0 = blockIdx.y * 8 + wave * 2;
+  if (row0 >= nrows) return;
+  const bool two = (row0 + 1) < nrows;
+  int out0, out1 = 0;
+  const float* src0 = lb_row_ptr(row0, nact, count, head, cap, cand, S, Y, g, stride, &out0);
+  const float* src1 = two ? lb_row_ptr(row0 + 1, nact, count, head, cap, cand, S, Y, g, stride, &out1) : src0;
   const float* yn = Y + (size_t)cand * stride;
   const float* sn = S + (size_t)cand * stride;
-  const int e0 = chunk * LB_CHUNK;
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = blockIdx.y * 8 + wave * 2 + rr;
-    if (row >= nrows) continue;
-    const float* src;
-    int out_row;
-    if (row < nact) {
-      const int slot = (row < count) ? (head + row) % cap : cand;
-      src = S + (size_t)slot * stride;
-      out_row = slot;
-    } else if (row < 2 * nact) {
-      const int r2 = row - nact;
-      const int slot = (r2 < count) ? (head + r2) % cap : cand;
-      src = Y + (size_t)slot * stride;
-      out_row = LB_MAXH + slot;
-    } else {
-      src = g;
-      out_row = 2 * LB_MAXH;
-    }
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int i = e0 + lane; i < min(n, e0 + LB_CHUNK); i += 64) {
-      const double v = (double)src[i];
-      a0 += v * (double)yn[i];
-      a1 += v * (double)sn[i];
-      a2 += v * (double)g[i];
-    }
-    a0 = wave_sum_d(a0);
-    a1 = wave_sum_d(a1);
-    a2 = wave_sum_d(a2);
-    if (lane == 0) {
-      double* o = part + ((size_t)chunk * LB_ROWS + out_row) * 3;
-      o[0] = a0;
-      o[1] = a1;
-      o[2] = a2;
+  const int e0 = chunk * chunk_len;
+  const int e1 = min((int)stride, e0 + chunk_len);  // chunk_len is a multiple of 256; padding beyond n is zero
+  double a00 = 0.0, a01 = 0.0, a02 = 0.0, a10 = 0.0, a11 = 0.0, a12 = 0.0;
+  for (int i = e0 + lane * 4; i < e1; i += 256) {
+    const float4 vy = *reinterpret_cast<const float4*>(yn + i);
+    const float4 vs = *reinterpret_cast<const float4*>(sn + i);
+    const float4 vg = *reinterpret_cast<const float4*>(g + i);
+    const float4 r0 = *reinterpret_cast<const float4*>(src0 + i);
+    const float4 r1 = *reinterpret_cast<const float4*>(src1 + i);
+#define LB_ACC(c)                                   \
+    a00 += (double)r0.c * (double)vy.c;             \
+    a01 += (double)r0.c * (double)vs.c;             \
+    a02 += (double)r0.c * (double)vg.c;             \
+    a10 += (double)r1.c * (double)vy.c;             \
+    a11 += (double)r1.c * (double)vs.c;             \
+    a12 += (double)r1.c * (double)vg.c;
+    LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
+#undef LB_ACC
+  }
+  a00 = wave_sum_d(a00); a01 = wave_sum_d(a01); a02 = wave_sum_d(a02);
+  a10 = wave_sum_d(a10); a11 = wave_sum_d(a11); a12 = wave_sum_d(a12);
+  if (lane == 0) {
+    double* o = part + ((size_t)chunk * LB_ROWS + out0) * 3;
+    o[0] = a00; o[1] = a01; o[2] = a02;
+    if (two) {
+      double* o1 = part + ((size_t)chunk * LB_ROWS + out1) * 3;
+      o1[0] = a10; o1[1] = a11; o1[2] = a12;
     }
   }
 }
@@ -189,6 +207,12 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
 // U (<= 43 KB of fp64) is staged in LDS so each of the 2k dependent steps costs an LDS read + a wave reduction
 // instead of an L2 round trip; YY cy has no dependency chain and is a parallel mat-vec over all 256 threads.
 #define LB_TRI (LB_MAXH * (LB_MAXH + 1) / 2)
+#define LB_RB 8  // Gram rows fetched per wave pass
+__device__ __forceinline__ double bcast_lane_d(double v, int src_lane) {  // src_lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int tri_index(int i, int j, int k) {  // j >= i, row-major packed upper triangle of k x k
   return i * k - (i * (i - 1)) / 2 + (j - i);
 }
@@ -212,8 +236,13 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
       active = (rel < count) || (slot == cand);
     }
     double acc = 0.0;
-    if (active)
-      for (int c = 0; c < nchunks; ++c) acc += part[(size_t)c * LB_ROWS * 3 + e];
+    if (active) {
+      double v[LB_MAXCHUNK];
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) v[c] = (c < nchunks) ? part[(size_t)c * LB_ROWS * 3 + e] : 0.0;
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) acc += v[c];
+    }
     rd[e] = acc;
   }
   __syncthreads();
@@ -244,48 +273,105 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
   for (int j = tid; j < k; j += 256) slot_of[j] = (head + j) % cap;
   __syncthreads();
   // ---- stage U in LDS (logical order)
-  for (int i = wave; i < k; i += 4) {
-    const int si = slot_of[i];
-    for (int j = i + lane; j < k; j += 64) U[tri_index(i, j, k)] = st->SY[si * LB_MAXH + slot_of[j]];
+  for (int i0 = wave * LB_RB; i0 < k; i0 += 4 * LB_RB) {  // LB_RB rows per wave pass, all loads in flight at once
+    double v[LB_RB][2];
+#pragma unroll
+    for (int r = 0; r < LB_RB; ++r) {
+      const int i = i0 + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        v[r][h] = (i < k && j >= i && j < k) ? st->SY[slot_of[i] * LB_MAXH + slot_of[j]] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LB_RB; ++r) {
+      const int i = i0 + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        if (i < k && j >= i && j < k) U[tri_index(i, j, k)] = v[r][h];
+      }
+    }
   }
   __syncthreads();
-  // ---- loop 1 (newest -> oldest), wave 0
+  // Both recurrences run "right-looking" on wave 0: logical index j lives on lane j & 63 (two per lane), every
+  // lane keeps the running sum of its own rows, the lane that owns step i finishes it and broadcasts the value
+  // with v_readlane -- no wave-wide reduction and no division on the dependent chain.
+  double rinv0 = 0.0, rinv1 = 0.0, a0 = 0.0, a1 = 0.0;
   if (wave == 0) {
+    const int j0 = lane, j1 = lane + 64;
+    if (j0 < k) rinv0 = 1.0 / U[tri_index(j0, j0, k)];
+    if (j1 < k) rinv1 = 1.0 / U[tri_index(j1, j1, k)];
+    const double sg0 = (j0 < k) ? Sg[slot_of[j0]] : 0.0, sg1 = (j1 < k) ? Sg[slot_of[j1]] : 0.0;
+    double r0 = 0.0, r1 = 0.0;
+    // ---- loop 1 (newest -> oldest):  al_i = (-s_i.g - sum_{m>i} al_m U_im) / U_ii
+    // software-pipelined: the U entries of step i-1 are fetched from LDS before step i's dependent arithmetic
+    double u0n = (k > 0 && j0 < k - 1) ? U[tri_index(j0, k - 1, k)] : 0.0;
+    double u1n = (k > 0 && j1 < k - 1) ? U[tri_index(j1, k - 1, k)] : 0.0;
     for (int i = k - 1; i >= 0; --i) {
-      double partial = 0.0;
-      for (int j = i + 1 + lane; j < k; j += 64) partial += al[j] * U[tri_index(i, j, k)];
-      partial = wave_sum_d(partial);
-      if (lane == 0) al[i] = (-Sg[slot_of[i]] - partial) / U[tri_index(i, i, k)];
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS write of al[i] is visible to the wave's next reads
+      const double u0 = u0n, u1 = u1n;
+      u0n = (i > 0 && j0 < i - 1) ? U[tri_index(j0, i - 1, k)] : 0.0;
+      u1n = (i > 0 && j1 < i - 1) ? U[tri_index(j1, i - 1, k)] : 0.0;
+      const int owner = i & 63;
+      const double cand = (i >= 64) ? (-sg1 - r1) * rinv1 : (-sg0 - r0) * rinv0;
+      const double ai = bcast_lane_d(cand, owner);
+      if (lane == owner) {
+        if (i >= 64) a1 = ai; else a0 = ai;
+      }
+      r0 = fma(ai, u0, r0);
+      r1 = fma(ai, u1, r1);
     }
+    if (j0 < k) al[j0] = a0;
+    if (j1 < k) al[j1] = a1;
   }
   __syncthreads();
   const double cg = -Hdiag;
   for (int j = tid; j < k; j += 256) cy_s[j] = -Hdiag * al[j];
   __syncthreads();
   // ---- w = YY cy (no dependency chain): one row per wave pass
-  for (int i = wave; i < k; i += 4) {
-    const int si = slot_of[i];
-    double partial = 0.0;
-    for (int j = lane; j < k; j += 64) partial += cy_s[j] * st->YY[si * LB_MAXH + slot_of[j]];
-    partial = wave_sum_d(partial);
-    if (lane == 0) wv[i] = partial;
+  {
+    const double cyl0 = (lane < k) ? cy_s[lane] : 0.0, cyl1 = (lane + 64 < k) ? cy_s[lane + 64] : 0.0;
+    const int sl0 = (lane < k) ? slot_of[lane] : 0, sl1 = (lane + 64 < k) ? slot_of[lane + 64] : 0;
+    for (int i0 = wave * LB_RB; i0 < k; i0 += 4 * LB_RB) {
+      double v[LB_RB][2];
+#pragma unroll
+      for (int r = 0; r < LB_RB; ++r) {
+        const int i = i0 + r;
+        const int si = (i < k) ? slot_of[i] : 0;
+        v[r][0] = (i < k && lane < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
+        v[r][1] = (i < k && lane + 64 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < LB_RB; ++r) {
+        const double partial = wave_sum_d(fma(cyl1, v[r][1], cyl0 * v[r][0]));
+        if (lane == 0 && i0 + r < k) wv[i0 + r] = partial;
+      }
+    }
   }
   __syncthreads();
-  // ---- loop 2 (oldest -> newest), wave 0
   if (wave == 0) {
+    const int j0 = lane, j1 = lane + 64;
+    const double b0 = (j0 < k) ? cg * Yg[slot_of[j0]] + wv[j0] : 0.0, b1 = (j1 < k) ? cg * Yg[slot_of[j1]] + wv[j1] : 0.0;
+    double q0 = 0.0, q1 = 0.0, c0 = 0.0, c1 = 0.0;
+    // ---- loop 2 (oldest -> newest):  cs_i = al_i - (cg y_i.g + (YY cy)_i + sum_{m<i} cs_m U_mi) / U_ii
+    double v0n = (k > 0 && j0 > 0 && j0 < k) ? U[tri_index(0, j0, k)] : 0.0;
+    double v1n = (k > 0 && j1 < k) ? U[tri_index(0, j1, k)] : 0.0;
     for (int i = 0; i < k; ++i) {
-      double partial = 0.0;
-      for (int j = lane; j < i; j += 64) partial += cs_s[j] * U[tri_index(j, i, k)];
-      partial = wave_sum_d(partial);
-      if (lane == 0) {
-        const double yr = cg * Yg[slot_of[i]] + wv[i] + partial;
-        cs_s[i] = al[i] - yr / U[tri_index(i, i, k)];
+      const double v0 = v0n, v1 = v1n;
+      v0n = (i + 1 < k && j0 > i + 1 && j0 < k) ? U[tri_index(i + 1, j0, k)] : 0.0;
+      v1n = (i + 1 < k && j1 > i + 1 && j1 < k) ? U[tri_index(i + 1, j1, k)] : 0.0;
+      const int owner = i & 63;
+      const double cand = (i >= 64) ? a1 - (b1 + q1) * rinv1 : a0 - (b0 + q0) * rinv0;
+      const double ci = bcast_lane_d(cand, owner);
+      if (lane == owner) {
+        if (i >= 64) c1 = ci; else c0 = ci;
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0xC07F);
+      q0 = fma(ci, v0, q0);
+      q1 = fma(ci, v1, q1);
     }
+    if (j0 < k) cs_s[j0] = c0;
+    if (j1 < k) cs_s[j1] = c1;
   }
   __syncthreads();
   // ---- publish: coefficients by slot, g.d from the Gram data
@@ -317,33 +403,48 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
 __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const float* __restrict__ S,
                                                        const float* __restrict__ Y, const float* __restrict__ g,
                                                        size_t stride, LbDev* __restrict__ st, float* __restrict__ d) {
-  __shared__ double scy[LB_MAXH], scs[LB_MAXH];
-  __shared__ int sslot[LB_MAXH];
+  __shared__ double scy[LB_MAXH + 8], scs[LB_MAXH + 8];
+  __shared__ int sslot[LB_MAXH + 8];
   const int k = st->count, head = st->head;
-  for (int j = threadIdx.x; j < k; j += 256) {
-    const int sj = (head + j) % cap;
+  for (int j = threadIdx.x; j < LB_MAXH + 8; j += 256) {
+    const bool on = j < k;
+    const int sj = on ? (head + j) % cap : 0;
     sslot[j] = sj;
-    scy[j] = st->cy[sj];
-    scs[j] = st->cs[sj];
+    scy[j] = on ? st->cy[sj] : 0.0;
+    scs[j] = on ? st->cs[sj] : 0.0;
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 2;  // two elements per thread (rows are 8-byte aligned)
   float mx = 0.f;
   if (i < n) {
-    double acc = st->cg * (double)g[i];
-    for (int j = 0; j < k; ++j) {
-      const size_t off = (size_t)sslot[j] * stride + i;
-      acc += scy[j] * (double)Y[off] + scs[j] * (double)S[off];
+    const float2 gv = *reinterpret_cast<const float2*>(g + i);
+    double acc0 = st->cg * (double)gv.x, acc1 = st->cg * (double)gv.y;
+    for (int j0 = 0; j0 < k; j0 += 8) {
+      float2 yv[8], sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
+        const size_t off = (size_t)sslot[j0 + u] * stride + i;
+        yv[u] = *reinterpret_cast<const float2*>(Y + off);
+        sv[u] = *reinterpret_cast<const float2*>(S + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc0 += scy[j0 + u] * (double)yv[u].x + scs[j0 + u] * (double)sv[u].x;
+        acc1 += scy[j0 + u] * (double)yv[u].y + scs[j0 + u] * (double)sv[u].y;
+      }
     }
-    const float di = (float)acc;
-    d[i] = di;
-    mx = fabsf(di);
+    const float d0 = (float)acc0, d1 = (float)acc1;
+    d[i] = d0;
+    mx = fabsf(d0);
+    if (i + 1 < n) {
+      d[i + 1] = d1;
+      mx = fmaxf(mx, fabsf(d1));
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(&st->dmax_bits, __float_as_uint(mx));
 }
-
 
 // -------------------------------------------------------------------------------------------------- objectives
 struct Objective {
@@ -432,9 +533,10 @@ static int lbws_destroy(LbWs* w) {
 static int lbws_create(int n, int hist, LbWs** out) {
   UUO_REQUIRE(hist >= 1 && hist <= LB_MAXH - 4, "lbfgs: history_size must be in [1,100]");
   LbWs* w = new LbWs();
+  n = (n + 255) / 256 * 256;  // row stride: 16-byte loads never straddle rows, padding stays zero
   w->n_cap = n;
   w->cap = hist + 1;
-  w->nchunks = (n + LB_CHUNK - 1) / LB_CHUNK;
+  w->nchunks = LB_MAXCHUNK;
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes);
@@ -450,6 +552,9 @@ static int lbws_create(int n, int hist, LbWs** out) {
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
   if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(w->S, 0, (size_t)w->cap * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(w->Y, 0, (size_t)w->cap * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(w->vecs, 0, (size_t)LB_NVEC * n * sizeof(float));
   if (e != hipSuccess) {
     lbws_destroy(w);
     uuo_set_error(std::string("lbfgs workspace: ") + hipGetErrorString(e));
@@ -505,6 +610,8 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   const double lr = opt->lr, tol_grad = opt->tolerance_grad, tol_change = opt->tolerance_change;
   const double c1 = 1e-4, c2 = 0.9;
   const size_t stride = (size_t)w->n_cap;
+  const int nchunks = std::max(1, std::min(LB_MAXCHUNK, (n + 2047) / 2048));
+  const int chunk_len = (((n + nchunks - 1) / nchunks) + 255) / 256 * 256;
   const int nb = (n + 255) / 256;
   const int nstat = std::min(64, nb);
   auto vec = [&](int i) { return w->vecs + (size_t)i * stride; };
@@ -577,10 +684,10 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         float* y_new = w->Y + (size_t)cand * stride;
         hipLaunchKernelGGL(k_lb_form, dim3(nb), dim3(256), 0, s, n, g, prev_g, d, (float)t, s_new, y_new);
         const int nrows = 2 * (count + 1) + 1;
-        hipLaunchKernelGGL(k_lb_dots, dim3(w->nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand,
-                           w->S, w->Y, g, stride, w->part);
-        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, w->nchunks, cap, hist, cand, w->part, w->st);
-        hipLaunchKernelGGL(k_lb_direction, dim3(nb), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st, d);
+        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand,
+                           w->S, w->Y, g, stride, chunk_len, w->part);
+        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st);
+        hipLaunchKernelGGL(k_lb_direction, dim3((n + 511) / 512), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st, d);
       }
       UUO_HIP_CHECK(hipGetLastError());
       UUO_HIP_CHECK(hipMemcpyAsync(prev_g, g, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -800,7 +907,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   fit->model = model;
   fit->F = F;
   fit->M = M;
-  fit->nFT = (F + 31) / 32;
+  fit->nFT = (F + UUO_FT - 1) / UUO_FT;
   fit->n_max = 219 * F + 10;
   const int nFT = fit->nFT;
   hipError_t e = hipSuccess;
@@ -808,8 +915,8 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
     if (e == hipSuccess) e = hipMalloc(p, bytes);
     if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
   };
-  A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * 32 * sizeof(float));
-  A((void**)&fit->A, (size_t)nFT * 32 * UUO_NUM_JOINTS * 12 * sizeof(float));
+  A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));
+  A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * 16 * sizeof(float));

@@ -8,9 +8,9 @@
 
 #include "../../include/uuo_hip.h"
 
-#define UUO_KP 220        // padded K of the augmented blend GEMM: 207 pose features | 10 betas | 3 zero
+#define UUO_KP 224        // padded K of the augmented blend GEMM: 207 pose features | 10 betas | 7 zero (56 MFMA K-steps)
 #define UUO_KB 208        // padded K of the per-vertex transposed posedirs rows
-#define UUO_FT 32         // frames per MFMA row tile
+#define UUO_FT 16         // frames per MFMA row tile (v_mfma_f32_16x16x4_f32)
 #define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
 
 void uuo_set_error(const std::string& msg);
@@ -50,7 +50,8 @@ struct uuo_model {
   int VP = 0;   // padded to a multiple of 128
   int nnz = 0;  // max non-zero skin weights per vertex (sparse path iff <= 4)
   // device tables
-  float* P3 = nullptr;    // [3][UUO_KP][VP]   coordinate-planar blend basis: posedirs rows then shapedirs rows
+  float* P3 = nullptr;    // [3][VP/16][14][64][4]  blend basis (posedirs rows then shapedirs rows) in MFMA-operand order:
+                          //   per (coord, 16-vertex unit, group of 4 K-steps) one 1-KB block = lane l's 4 B values
   float* vt3 = nullptr;   // [3][VP]           template, coordinate-planar
   float* PT = nullptr;    // [V][3][UUO_KB]    per-vertex posedirs rows (backward / gather-LBS)
   float* ST = nullptr;    // [V][3][10]        shapedirs
@@ -90,8 +91,8 @@ struct uuo_fit {
   int F = 0, M = 0, nFT = 0;
   int n_max = 0;  // 219F+10
   // closure workspace
-  float* pfaT = nullptr;            // [nFT][UUO_KP][32]
-  float* A = nullptr;               // [nFT*32][24][12]
+  float* pfaT = nullptr;            // [nFT][14][64][4]: A operand (pose features | betas) in MFMA-operand order
+  float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][16]: loss, dz, dbeta[10], pad

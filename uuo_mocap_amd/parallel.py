@@ -1,0 +1,67 @@
+"""One process per GPU: sequences are independent in the reference (one multimodal_video_mocap call per sequence
+with its own betas: reference test/test.py:57-112), so a node shards *sequences* over ranks with no data-path
+collective.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used only for the
+timing barrier, the max-over-ranks of the elapsed time and the gather of per-sequence results."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, Dict, List, Sequence
+
+import torch
+
+
+def world_info():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_indices(num_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment of sequence ids to ranks (balanced to within one item)."""
+    return list(range(rank, num_items, world))
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def barrier(device=None):
+    dist = _dist()
+    if dist is not None:
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    dist = _dist()
+    if dist is None:
+        return float(value)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def fit_sharded(sequence_ids: Sequence[int], fit_fn: Callable[[int], Dict], device=None):
+    """Every rank fits its share of `sequence_ids` with `fit_fn(seq_id) -> result`; returns
+    (results gathered on rank 0 as {seq_id: result} else None, elapsed seconds = max over ranks)."""
+    rank, world, _ = world_info()
+    mine = [sequence_ids[i] for i in shard_indices(len(sequence_ids), rank, world)]
+    barrier(device)
+    t0 = time.perf_counter()
+    local = {sid: fit_fn(sid) for sid in mine}
+    barrier(device)
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    dist = _dist()
+    if dist is None:
+        return local, elapsed
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(local, gathered, dst=0)
+    if rank != 0:
+        return None, elapsed
+    merged: Dict = {}
+    for part in gathered:
+        merged.update(part)
+    return merged, elapsed
