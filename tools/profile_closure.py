@@ -44,3 +44,4 @@ print("marker closure: %.1f us/eval" % (1e3 * mprob.time_closure(xm, iters=args.
 if args.solve_iters > 0:
     st = prob.solve(x, max_iter=args.solve_iters, lr=0.1)
     print("solve:", st)
+    print("chamfer closure at the solved point: %.1f us/eval" % (1e3 * prob.time_closure(x, iters=args.evals)))

@@ -514,8 +514,11 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   const uuo_model* m = fit->model;
   int rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr);
   if (rc) return rc;
-  rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts);
+  const bool cull = (p->d_subset == nullptr) && (m->VP / 16) <= 512 && p->M <= 512;
+  rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
   if (rc) return rc;
+  if (cull)  // exact search pruned by per-unit bounding boxes and the previous closure's assignment (kept in fit->nn)
+    return uuo_launch_nn_cull(s, p->F, p->M, m->V, m->VP / 16, p->d_markers, fit->verts, fit->bbox, fit->nn, fit->nn_flags);
   return uuo_launch_nn(s, p->F, p->M, m->V, p->d_markers, fit->verts, p->d_subset, p->n_subset, fit->nn);
 }
 
@@ -614,7 +617,7 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   UUO_HIP_CHECK(hipEventRecord(fit->ev0, s));
   for (int i = 0; i < iters; ++i) {
     if (dominant_only) {
-      rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts);
+      rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
     } else {
       rc = uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr);
     }
@@ -625,5 +628,12 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   float ms = 0.f;
   UUO_HIP_CHECK(hipEventElapsedTime(&ms, fit->ev0, fit->ev1));
   *ms_per_eval = ms / (float)iters;
+  return 0;
+}
+
+// debug/test hook (not in the public header): survivor counts of the last pruned nearest-neighbour search
+extern "C" int uuo_debug_nn_flags(uuo_fit_t* fit, int* h_out) {
+  UUO_REQUIRE(fit && h_out, "uuo_debug_nn_flags: null argument");
+  UUO_HIP_CHECK(hipMemcpy(h_out, fit->nn_flags, (size_t)fit->F * 8 * sizeof(int), hipMemcpyDeviceToHost));
   return 0;
 }

@@ -84,6 +84,152 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Exact K=1 search with pruning (chamfer closure: markers -> all vertices of the frame).
+// One block per frame.  k_skin's epilogue leaves the bounding box of every 16-vertex unit of the frame.  The previous closure's assignment gives, per marker, an upper
+// bound d_ub = |x - v[prev]|^2 and a starting key (d_ub, prev).  Phase A tests every (marker, unit) pair:
+// lb = ((dx*dx)+(dy*dy))+(dz*dz) with dx = max(lo-x, x-hi, 0).  Every fp32 operation involved is monotone and the
+// summation order is that of the vertex distance, so lb <= the computed distance of every vertex in the box; a pair
+// with lb > d_ub can neither improve nor tie the key and is dropped without an epsilon.  Survivors go to an LDS list;
+// phase B evaluates their 16 vertices (16 lanes per entry), reduces (dist bits << 32 | vertex) inside the DPP row
+// and merges with a 64-bit LDS atomicMin: the result equals the brute-force first-index minimum bit for bit.
+// A frame is split over several blocks by marker groups so that several waves share each SIMD.  If a block has too
+// many survivors for its LDS list (poor bounds: first call, markers far from the body) it enumerates all pairs.
+// ----------------------------------------------------------------------------------------------------
+#define CULL_CAP 4096
+#define CULL_MG 64
+#define CULL_MAXU 512
+#define CULL_UB 4
+#define CULL_MAXG 8
+__global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int mper, const float* __restrict__ x,
+                                                  const float* __restrict__ verts, const float* __restrict__ bbox,
+                                                  unsigned long long* __restrict__ packed, int* __restrict__ stats) {
+  __shared__ float sbox[CULL_MAXU * 6];
+  __shared__ float smx[CULL_MG * 3];
+  __shared__ float sub[CULL_MG];
+  __shared__ unsigned long long skey[CULL_MG];
+  __shared__ unsigned slist[CULL_CAP];
+  __shared__ unsigned scount;
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.y * mper;
+  const int mg = min(mper, M - m0);
+  if (mg <= 0) return;
+  const float* vf = verts + (size_t)f * V * 3;
+  {  // unit bounding boxes of this frame (written by k_skin's epilogue) -> LDS
+    const float* bf = bbox + (size_t)f * nunits * 6;
+    for (int i = tid; i < nunits * 6; i += 256) sbox[i] = bf[i];
+  }
+  if (tid < mg) {
+    const float* px = x + ((size_t)f * M + m0 + tid) * 3;
+    const float qx = px[0], qy = px[1], qz = px[2];
+    smx[tid * 3] = qx;
+    smx[tid * 3 + 1] = qy;
+    smx[tid * 3 + 2] = qz;
+    unsigned prev = (unsigned)(packed[(size_t)f * M + m0 + tid] & 0xFFFFFFFFull);  // previous closure's assignment
+    if (prev >= (unsigned)V) prev = 0;
+    const float* pv = vf + (size_t)prev * 3;
+    const unsigned long long key = pack_key(sqdist(qx, qy, qz, pv[0], pv[1], pv[2]), prev);
+    skey[tid] = key;
+    sub[tid] = __uint_as_float((unsigned)(key >> 32));
+  }
+  if (tid == 0) scount = 0u;
+  __syncthreads();
+  // ---- phase A: thread = unit (box in registers); the marker loop only sets bits of a survivor mask (no branch,
+  // no atomic on the loop path), then one LDS atomicAdd per thread reserves the list slots
+  for (int u = tid; u < nunits; u += 256) {
+    const float* b = sbox + u * 6;
+    const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+    unsigned long long mask = 0ull;
+#pragma unroll 4
+    for (int m = 0; m < mg; ++m) {
+      const float qx = smx[m * 3], qy = smx[m * 3 + 1], qz = smx[m * 3 + 2];
+      const float dx = fmaxf(fmaxf(__fsub_rn(b0, qx), __fsub_rn(qx, b3)), 0.f);
+      const float dy = fmaxf(fmaxf(__fsub_rn(b1, qy), __fsub_rn(qy, b4)), 0.f);
+      const float dz = fmaxf(fmaxf(__fsub_rn(b2, qz), __fsub_rn(qz, b5)), 0.f);
+      const float lb = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      mask |= (lb <= sub[m]) ? (1ull << m) : 0ull;
+    }
+    const int cnt = __popcll(mask);
+    if (cnt) {
+      unsigned pos = atomicAdd(&scount, (unsigned)cnt);
+      while (mask) {
+        const int m = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        if (pos < CULL_CAP) slist[pos] = ((unsigned)m << 16) | (unsigned)u;
+        ++pos;
+      }
+    }
+  }
+  __syncthreads();
+  const int found = (int)scount;
+  const bool overflow = found > CULL_CAP;  // poor bounds (first call, markers far from the body): enumerate all pairs
+  const int nent = overflow ? nunits * mg : found;
+  // ---- phase B: 16 lanes per (marker, unit) pair, 4 pairs per wave pass, CULL_UB passes in flight
+  // (the vertex gathers are L2 round trips: issue them for several passes before the first is consumed)
+  for (int e0 = wave * 4; e0 < nent; e0 += 16 * CULL_UB) {
+    unsigned long long key[CULL_UB];
+    int mm[CULL_UB];
+    float vx[CULL_UB], vy[CULL_UB], vz[CULL_UB];
+    int vid[CULL_UB];
+#pragma unroll
+    for (int r = 0; r < CULL_UB; ++r) {
+      const int e = e0 + 16 * r + (lane >> 4);
+      mm[r] = 0;
+      vid[r] = -1;
+      vx[r] = vy[r] = vz[r] = 0.f;
+      if (e < nent) {
+        int u;
+        if (overflow) {
+          u = e / mg;
+          mm[r] = e - u * mg;
+        } else {
+          const unsigned ent = slist[e];
+          mm[r] = (int)(ent >> 16);
+          u = (int)(ent & 0xFFFFu);
+        }
+        const int vtx = u * 16 + (lane & 15);
+        if (vtx < V) {
+          const float* pv = vf + (size_t)vtx * 3;
+          vx[r] = pv[0];
+          vy[r] = pv[1];
+          vz[r] = pv[2];
+          vid[r] = vtx;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CULL_UB; ++r) {
+      const int m = mm[r];
+      key[r] = (vid[r] >= 0)
+                   ? pack_key(sqdist(smx[m * 3], smx[m * 3 + 1], smx[m * 3 + 2], vx[r], vy[r], vz[r]), (unsigned)vid[r])
+                   : ~0ull;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key[r], off, 16);
+        key[r] = o < key[r] ? o : key[r];
+      }
+      if ((lane & 15) == 0 && key[r] != ~0ull) atomicMin(&skey[m], key[r]);
+    }
+  }
+  __syncthreads();
+  if (tid < mg) packed[(size_t)f * M + m0 + tid] = skey[tid];
+  if (tid == 0 && stats) stats[f * CULL_MAXG + blockIdx.y] = overflow ? -found : found;
+}
+
+int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
+                       const float* bbox, unsigned long long* packed, int* stats) {
+  if (F <= 0 || M <= 0) return 0;
+  UUO_REQUIRE(nunits <= CULL_MAXU, "uuo_launch_nn_cull: too many vertex units for the LDS box table");
+  // marker groups per frame: enough blocks (>= ~1024) that several waves share a SIMD, at most 64 markers per group
+  int G = (M + CULL_MG - 1) / CULL_MG;
+  while (G < CULL_MAXG && (long)F * G < 1024 && (M + G) / (G + 1) >= 8) ++G;
+  const int mper = (M + G - 1) / G;
+  UUO_REQUIRE(mper <= CULL_MG && G <= CULL_MAXG, "uuo_launch_nn_cull: too many markers per frame for the pruned search");
+  hipLaunchKernelGGL(k_nn_cull, dim3(F, G), dim3(256), 0, s, M, V, nunits, mper, markers, verts, bbox, packed, stats);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 __global__ void k_nn_unpack(int count, const unsigned long long* __restrict__ packed, float* __restrict__ dist,
                             int32_t* __restrict__ idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

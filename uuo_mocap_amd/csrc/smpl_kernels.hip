@@ -63,6 +63,25 @@ int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPose
 // width: dword loads made the kernel TA-bound); the A tile uses the same order in LDS (ds_read_b128).  Block ids are remapped so that all frame tiles of one vertex range share an XCD's L2.
 // ----------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define UUO_BIG 3.0e38f
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {  // lanes without a source keep their own value
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_min(float v) {  // row_ror:8,4,2,1 -> reduction over the 16 lanes of a row
+  v = fminf(v, dpp_row<0x128>(v));
+  v = fminf(v, dpp_row<0x124>(v));
+  v = fminf(v, dpp_row<0x122>(v));
+  return fminf(v, dpp_row<0x121>(v));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_row<0x128>(v));
+  v = fmaxf(v, dpp_row<0x124>(v));
+  v = fmaxf(v, dpp_row<0x122>(v));
+  return fmaxf(v, dpp_row<0x121>(v));
+}
+#define UUO_BIG 3.0e38f
 #define SKIN_WAVES 8
 #define SKIN_GROUPS (UUO_KP / 16)  // 14 groups of 4 K-steps (one dwordx4 per lane per coordinate each)
 #define SKIN_CG 2                  // groups per register buffer  -> 7 chunks, 24 MFMAs each
@@ -73,8 +92,8 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
                                                            const int* __restrict__ Wi, const float* __restrict__ Ww,
                                                            const float* __restrict__ Wd, const float* __restrict__ pfaT,
                                                            const float* __restrict__ A, const float* __restrict__ trans,
-                                                           float* __restrict__ verts, int F, int V, int VP, int nFT,
-                                                           int nVB, int nblocks) {
+                                                           float* __restrict__ verts, float* __restrict__ bbox, int F,
+                                                           int V, int VP, int nFT, int nVB, int nblocks) {
   __shared__ float sA[UUO_KP * UUO_FT];                    // [k][i]
   __shared__ float sT[UUO_FT * UUO_NUM_JOINTS * 12];       // [i][j][12]
   const int b = blockIdx.x;
@@ -225,18 +244,31 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
       float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
       float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
       float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+      if (trans && f < F) {
+        ox += trans[(size_t)f * 3 + 0];
+        oy += trans[(size_t)f * 3 + 1];
+        oz += trans[(size_t)f * 3 + 2];
+      }
       if (VAR == 3) {
         asm volatile("" ::"v"(ox), "v"(oy), "v"(oz));
       } else if (vok && f < F) {
-        if (trans) {
-          ox += trans[(size_t)f * 3 + 0];
-          oy += trans[(size_t)f * 3 + 1];
-          oz += trans[(size_t)f * 3 + 2];
-        }
         float* po = verts + ((size_t)f * V + v) * 3;
         po[0] = ox;
         po[1] = oy;
         po[2] = oz;
+      }
+      if (bbox) {
+        // bounding box of the unit's 16 vertices in frame f: they sit on the 16 lanes of one DPP row, so four
+        // row-rotate steps (v_min/v_max with a DPP operand, no LDS traffic) leave the box on every lane
+        const float lx = row16_min(vok ? ox : UUO_BIG), ly = row16_min(vok ? oy : UUO_BIG),
+                    lz = row16_min(vok ? oz : UUO_BIG);
+        const float hx = row16_max(vok ? ox : -UUO_BIG), hy = row16_max(vok ? oy : -UUO_BIG),
+                    hz = row16_max(vok ? oz : -UUO_BIG);
+        if (j == 0 && f < F) {
+          float* pbx = bbox + ((size_t)f * nunits + u) * 6;
+          pbx[0] = lx; pbx[1] = ly; pbx[2] = lz;
+          pbx[3] = hx; pbx[4] = hy; pbx[5] = hz;
+        }
       }
     }
   }
@@ -246,11 +278,12 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
 }
 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
-                    float* verts) {
+                    float* verts, float* bbox) {
   const int nFT = (F + UUO_FT - 1) / UUO_FT;
   const int nunits = m->VP / 16;
   // vertex ranges per frame tile: one resident round of <= 256 blocks, every wave gets at least one unit
-  int nVB = 256 / nFT;
+  static const int slots = getenv("UUO_SKIN_SLOTS") ? atoi(getenv("UUO_SKIN_SLOTS")) : 256;
+  int nVB = slots / nFT;
   const int maxVB = (nunits + SKIN_WAVES - 1) / SKIN_WAVES;
   if (nVB > maxVB) nVB = maxVB;
   if (nVB < 1) nVB = 1;
@@ -258,7 +291,7 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
   static const int variant = getenv("UUO_SKIN_VARIANT") ? atoi(getenv("UUO_SKIN_VARIANT")) : 0;  // ablation only
 #define SKIN_LAUNCH(SP, VAR)                                                                                     \
   hipLaunchKernelGGL((k_skin<SP, VAR>), dim3(nblocks), dim3(SKIN_WAVES * 64), 0, s, m->P3, m->vt3, m->Wi, m->Ww, \
-                     m->W, pfaT, A, trans, verts, F, m->V, m->VP, nFT, nVB, nblocks)
+                     m->W, pfaT, A, trans, verts, bbox, F, m->V, m->VP, nFT, nVB, nblocks)
   if (m->nnz > 4) SKIN_LAUNCH(false, 0);
   else if (variant == 1) SKIN_LAUNCH(true, 1);
   else if (variant == 2) SKIN_LAUNCH(true, 2);
@@ -335,7 +368,7 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   src.trans = d_trans;
   int rc = uuo_launch_pose_prep(m, s, F, src, sc.pfaT, sc.A, sc.jp);
   if (rc) return rc;
-  rc = uuo_launch_skin(m, s, F, sc.pfaT, sc.A, d_trans, d_verts);
+  rc = uuo_launch_skin(m, s, F, sc.pfaT, sc.A, d_trans, d_verts, nullptr);
   if (rc) return rc;
   if (d_joints) rc = uuo_launch_joints45(m, s, F, sc.jp, d_verts, d_joints);
   return rc;

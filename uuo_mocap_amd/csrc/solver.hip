@@ -918,6 +918,8 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));
   A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
+  A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
+  A((void**)&fit->bbox, (size_t)F * (model->VP / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * 16 * sizeof(float));
   A((void**)&fit->mask, (size_t)F * M * sizeof(float));
@@ -936,7 +938,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
 
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
-  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn, fit->frame_part, fit->mask, fit->scalars, fit->vecs};
+  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->mask, fit->scalars, fit->vecs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);

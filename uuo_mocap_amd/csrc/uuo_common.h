@@ -94,6 +94,8 @@ struct uuo_fit {
   float* pfaT = nullptr;            // [nFT][14][64][4]: A operand (pose features | betas) in MFMA-operand order
   float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
+  float* bbox = nullptr;            // [F][VP/16][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
+  int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][16]: loss, dz, dbeta[10], pad
   float* mask = nullptr;            // [F][M] 0/1
@@ -108,7 +110,9 @@ struct uuo_fit {
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
                          float* joints_posed);
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
-                    const float* trans, float* verts);
+                    const float* trans, float* verts, float* bbox);
+int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
+                       const float* bbox, unsigned long long* packed, int* flags);
 int uuo_launch_joints45(const uuo_model* m, hipStream_t s, int F, const float* joints_posed, const float* verts,
                         float* joints45);
 int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub,
