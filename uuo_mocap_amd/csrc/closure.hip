@@ -35,7 +35,10 @@ struct BwdArgs {
   float* g_root;
   float* g_z;
   float* g_trans;
-  float* frame_part;  // [F][16]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta
+  const float* dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
+  int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat vector (-1 = absent)
+  float* frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
+                      //              16 g.d, 17 sum|g|, 18 g.g, 19 max|g| over this frame's gradient entries
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   __shared__ float red[16];
   __shared__ float sdGR[UUO_NUM_JOINTS][9], sdGt[UUO_NUM_JOINTS][3], sdJ[UUO_NUM_JOINTS][3], sdR[UUO_NUM_JOINTS][9];
   __shared__ float spsq[UUO_NUM_JOINTS];
+  __shared__ float sstat[28][4];  // per writer: g.d, sum|g|, g.g, max|g| (0..22 body joints, 23 root/z, 24..26 transl)
 
   const int f = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     spf[tid] = v;
   }
   for (int i = tid; i < BWD_NW * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
+  if (tid < 28 * 4) (&sstat[0][0])[tid] = 0.f;
   __syncthreads();
 
   float tr[3] = {0.f, 0.f, 0.f};
@@ -84,6 +89,24 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   }
   float acc_dpf[4] = {0.f, 0.f, 0.f, 0.f};
   float acc_db = 0.f, acc_dt = 0.f, acc_loss = 0.f;
+  // direction entries this thread will need for the fused g.d (fetched now, consumed after the item loop)
+  float dpre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.dir) {
+    if (tid >= 1 && tid < UUO_NUM_JOINTS && a.off_pose >= 0) {
+      const float* pd = a.dir + a.off_pose + ((size_t)f * 23 + (tid - 1)) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) dpre[e] = pd[e];
+    } else if (tid == 0) {
+      if (a.stage == UUO_STAGE_CHAMFER) dpre[0] = a.dir[a.off_z + f];
+      if (a.stage == UUO_STAGE_MARKER) {
+        const float* pd = a.dir + a.off_root + (size_t)f * 9;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) dpre[e] = pd[e];
+      }
+    } else if (tid >= 32 && tid < 35) {
+      dpre[0] = a.dir[a.off_trans + (size_t)f * 3 + (tid - 32)];
+    }
+  }
 
   for (int m = wave; m < M; m += BWD_NW) {
     float wgt = 1.f, d2 = 0.f;
@@ -296,7 +319,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc = fmaf(tree->JS[jj][c][tid], sdJ[jj][c], acc);
-    a.frame_part[(size_t)f * 16 + 4 + tid] = acc;
+    a.frame_part[(size_t)f * UUO_FP + 4 + tid] = acc;
   }
   // body rotations
   if (j >= 1 && j < UUO_NUM_JOINTS) {
@@ -329,8 +352,16 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
         }
       }
       float* pg = a.g_pose + ((size_t)f * 23 + (j - 1)) * 9;
+      float sd = 0.f, s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 9; ++e) pg[e] = gout[e];
+      for (int e = 0; e < 9; ++e) {
+        pg[e] = gout[e];
+        sd = fmaf(gout[e], dpre[e], sd);
+        s1 += fabsf(gout[e]);
+        s2 = fmaf(gout[e], gout[e], s2);
+        sm = fmaxf(sm, fabsf(gout[e]));
+      }
+      sstat[j - 1][0] = sd; sstat[j - 1][1] = s1; sstat[j - 1][2] = s2; sstat[j - 1][3] = sm;
     }
     spsq[j] = psq;
   }
@@ -349,13 +380,23 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
         dzv = fmaf(da[3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
       }
       a.g_z[f] = dzv;
+      sstat[23][0] = dzv * dpre[0];
+      sstat[23][1] = fabsf(dzv); sstat[23][2] = dzv * dzv; sstat[23][3] = fabsf(dzv);
     } else if (a.stage == UUO_STAGE_MARKER) {
       float da[6];
       gs6d_backward(a.raw_root + (size_t)f * 9, sdR[0], da);
       float* pg = a.g_root + (size_t)f * 9;
+      float sd = 0.f, s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 6; ++e) pg[e] = da[e];
+      for (int e = 0; e < 6; ++e) {
+        pg[e] = da[e];
+        sd = fmaf(da[e], dpre[e], sd);
+        s1 += fabsf(da[e]);
+        s2 = fmaf(da[e], da[e], s2);
+        sm = fmaxf(sm, fabsf(da[e]));
+      }
       pg[6] = pg[7] = pg[8] = 0.f;
+      sstat[23][0] = sd; sstat[23][1] = s1; sstat[23][2] = s2; sstat[23][3] = sm;
     } else {
       const float* r0 = a.src.root + (size_t)f * 9;
       float dzv = 0.f;
@@ -364,17 +405,32 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
         dzv = fmaf(sdR[0][c], (-sz * r0[c] - cz * r0[3 + c]), dzv);
         dzv = fmaf(sdR[0][3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
       }
-      a.frame_part[(size_t)f * 16 + 1] = dzv;
+      a.frame_part[(size_t)f * UUO_FP + 1] = dzv;
     }
   }
-  if (tid < 3 && a.g_trans) a.g_trans[(size_t)f * 3 + tid] = red[1 + tid];
+  if (tid >= 32 && tid < 35 && a.g_trans) {
+    const int c = tid - 32;
+    const float gt = red[1 + c];
+    a.g_trans[(size_t)f * 3 + c] = gt;
+    sstat[24 + c][0] = gt * dpre[0];
+    sstat[24 + c][1] = fabsf(gt); sstat[24 + c][2] = gt * gt; sstat[24 + c][3] = fabsf(gt);
+  }
   __syncthreads();
+  if (tid < 4) {  // fixed-order sum of the writers' statistics
+    float acc = 0.f;
+    if (tid < 3) {
+      for (int w = 0; w < 27; ++w) acc += sstat[w][tid];
+    } else {
+      for (int w = 0; w < 27; ++w) acc = fmaxf(acc, sstat[w][3]);
+    }
+    a.frame_part[(size_t)f * UUO_FP + 16 + tid] = acc;
+  }
   if (tid == 0) {
     float ps = 0.f;
     for (int jj = 1; jj < UUO_NUM_JOINTS; ++jj) ps += spsq[jj];
-    a.frame_part[(size_t)f * 16 + 0] = red[0];
-    a.frame_part[(size_t)f * 16 + 2] = ps;
-    if (a.stage != UUO_STAGE_PART) a.frame_part[(size_t)f * 16 + 1] = 0.f;
+    a.frame_part[(size_t)f * UUO_FP + 0] = red[0];
+    a.frame_part[(size_t)f * UUO_FP + 2] = ps;
+    if (a.stage != UUO_STAGE_PART) a.frame_part[(size_t)f * UUO_FP + 1] = 0.f;
   }
 }
 
@@ -393,35 +449,70 @@ struct FinArgs {
   float* g_betas;
   float* g_z;  // part stage
   float* loss;
+  const float* dir_betas;  // optional direction entries of the shared parameters
+  const float* dir_z;
+  double* stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
 };
 
-__global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
-  __shared__ double sh[16][16];
+__global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
+  __shared__ double sh[32][32];
   const int tid = threadIdx.x;
-  const int comp = tid & 15, grp = tid >> 4;  // 16 groups of frames
+  const int comp = tid & 31, grp = tid >> 5;  // 32 groups of frames, components 0..UUO_FP-1
   double acc = 0.0;
-  for (int f = grp; f < a.F; f += 16) acc += (double)a.frame_part[(size_t)f * 16 + comp];
+  if (comp < UUO_FP) {
+    const bool is_max = (comp == 19);
+    for (int f0 = grp; f0 < a.F; f0 += 32 * 8) {  // 8 independent loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + 32 * u;
+        v[u] = (f < a.F) ? a.frame_part[(size_t)f * UUO_FP + comp] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = is_max ? fmax(acc, (double)v[u]) : acc + (double)v[u];
+    }
+  }
   sh[grp][comp] = acc;
   __syncthreads();
-  if (tid < 16) {
+  if (tid < 32) {
     double s = 0.0;
-    for (int g = 0; g < 16; ++g) s += sh[g][tid];
+    if (tid == 19) {
+      for (int g = 0; g < 32; ++g) s = fmax(s, sh[g][tid]);
+    } else {
+      for (int g = 0; g < 32; ++g) s += sh[g][tid];
+    }
     sh[0][tid] = s;
   }
   __syncthreads();
-  if (tid < 10) {
-    const double diff = (double)a.betas[tid] - (double)a.o_betas[tid];
-    a.g_betas[tid] = (float)(sh[0][4 + tid] + 2.0 * a.cbetas * diff);
-  }
   if (tid == 0) {
-    double bsq = 0.0;
+    double bsq = 0.0, sd = sh[0][16], s1 = sh[0][17], s2 = sh[0][18], sm = sh[0][19];
     for (int l = 0; l < 10; ++l) {
       const double diff = (double)a.betas[l] - (double)a.o_betas[l];
       bsq += diff * diff;
+      const float gb = (float)(sh[0][4 + l] + 2.0 * a.cbetas * diff);
+      a.g_betas[l] = gb;
+      if (a.dir_betas) sd += (double)gb * (double)a.dir_betas[l];
+      s1 += fabs((double)gb);
+      s2 += (double)gb * (double)gb;
+      sm = fmax(sm, fabs((double)gb));
     }
-    const double loss = a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq;
-    a.loss[0] = (float)loss;
-    if (a.stage == UUO_STAGE_PART) a.g_z[0] = (float)sh[0][1];
+    const float lossf = (float)(a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq);
+    a.loss[0] = lossf;
+    if (a.stage == UUO_STAGE_PART) {
+      const float gz = (float)sh[0][1];
+      a.g_z[0] = gz;
+      if (a.dir_z) sd += (double)gz * (double)a.dir_z[0];
+      s1 += fabs((double)gz);
+      s2 += (double)gz * (double)gz;
+      sm = fmax(sm, fabs((double)gz));
+    }
+    if (a.stats) {
+      a.stats[0] = (double)lossf;
+      a.stats[1] = sd;
+      a.stats[2] = sm;
+      a.stats[3] = s1;
+      a.stats[4] = s2;
+    }
   }
 }
 
@@ -526,7 +617,7 @@ int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return va
 
 // closure evaluation proper; the marker mask must be current (uuo_ensure_mask)
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
-                          float* d_grad, int32_t* d_nn_idx) {
+                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats) {
   int rc = 0;
   const uuo_model* m = fit->model;
   const int F = p->F, M = p->M;
@@ -566,6 +657,8 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + lay.off_z : nullptr;
   a.g_trans = d_grad + lay.off_trans;
   a.frame_part = fit->frame_part;
+  a.dir = d_dir;
+  a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
   if (m->nnz <= 4)
     hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   else
@@ -583,7 +676,10 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   fa.g_betas = d_grad + lay.off_betas;
   fa.g_z = (p->stage == UUO_STAGE_PART) ? d_grad + lay.off_z : nullptr;
   fa.loss = d_loss;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, fa);
+  fa.dir_betas = d_dir ? d_dir + lay.off_betas : nullptr;
+  fa.dir_z = (d_dir && p->stage == UUO_STAGE_PART) ? d_dir + lay.off_z : nullptr;
+  fa.stats = d_stats;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -596,7 +692,7 @@ extern "C" int uuo_closure_eval(uuo_fit_t* fit, void* stream, const uuo_problem_
   hipStream_t s = (hipStream_t)stream;
   rc = uuo_ensure_mask(fit, s, p);
   if (rc) return rc;
-  return uuo_closure_eval_impl(fit, s, p, d_x, d_loss, d_grad, d_nn_idx);
+  return uuo_closure_eval_impl(fit, s, p, d_x, d_loss, d_grad, d_nn_idx, nullptr, nullptr);
 }
 
 extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, int iters,
@@ -612,14 +708,14 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   if (rc) return rc;
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
   // warm-up
-  rc = dominant_only ? closure_forward(fit, s, p, src) : uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr);
+  rc = dominant_only ? closure_forward(fit, s, p, src) : uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr, nullptr, nullptr);
   if (rc) return rc;
   UUO_HIP_CHECK(hipEventRecord(fit->ev0, s));
   for (int i = 0; i < iters; ++i) {
     if (dominant_only) {
       rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
     } else {
-      rc = uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr);
+      rc = uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr, nullptr, nullptr);
     }
     if (rc) return rc;
   }

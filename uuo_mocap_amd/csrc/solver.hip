@@ -8,6 +8,7 @@
 //  * dot products accumulate in fp64, line-search scalars are fp64 on the host,
 //  * one small read-back per closure evaluation is the only host synchronisation.
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -47,9 +48,15 @@ __global__ void k_lb_init(LbDev* st) {
 }
 
 // ---------------------------------------------------------------------------------------------------- kernels
-__global__ void k_lb_neg(int n, const float* __restrict__ g, float* __restrict__ d) {
+// first iteration: d = -g and the first trial point x + t d in one pass
+__global__ void k_lb_neg(int n, const float* __restrict__ g, float* __restrict__ d, const float* __restrict__ x,
+                         float t, float* __restrict__ xt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i] = -g[i];
+  if (i < n) {
+    const float di = -g[i];
+    d[i] = di;
+    xt[i] = x[i] + t * di;
+  }
 }
 
 __global__ void k_lb_axpy(int n, const float* __restrict__ x, float t, const float* __restrict__ d,
@@ -151,10 +158,13 @@ __device__ __forceinline__ const float* lb_row_ptr(int row, int nact, int count,
   return g;
 }
 
-__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int count, int cand,
-                                                  const float* __restrict__ S, const float* __restrict__ Y,
-                                                  const float* __restrict__ g, size_t stride, int chunk_len,
+__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int count, int cand, float* __restrict__ S,
+                                                  float* __restrict__ Y, const float* __restrict__ g,
+                                                  const float* __restrict__ gp, const float* __restrict__ d, float t,
+                                                  size_t stride, int chunk_len,
                                                   double* __restrict__ part /* [chunks][LB_ROWS][3] */) {
+  // The new pair y = g - g_prev, s = t d is formed on the fly (and stored to the candidate slot by the first row
+  // group), so no separate pass writes it before the dots.
   const int chunk = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nact = count + 1;  // active slots incl. the candidate
@@ -165,17 +175,27 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
   int out0, out1 = 0;
   const float* src0 = lb_row_ptr(row0, nact, count, head, cap, cand, S, Y, g, stride, &out0);
   const float* src1 = two ? lb_row_ptr(row0 + 1, nact, count, head, cap, cand, S, Y, g, stride, &out1) : src0;
-  const float* yn = Y + (size_t)cand * stride;
-  const float* sn = S + (size_t)cand * stride;
+  // rows that ARE the candidate (not yet in memory): 1 = s_new, 2 = y_new
+  const int c0 = (out0 == cand) ? 1 : (out0 == LB_MAXH + cand ? 2 : 0);
+  const int c1 = (out1 == cand) ? 1 : (out1 == LB_MAXH + cand ? 2 : 0);
+  float* yn = Y + (size_t)cand * stride;
+  float* sn = S + (size_t)cand * stride;
+  const bool writer = (blockIdx.y == 0 && wave == 0);
   const int e0 = chunk * chunk_len;
   const int e1 = min((int)stride, e0 + chunk_len);  // chunk_len is a multiple of 256; padding beyond n is zero
   double a00 = 0.0, a01 = 0.0, a02 = 0.0, a10 = 0.0, a11 = 0.0, a12 = 0.0;
   for (int i = e0 + lane * 4; i < e1; i += 256) {
-    const float4 vy = *reinterpret_cast<const float4*>(yn + i);
-    const float4 vs = *reinterpret_cast<const float4*>(sn + i);
     const float4 vg = *reinterpret_cast<const float4*>(g + i);
-    const float4 r0 = *reinterpret_cast<const float4*>(src0 + i);
-    const float4 r1 = *reinterpret_cast<const float4*>(src1 + i);
+    const float4 vp = *reinterpret_cast<const float4*>(gp + i);
+    const float4 vd = *reinterpret_cast<const float4*>(d + i);
+    const float4 vy = make_float4(vg.x - vp.x, vg.y - vp.y, vg.z - vp.z, vg.w - vp.w);
+    const float4 vs = make_float4(vd.x * t, vd.y * t, vd.z * t, vd.w * t);
+    if (writer) {
+      *reinterpret_cast<float4*>(yn + i) = vy;
+      *reinterpret_cast<float4*>(sn + i) = vs;
+    }
+    const float4 r0 = c0 == 1 ? vs : (c0 == 2 ? vy : *reinterpret_cast<const float4*>(src0 + i));
+    const float4 r1 = c1 == 1 ? vs : (c1 == 2 ? vy : *reinterpret_cast<const float4*>(src1 + i));
 #define LB_ACC(c)                                   \
     a00 += (double)r0.c * (double)vy.c;             \
     a01 += (double)r0.c * (double)vs.c;             \
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
 // instead of an L2 round trip; YY cy has no dependency chain and is a parallel mat-vec over all 256 threads.
 #define LB_TRI (LB_MAXH * (LB_MAXH + 1) / 2)
 #define LB_RB 8  // Gram rows fetched per wave pass
+#define LB_YR ((LB_MAXH + 2) / 3)  // rows of Y.Y^T per helper wave
 __device__ __forceinline__ double bcast_lane_d(double v, int src_lane) {  // src_lane must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -218,11 +239,12 @@ __device__ __forceinline__ int tri_index(int i, int j, int k) {  // j >= i, row-
 }
 
 __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist, int cand,
-                                                   const double* __restrict__ part, LbDev* __restrict__ st) {
+                                                   const double* __restrict__ part, LbDev* __restrict__ st, int stop) {
   __shared__ double U[LB_TRI];
   __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH];
   __shared__ double rd[LB_ROWS * 3];
   __shared__ int slot_of[LB_MAXH];
+  __shared__ double wpart[3][LB_MAXH + 24];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int head = st->head, count = st->count;
   const int nact = count + 1;
@@ -272,6 +294,7 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
   const int k = count;
   for (int j = tid; j < k; j += 256) slot_of[j] = (head + j) % cap;
   __syncthreads();
+  if (stop == 1) return;
   // ---- stage U in LDS (logical order)
   for (int i0 = wave * LB_RB; i0 < k; i0 += 4 * LB_RB) {  // LB_RB rows per wave pass, all loads in flight at once
     double v[LB_RB][2];
@@ -295,80 +318,138 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
     }
   }
   __syncthreads();
-  // Both recurrences run "right-looking" on wave 0: logical index j lives on lane j & 63 (two per lane), every
-  // lane keeps the running sum of its own rows, the lane that owns step i finishes it and broadcasts the value
-  // with v_readlane -- no wave-wide reduction and no division on the dependent chain.
+  if (stop == 2) return;
+  // Both recurrences are blocked (16 x 16) right-looking triangular solves on wave 0.  Logical index j lives on
+  // lane j & 63 (two rows per lane: j0 = lane, j1 = lane + 64).  Inside a diagonal block the owning lane finishes
+  // step i and broadcasts the value with v_readlane while the block's entries of U sit in registers; the update of
+  // the rows outside the block is a 16-term FMA per lane whose LDS reads are issued together.  So the dependent
+  // chain never waits on LDS (one LDS latency per block of 16 steps instead of one per step).
+  // Meanwhile waves 1..3 fetch their rows of Y.Y^T into registers for the mat-vec between the two loops.
   double rinv0 = 0.0, rinv1 = 0.0, a0 = 0.0, a1 = 0.0;
-  if (wave == 0) {
-    const int j0 = lane, j1 = lane + 64;
+  const int j0 = lane, j1 = lane + 64;
+  const int nblk = (k + 15) >> 4;
+  double yv0[LB_YR], yv1[LB_YR];  // waves 1..3: rows i = (wave-1) + 3 r of YY, columns j0 / j1
+  if (wave > 0) {
+    const int sl0 = (j0 < k) ? slot_of[j0] : 0, sl1 = (j1 < k) ? slot_of[j1] : 0;
+#pragma unroll
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 1) + 3 * r;
+      const int si = (i < k) ? slot_of[i] : 0;
+      yv0[r] = (i < k && j0 < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
+      yv1[r] = (i < k && j1 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
+    }
+  } else {
     if (j0 < k) rinv0 = 1.0 / U[tri_index(j0, j0, k)];
     if (j1 < k) rinv1 = 1.0 / U[tri_index(j1, j1, k)];
     const double sg0 = (j0 < k) ? Sg[slot_of[j0]] : 0.0, sg1 = (j1 < k) ? Sg[slot_of[j1]] : 0.0;
     double r0 = 0.0, r1 = 0.0;
     // ---- loop 1 (newest -> oldest):  al_i = (-s_i.g - sum_{m>i} al_m U_im) / U_ii
-    // software-pipelined: the U entries of step i-1 are fetched from LDS before step i's dependent arithmetic
-    double u0n = (k > 0 && j0 < k - 1) ? U[tri_index(j0, k - 1, k)] : 0.0;
-    double u1n = (k > 0 && j1 < k - 1) ? U[tri_index(j1, k - 1, k)] : 0.0;
-    for (int i = k - 1; i >= 0; --i) {
-      const double u0 = u0n, u1 = u1n;
-      u0n = (i > 0 && j0 < i - 1) ? U[tri_index(j0, i - 1, k)] : 0.0;
-      u1n = (i > 0 && j1 < i - 1) ? U[tri_index(j1, i - 1, k)] : 0.0;
-      const int owner = i & 63;
-      const double cand = (i >= 64) ? (-sg1 - r1) * rinv1 : (-sg0 - r0) * rinv0;
-      const double ai = bcast_lane_d(cand, owner);
-      if (lane == owner) {
-        if (i >= 64) a1 = ai; else a0 = ai;
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int lo = b << 4, hi = min(lo + 16, k);
+      const bool inhi = lo >= 64;
+      const int jr = inhi ? j1 : j0;  // this lane's row in the set that contains the block
+      double ublk[16], ablk[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = lo + t;
+        ublk[t] = (jr >= lo && jr < i && i < hi) ? U[tri_index(jr, i, k)] : 0.0;
       }
-      r0 = fma(ai, u0, r0);
-      r1 = fma(ai, u1, r1);
+#pragma unroll
+      for (int t = 15; t >= 0; --t) {
+        const int i = lo + t;
+        ablk[t] = 0.0;
+        if (i < hi) {  // wave-uniform
+          const double cand = inhi ? (-sg1 - r1) * rinv1 : (-sg0 - r0) * rinv0;
+          const double ai = bcast_lane_d(cand, i & 63);
+          ablk[t] = ai;
+          if (lane == (i & 63)) {
+            if (inhi) a1 = ai; else a0 = ai;
+          }
+          if (inhi) r1 = fma(ai, ublk[t], r1); else r0 = fma(ai, ublk[t], r0);
+        }
+      }
+      // rows above the block
+      if (lo > 0) {
+        double un[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) un[t] = (j0 < lo && lo + t < hi) ? U[tri_index(j0, lo + t, k)] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) r0 = fma(ablk[t], un[t], r0);
+        if (lo > 64) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) un[t] = (j1 < lo && lo + t < hi) ? U[tri_index(j1, lo + t, k)] : 0.0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) r1 = fma(ablk[t], un[t], r1);
+        }
+      }
     }
     if (j0 < k) al[j0] = a0;
     if (j1 < k) al[j1] = a1;
   }
   __syncthreads();
+  if (stop == 3) return;
   const double cg = -Hdiag;
   for (int j = tid; j < k; j += 256) cy_s[j] = -Hdiag * al[j];
   __syncthreads();
-  // ---- w = YY cy (no dependency chain): one row per wave pass
-  {
-    const double cyl0 = (lane < k) ? cy_s[lane] : 0.0, cyl1 = (lane + 64 < k) ? cy_s[lane + 64] : 0.0;
-    const int sl0 = (lane < k) ? slot_of[lane] : 0, sl1 = (lane + 64 < k) ? slot_of[lane + 64] : 0;
-    for (int i0 = wave * LB_RB; i0 < k; i0 += 4 * LB_RB) {
-      double v[LB_RB][2];
+  // ---- w = YY cy: YY is symmetric, so lane j accumulates sum_i YY[i][j] cy_i over the rows its wave fetched
+  if (wave > 0) {
+    double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-      for (int r = 0; r < LB_RB; ++r) {
-        const int i = i0 + r;
-        const int si = (i < k) ? slot_of[i] : 0;
-        v[r][0] = (i < k && lane < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
-        v[r][1] = (i < k && lane + 64 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < LB_RB; ++r) {
-        const double partial = wave_sum_d(fma(cyl1, v[r][1], cyl0 * v[r][0]));
-        if (lane == 0 && i0 + r < k) wv[i0 + r] = partial;
-      }
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 1) + 3 * r;
+      const double c = (i < k) ? cy_s[i] : 0.0;
+      acc0 = fma(yv0[r], c, acc0);
+      acc1 = fma(yv1[r], c, acc1);
     }
+    wpart[wave - 1][j0] = acc0;
+    if (j1 < LB_MAXH) wpart[wave - 1][j1] = acc1;
   }
   __syncthreads();
+  for (int j = tid; j < k; j += 256) wv[j] = (wpart[0][j] + wpart[1][j]) + wpart[2][j];
+  __syncthreads();
+  if (stop == 4) return;
   if (wave == 0) {
-    const int j0 = lane, j1 = lane + 64;
     const double b0 = (j0 < k) ? cg * Yg[slot_of[j0]] + wv[j0] : 0.0, b1 = (j1 < k) ? cg * Yg[slot_of[j1]] + wv[j1] : 0.0;
     double q0 = 0.0, q1 = 0.0, c0 = 0.0, c1 = 0.0;
     // ---- loop 2 (oldest -> newest):  cs_i = al_i - (cg y_i.g + (YY cy)_i + sum_{m<i} cs_m U_mi) / U_ii
-    double v0n = (k > 0 && j0 > 0 && j0 < k) ? U[tri_index(0, j0, k)] : 0.0;
-    double v1n = (k > 0 && j1 < k) ? U[tri_index(0, j1, k)] : 0.0;
-    for (int i = 0; i < k; ++i) {
-      const double v0 = v0n, v1 = v1n;
-      v0n = (i + 1 < k && j0 > i + 1 && j0 < k) ? U[tri_index(i + 1, j0, k)] : 0.0;
-      v1n = (i + 1 < k && j1 > i + 1 && j1 < k) ? U[tri_index(i + 1, j1, k)] : 0.0;
-      const int owner = i & 63;
-      const double cand = (i >= 64) ? a1 - (b1 + q1) * rinv1 : a0 - (b0 + q0) * rinv0;
-      const double ci = bcast_lane_d(cand, owner);
-      if (lane == owner) {
-        if (i >= 64) c1 = ci; else c0 = ci;
+    for (int b = 0; b < nblk; ++b) {
+      const int lo = b << 4, hi = min(lo + 16, k);
+      const bool inhi = lo >= 64;
+      const int jr = inhi ? j1 : j0;
+      double ublk[16], cblk[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = lo + t;
+        ublk[t] = (jr > i && jr < hi) ? U[tri_index(i, jr, k)] : 0.0;
       }
-      q0 = fma(ci, v0, q0);
-      q1 = fma(ci, v1, q1);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = lo + t;
+        cblk[t] = 0.0;
+        if (i < hi) {  // wave-uniform
+          const double cand = inhi ? a1 - (b1 + q1) * rinv1 : a0 - (b0 + q0) * rinv0;
+          const double ci = bcast_lane_d(cand, i & 63);
+          cblk[t] = ci;
+          if (lane == (i & 63)) {
+            if (inhi) c1 = ci; else c0 = ci;
+          }
+          if (inhi) q1 = fma(ci, ublk[t], q1); else q0 = fma(ci, ublk[t], q0);
+        }
+      }
+      // rows below the block
+      if (hi < k) {
+        double un[16];
+        if (hi <= 64) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) un[t] = (j0 >= hi && j0 < k && lo + t < hi) ? U[tri_index(lo + t, j0, k)] : 0.0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) q0 = fma(cblk[t], un[t], q0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) un[t] = (j1 >= hi && j1 < k && lo + t < hi) ? U[tri_index(lo + t, j1, k)] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) q1 = fma(cblk[t], un[t], q1);
+      }
     }
     if (j0 < k) cs_s[j0] = c0;
     if (j1 < k) cs_s[j1] = c1;
@@ -402,7 +483,9 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
 
 __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const float* __restrict__ S,
                                                        const float* __restrict__ Y, const float* __restrict__ g,
-                                                       size_t stride, LbDev* __restrict__ st, float* __restrict__ d) {
+                                                       size_t stride, LbDev* __restrict__ st, float* __restrict__ d,
+                                                       const float* __restrict__ x, float t, float* __restrict__ xt) {
+  // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass
   __shared__ double scy[LB_MAXH + 8], scs[LB_MAXH + 8];
   __shared__ int sslot[LB_MAXH + 8];
   const int k = st->count, head = st->head;
@@ -435,9 +518,11 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const floa
     }
     const float d0 = (float)acc0, d1 = (float)acc1;
     d[i] = d0;
+    xt[i] = x[i] + t * d0;
     mx = fabsf(d0);
     if (i + 1 < n) {
       d[i + 1] = d1;
+      xt[i + 1] = x[i + 1] + t * d1;
       mx = fmaxf(mx, fabsf(d1));
     }
   }
@@ -449,15 +534,16 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const floa
 // -------------------------------------------------------------------------------------------------- objectives
 struct Objective {
   int n = 0;
-  virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) = 0;
+  bool fused_stats = false;  // eval() also writes {loss, g.d, max|g|, sum|g|, g.g} to stats_dev
+  virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev) = 0;
   virtual ~Objective() {}
 };
 
 struct StageObjective : Objective {
   uuo_fit* fit;
   const uuo_problem_t* p;
-  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) override {
-    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr);
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev) override {
+    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr, dir, stats_dev);
   }
 };
 
@@ -497,7 +583,7 @@ __global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const f
 
 struct TestObjective : Objective {
   int kind;
-  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad) override {
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*) override {
     hipLaunchKernelGGL(k_test_objective, dim3(1), dim3(256), 0, s, kind, n, x, loss_dev, grad);
     UUO_HIP_CHECK(hipGetLastError());
     return 0;
@@ -548,7 +634,7 @@ static int lbws_create(int n, int hist, LbWs** out) {
   A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
   A((void**)&w->st, sizeof(LbDev));
   A((void**)&w->loss_dev, 16 * sizeof(float));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 16 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 32 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
   if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
@@ -598,6 +684,12 @@ struct LsPoint {
   int buf = -1;  // index of the work vector holding the gradient
 };
 
+struct LbHostOut {  // mirror of the tail of LbDev read back after every closure evaluation
+  unsigned dmax_bits;
+  int pad;
+  LbOut out;
+};
+
 static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
                      uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
   const int n = obj.n;
@@ -615,38 +707,45 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   const int nb = (n + 255) / 256;
   const int nstat = std::min(64, nb);
   auto vec = [&](int i) { return w->vecs + (size_t)i * stride; };
-  // work vectors: 0 g (gradient at x), 1 d, 2 prev_g, 3 x_trial, 4.. pool for line-search gradients
-  float* g = vec(0);
-  float* d = vec(1);
-  float* prev_g = vec(2);
-  float* xt = vec(3);
+  // work vectors: 0 direction d, 1 spare iterate buffer, 2.. gradient pool.  Iterates and gradients change hands by
+  // pointer, never by copy: x lives in d_x or vec(1) (the other one receives the next trial point), the gradient at
+  // x and the previous gradient are pool entries.
+  float* d = vec(0);
+  float* xcur = d_x;
+  float* xoth = vec(1);
   bool pool_used[LB_NVEC] = {false};
   auto pool_alloc = [&]() {
-    for (int i = 4; i < LB_NVEC; ++i)
+    for (int i = 2; i < LB_NVEC; ++i)
       if (!pool_used[i]) {
         pool_used[i] = true;
         return i;
       }
     return -1;
   };
-  auto pool_free = [&](int i) {
-    if (i >= 4) pool_used[i] = false;
-  };
-  LbOut* ho = reinterpret_cast<LbOut*>(w->h_out);
+  LbHostOut* hh = reinterpret_cast<LbHostOut*>(w->h_out);
+  LbOut* ho = &hh->out;
+  double* stats_dev = reinterpret_cast<double*>((char*)w->st + offsetof(LbDev, out));
   int evals_total = 0;
 
-  // evaluate at x_eval into gradient vector gv; stats against d (or none); read back
+  // evaluate at x_eval into gradient vector gv; statistics against d (or none); read back
   auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
-    int rc = obj.eval(s, x_eval, w->loss_dev, gv);
+    const float* dir = with_dir ? d : (const float*)nullptr;
+    int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lb_stats, dim3(nstat), dim3(256), 0, s, n, gv, with_dir ? d : (const float*)nullptr,
-                       w->part);
-    hipLaunchKernelGGL(k_lb_stats_final, dim3(1), dim3(64), 0, s, nstat, w->part, w->loss_dev, w->st);
-    UUO_HIP_CHECK(hipGetLastError());
-    UUO_HIP_CHECK(hipMemcpyAsync(w->h_out, (const char*)w->st + offsetof(LbDev, out), 16 * sizeof(double),
+    if (!obj.fused_stats) {
+      hipLaunchKernelGGL(k_lb_stats, dim3(nstat), dim3(256), 0, s, n, gv, dir, w->part);
+      hipLaunchKernelGGL(k_lb_stats_final, dim3(1), dim3(64), 0, s, nstat, w->part, w->loss_dev, w->st);
+      UUO_HIP_CHECK(hipGetLastError());
+    }
+    UUO_HIP_CHECK(hipMemcpyAsync(w->h_out, (const char*)w->st + offsetof(LbDev, dmax_bits), sizeof(LbHostOut),
                                  hipMemcpyDeviceToHost, s));
     UUO_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
+  };
+  auto host_dmax = [&]() -> double {
+    float f;
+    std::memcpy(&f, &hh->dmax_bits, sizeof(float));
+    return (double)f;
   };
   auto report = [&](double loss) {
     if (cb) cb(cb_user, evals_total, (float)loss);
@@ -656,7 +755,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
 
   UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
   hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, w->st);
-  int rc = evaluate(d_x, g, false);
+  int ig = pool_alloc();  // gradient at the current iterate
+  int ipg = -1;           // gradient at the previous iterate
+  int rc = evaluate(xcur, vec(ig), false);
   if (rc) return rc;
   double loss = ho->loss;
   double gmax = ho->gmax;
@@ -674,44 +775,42 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   } else {
     while (n_iter < max_iter) {
       ++n_iter;
-      // ---------------------------------------------------------------- direction
-      int cand = -1;
-      if (n_iter == 1) {
-        hipLaunchKernelGGL(k_lb_neg, dim3(nb), dim3(256), 0, s, n, g, d);
-      } else {
-        cand = (head + count) % cap;
-        float* s_new = w->S + (size_t)cand * stride;
-        float* y_new = w->Y + (size_t)cand * stride;
-        hipLaunchKernelGGL(k_lb_form, dim3(nb), dim3(256), 0, s, n, g, prev_g, d, (float)t, s_new, y_new);
-        const int nrows = 2 * (count + 1) + 1;
-        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand,
-                           w->S, w->Y, g, stride, chunk_len, w->part);
-        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st);
-        hipLaunchKernelGGL(k_lb_direction, dim3((n + 511) / 512), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st, d);
-      }
-      UUO_HIP_CHECK(hipGetLastError());
-      UUO_HIP_CHECK(hipMemcpyAsync(prev_g, g, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-      prev_loss = loss;
-      // ---------------------------------------------------------------- step length guess
+      float* g = vec(ig);
+      // ---------------------------------------------------------------- step length guess (lbfgs.py:453-456)
+      const double t_prev_iter = t;
       if (n_iter == 1)
         t = std::fmin(1.0, 1.0 / g1) * lr;
       else
         t = lr;
+      // ---------------------------------------------------------------- direction + first trial point
+      if (n_iter == 1) {
+        hipLaunchKernelGGL(k_lb_neg, dim3(nb), dim3(256), 0, s, n, g, d, xcur, (float)t, xoth);
+      } else {
+        const int cand = (head + count) % cap;
+        const int nrows = 2 * (count + 1) + 1;
+        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand, w->S,
+                           w->Y, g, vec(ipg), d, (float)t_prev_iter, stride, chunk_len, w->part);
+        static const int small_stop = getenv("UUO_SMALL_STOP") ? atoi(getenv("UUO_SMALL_STOP")) : 0;  // ablation only
+        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
+        hipLaunchKernelGGL(k_lb_direction, dim3((n + 511) / 512), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st,
+                           d, xcur, (float)t, xoth);
+      }
+      UUO_HIP_CHECK(hipGetLastError());
+      prev_loss = loss;
       // ---------------------------------------------------------------- first trial (speculative: launched
       // before g.d is known on the host; discarded if the direction test fails)
       LsPoint pnew;
       pnew.buf = pool_alloc();
-      hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)t, d, xt);
-      rc = evaluate(xt, vec(pnew.buf), true);
+      UUO_REQUIRE(pnew.buf >= 0, "lbfgs: gradient pool exhausted");
+      rc = evaluate(xoth, vec(pnew.buf), true);
       if (rc) return rc;
       double gtd, d_norm;
-      if (n_iter == 1) {
-        // d = -g: g.d = -g.g, max|d| = max|g|
+      if (n_iter == 1) {  // d = -g: g.d = -g.g, max|d| = max|g|
         gtd = -gg0;
         d_norm = gmax;
       } else {
         gtd = ho->gtd_dir;
-        d_norm = ho->dmax;
+        d_norm = host_dmax();
         if (ho->accepted != 0.0) {
           if (count == hist)
             head = (head + 1) % cap;
@@ -720,7 +819,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         }
       }
       if (gtd > -tol_change) {
-        pool_free(pnew.buf);
+        pool_used[pnew.buf] = false;
         reason = 5;
         break;
       }
@@ -729,6 +828,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       pnew.gtd = ho->gtd_new;
       pnew.gmax = ho->gmax;
       report(pnew.f);
+      double t_at_xoth = t;  // step whose iterate currently sits in xoth
       // ---------------------------------------------------------------- strong Wolfe (lbfgs.py:40-209)
       const int max_ls = max_eval - current_evals;
       int ls_func_evals = 1;
@@ -737,7 +837,24 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       p0.f = loss;
       p0.gtd = gtd;
       p0.gmax = gmax;
-      p0.buf = 0;
+      p0.buf = ig;
+      auto release = [&](int buf) {
+        if (buf != ig && buf >= 2) pool_used[buf] = false;
+      };
+      auto trial = [&](LsPoint& pt) -> int {
+        pt.buf = pool_alloc();
+        UUO_REQUIRE(pt.buf >= 0, "lbfgs: gradient pool exhausted");
+        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, xcur, (float)pt.t, d, xoth);
+        int r = evaluate(xoth, vec(pt.buf), true);
+        if (r) return r;
+        t_at_xoth = pt.t;
+        pt.f = ho->loss;
+        pt.gtd = ho->gtd_new;
+        pt.gmax = ho->gmax;
+        report(pt.f);
+        ++ls_func_evals;
+        return 0;
+      };
       LsPoint pprev = p0;
       LsPoint br[2];
       int nbr = 0;
@@ -754,7 +871,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           br[0] = pnew;
           nbr = 1;
           done = true;
-          if (pprev.buf != 0) pool_free(pprev.buf);
+          release(pprev.buf);
           break;
         }
         if (pnew.gtd >= 0) {
@@ -767,27 +884,19 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         const double max_step = pnew.t * 10;
         const double t_next = cubic_interpolate(pprev.t, pprev.f, pprev.gtd, pnew.t, pnew.f, pnew.gtd, true, min_step,
                                                 max_step);
-        if (pprev.buf != 0) pool_free(pprev.buf);
+        release(pprev.buf);
         pprev = pnew;
         pnew = LsPoint();
-        pnew.buf = pool_alloc();
-        UUO_REQUIRE(pnew.buf >= 0, "lbfgs: line-search buffer pool exhausted");
         pnew.t = t_next;
-        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)pnew.t, d, xt);
-        rc = evaluate(xt, vec(pnew.buf), true);
+        rc = trial(pnew);
         if (rc) return rc;
-        pnew.f = ho->loss;
-        pnew.gtd = ho->gtd_new;
-        pnew.gmax = ho->gmax;
-        report(pnew.f);
-        ++ls_func_evals;
         ++ls_iter;
       }
       if (nbr == 0) {  // ls_iter == max_ls
         br[0] = p0;
         br[1] = pnew;
         nbr = 2;
-        if (pprev.buf != 0 && pprev.buf != pnew.buf) pool_free(pprev.buf);
+        if (pprev.buf != pnew.buf) release(pprev.buf);
       }
       bool insuf_progress = false;
       int low_pos, high_pos;
@@ -817,20 +926,12 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           insuf_progress = false;
         }
         LsPoint pz;
-        pz.buf = pool_alloc();
-        UUO_REQUIRE(pz.buf >= 0, "lbfgs: line-search buffer pool exhausted");
         pz.t = tz;
-        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)pz.t, d, xt);
-        rc = evaluate(xt, vec(pz.buf), true);
+        rc = trial(pz);
         if (rc) return rc;
-        pz.f = ho->loss;
-        pz.gtd = ho->gtd_new;
-        pz.gmax = ho->gmax;
-        report(pz.f);
-        ++ls_func_evals;
         ++ls_iter;
         if (pz.f > (loss + c1 * pz.t * gtd) || pz.f >= br[low_pos].f) {
-          if (br[high_pos].buf != 0) pool_free(br[high_pos].buf);
+          release(br[high_pos].buf);
           br[high_pos] = pz;
           if (br[0].f <= br[1].f) {
             low_pos = 0;
@@ -843,26 +944,48 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           if (std::fabs(pz.gtd) <= -c2 * gtd) {
             done = true;
           } else if (pz.gtd * (br[high_pos].t - br[low_pos].t) >= 0) {
-            if (br[high_pos].buf != 0) pool_free(br[high_pos].buf);
+            release(br[high_pos].buf);
             br[high_pos] = br[low_pos];
             br[low_pos] = pz;
             continue;
           }
           // new point becomes new low (the old low is dropped unless it was just moved to high)
-          if (br[low_pos].buf != 0) pool_free(br[low_pos].buf);
+          release(br[low_pos].buf);
           br[low_pos] = pz;
         }
       }
       const LsPoint res = (nbr == 1) ? br[0] : br[low_pos];
-      // ---------------------------------------------------------------- accept
+      // ---------------------------------------------------------------- accept: x <- x + t d by pointer where the
+      // accepted point is the trial that already sits in xoth (p.add_(d, alpha=t) rounds exactly like the trial)
       t = res.t;
       loss = res.f;
       gmax = res.gmax;
-      if (res.buf != 0)
-        UUO_HIP_CHECK(hipMemcpyAsync(g, vec(res.buf), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, d_x, (float)t, d, d_x);
+      if (res.t == 0.0) {
+        // line search returned the starting point (bracket low at t = 0): iterate unchanged
+      } else {
+        if (t_at_xoth != res.t) hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, xcur, (float)t, d, xoth);
+        float* tmp = xcur;
+        xcur = xoth;
+        xoth = tmp;
+      }
       UUO_HIP_CHECK(hipGetLastError());
-      for (int i = 4; i < LB_NVEC; ++i) pool_used[i] = false;
+      {  // gradient hand-over: previous <- current, current <- accepted point's
+        const int old_g = ig, old_pg = ipg;
+        const int new_g = res.buf;
+        for (int i = 2; i < LB_NVEC; ++i) pool_used[i] = false;
+        if (new_g == old_g) {
+          // accepted point is the starting point: prev gradient must still become a copy of g (y = 0 next time)
+          ipg = (old_pg >= 0 && old_pg != old_g) ? old_pg : pool_alloc();
+          pool_used[ipg] = true;
+          UUO_HIP_CHECK(hipMemcpyAsync(vec(ipg), vec(old_g), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+          ig = old_g;
+        } else {
+          ipg = old_g;
+          ig = new_g;
+        }
+        pool_used[ig] = true;
+        pool_used[ipg] = true;
+      }
       current_evals += ls_func_evals;
       // ---------------------------------------------------------------- termination (lbfgs.py:511-526)
       if (n_iter == max_iter) {
@@ -887,6 +1010,8 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       }
     }
   }
+  if (xcur != d_x)
+    UUO_HIP_CHECK(hipMemcpyAsync(d_x, xcur, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
   UUO_HIP_CHECK(hipEventRecord(w->ev1, s));
   UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
   float ms = 0.f;
@@ -921,7 +1046,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
   A((void**)&fit->bbox, (size_t)F * (model->VP / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
-  A((void**)&fit->frame_part, (size_t)F * 16 * sizeof(float));
+  A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));
   A((void**)&fit->mask, (size_t)F * M * sizeof(float));
   A((void**)&fit->scalars, 64 * sizeof(float));
   A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
@@ -970,6 +1095,7 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   StageObjective obj;
   obj.fit = fit;
   obj.p = p;
+  obj.fused_stats = true;
   obj.n = uuo_problem_num_params(p);
   std::memset(stats, 0, sizeof(*stats));
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
@@ -990,4 +1116,42 @@ extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, con
   rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, nullptr, nullptr);
   lbws_destroy(w);
   return rc;
+}
+
+// debug hook (not in the public header): device time of k_lb_small at a fixed history size k, optionally cut
+// short after a phase (stop = 1..4) -- used to attribute its latency (tools/, not on the product path)
+extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
+  UUO_REQUIRE(k >= 1 && k <= LB_MAXH - 4 && iters > 0 && ms_out, "uuo_debug_time_small: bad arguments");
+  LbWs* w = nullptr;
+  int rc = lbws_create(4096, LB_MAXH - 4, &w);
+  if (rc) return rc;
+  std::vector<double> SY((size_t)LB_MAXH * LB_MAXH, 0.0), YY((size_t)LB_MAXH * LB_MAXH, 0.0);
+  for (int i = 0; i < LB_MAXH; ++i)
+    for (int j = 0; j < LB_MAXH; ++j) {
+      SY[(size_t)i * LB_MAXH + j] = (i == j) ? 2.0 : 0.01 / (1 + std::abs(i - j));
+      YY[(size_t)i * LB_MAXH + j] = (i == j) ? 3.0 : 0.02 / (1 + std::abs(i - j));
+    }
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, SY), SY.data(), SY.size() * sizeof(double), hipMemcpyHostToDevice));
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, YY), YY.data(), YY.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double> part((size_t)LB_MAXCHUNK * LB_ROWS * 3, 1e-3);
+  UUO_HIP_CHECK(hipMemcpy(w->part, part.data(), part.size() * sizeof(double), hipMemcpyHostToDevice));
+  const int cap = LB_MAXH - 3, hist = LB_MAXH - 4;
+  float total = 0.f;
+  for (int it = 0; it < iters + 1; ++it) {
+    const int head = 0, count = k - 1;  // the kernel accepts the candidate -> k pairs
+    UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, head), &head, sizeof(int), hipMemcpyHostToDevice));
+    UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, count), &count, sizeof(int), hipMemcpyHostToDevice));
+    const double one = 1.0;
+    UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
+    UUO_HIP_CHECK(hipEventRecord(w->ev0, nullptr));
+    hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop);
+    UUO_HIP_CHECK(hipEventRecord(w->ev1, nullptr));
+    UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
+    float ms = 0.f;
+    UUO_HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    if (it > 0) total += ms;
+  }
+  *ms_out = total / iters;
+  lbws_destroy(w);
+  return 0;
 }

@@ -12,6 +12,7 @@
 #define UUO_KB 208        // padded K of the per-vertex transposed posedirs rows
 #define UUO_FT 16         // frames per MFMA row tile (v_mfma_f32_16x16x4_f32)
 #define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
+#define UUO_FP 24         // floats per frame of the closure's partial-sum block
 
 void uuo_set_error(const std::string& msg);
 
@@ -97,7 +98,7 @@ struct uuo_fit {
   float* bbox = nullptr;            // [F][VP/16][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
-  float* frame_part = nullptr;      // [F][16]: loss, dz, dbeta[10], pad
+  float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
   float* mask = nullptr;            // [F][M] 0/1
   float* scalars = nullptr;         // device scalars block (see solver)
   float* vecs = nullptr;            // one work vector of n_max floats (timing helper gradient)
@@ -130,4 +131,4 @@ int uuo_launch_finalize(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& 
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p);
 int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p);
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
-                          float* d_grad, int32_t* d_nn_idx);
+                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats);
