@@ -222,7 +222,9 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
       float T[12];
 #pragma unroll
       for (int c = 0; c < 12; ++c) T[c] = 0.f;
-      if (SPARSE) {
+      if (VAR == 5) {
+        T[0] = T[5] = T[10] = ww[0] + 1.f;
+      } else if (SPARSE) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const float4* pt = reinterpret_cast<const float4*>(sT + (i * UUO_NUM_JOINTS + wj[n]) * 12);
@@ -297,6 +299,7 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
   else if (variant == 2) SKIN_LAUNCH(true, 2);
   else if (variant == 3) SKIN_LAUNCH(true, 3);
   else if (variant == 4) SKIN_LAUNCH(true, 4);
+  else if (variant == 5) SKIN_LAUNCH(true, 5);
   else SKIN_LAUNCH(true, 0);
 #undef SKIN_LAUNCH
   UUO_HIP_CHECK(hipGetLastError());
