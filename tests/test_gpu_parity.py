@@ -456,3 +456,37 @@ def test_full_size_properties(smpl, dev):
     # a short solve decreases the loss monotonically over accepted iterates
     st = prob.solve(x, max_iter=10, lr=0.1)
     assert st["final_loss"] < st["first_loss"]
+
+
+# ------------------------------------------------------------------------------------------------ other configs
+@pytest.mark.parametrize("cfg_name,limb,F,M", [("hmr_part", True, 12, 9), ("mht_rotation", False, 10, 14),
+                                               ("hmr_full", False, 40, 20)])
+def test_packaged_configs_run_end_to_end(smpl, dev, cfg_name, limb, F, M):
+    """BASELINE configs[2] (partial marker set, sub-tree search), configs[4] (single yaw hypothesis) and
+    configs[1] at a size that crosses a frame-tile boundary: the orchestrator runs every enabled stage and
+    returns the reference's output dictionary; the fit does not move the body away from the markers."""
+    from uuo_mocap_amd.multimodal import LAST_RUN_STATS, multimodal_video_mocap
+    from uuo_mocap_amd.optimization import get_marker_mask, weighted_chamfer_distance
+
+    cfg = packaged_config(cfg_name)
+    for k in ("part", "chamfer", "marker"):
+        if cfg["stages"][k]["num_iters"] > 0:
+            cfg["stages"][k]["num_iters"] = 40
+    seq = make_sequence(smpl.tables, seed=11, num_frames=F, num_markers=M, limb_only=limb)
+    out = multimodal_video_mocap(seq.img_smpl, seq.markers, dev, cfg, offset=0, print_options=[], save_stages=True,
+                                 smpl_inference=smpl)
+    assert set(out) >= {"trans", "root_orient", "pose_body", "betas", "mocap_frame_rate", "mocap_markers",
+                        "markers_labels", "stages", "chain"}
+    assert out["trans"].shape == (F, 3) and out["pose_body"].shape == (F, 23, 3, 3) and out["betas"].shape == (F, 10)
+    assert np.asarray(out["markers_labels"]).shape == (F, M)
+    n_angles = cfg["num_root_orient_angles"]
+    assert len(LAST_RUN_STATS["chamfer"]) == (n_angles if cfg["stages"]["chamfer"]["num_iters"] > 0 else 0)
+    assert len(LAST_RUN_STATS["yaw_scores"]) == n_angles
+    assert len(LAST_RUN_STATS["part"]) >= 1
+    rot = torch.cat([out["root_orient"], out["pose_body"]], dim=1)
+    eye = torch.eye(3).expand(F, 24, 3, 3)
+    torch.testing.assert_close(rot @ rot.transpose(-1, -2), eye, atol=1e-4, rtol=0)  # outputs are normalised rotations
+    markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+    verts = smpl(out["pose_body"].to(dev), out["betas"].to(dev), out["root_orient"].to(dev), out["trans"].to(dev))["vertices"]
+    score = weighted_chamfer_distance(markers, verts, get_marker_mask(markers))[0].item()
+    assert np.isfinite(score) and score < 0.05, score  # mean squared marker-to-surface distance stays small (m^2)

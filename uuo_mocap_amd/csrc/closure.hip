@@ -2,6 +2,7 @@
 // (reference optimization.py:187-275 chamfer, :329-394 marker, markers/markers_utils.py:454-562 part).
 // Only the <= M vertices a frame's markers touch carry gradient, so the backward is a gather-LBS over those
 // vertices instead of the reference's dense autograd GEMMs.
+#include <cstdlib>
 #include <vector>
 
 #include "frame_math.h"
@@ -19,6 +20,7 @@ struct BwdArgs {
   // frame inputs
   UuoPoseSrc src;
   int stage, F, M;
+  int stop;  // ablation only
   const float* markers;
   const float* mask;
   const unsigned long long* nn;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   if (tid < 28 * 4) (&sstat[0][0])[tid] = 0.f;
   __syncthreads();
 
+  if (a.stop == 1) return;
   float tr[3] = {0.f, 0.f, 0.f};
   if (a.src.trans) {
     tr[0] = a.src.trans[(size_t)f * 3];
@@ -108,117 +111,155 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     }
   }
 
-  for (int m = wave; m < M; m += BWD_NW) {
-    float wgt = 1.f, d2 = 0.f;
+  // Items are software-pipelined: every global load of item m + BWD_NW (assignment key, marker, the vertex's
+  // posedirs rows, template, shape rows, skin weights) is issued before item m is processed, so the L2/MALL
+  // round trips of the gather overlap the arithmetic and the wave reductions of the previous item.
+  struct Item {
+    float p[3][4];
+    float x0, x1, x2, wgt, d2, vt0, vt1, vt2, stv;
+    int vi;
+    int4 wi;
+    float4 ww;
+    bool on;
+  };
+  auto fetch = [&](int m, Item& q) {
+    q.on = false;
+    q.wgt = 1.f;
+    q.d2 = 0.f;
+    if (m >= M) return;
     int vi;
     if (a.stage == UUO_STAGE_MARKER) {
-      wgt = a.mask[(size_t)f * M + m];
+      q.wgt = a.mask[(size_t)f * M + m];
       vi = a.assign[m];
     } else {
       const unsigned long long key = a.nn[(size_t)f * M + m];
-      d2 = __uint_as_float((unsigned)(key >> 32));
+      q.d2 = __uint_as_float((unsigned)(key >> 32));
       vi = (int)(unsigned)(key & 0xFFFFFFFFull);
-      if (a.stage == UUO_STAGE_PART) {
+      if (a.stage == UUO_STAGE_PART)
         vi = a.subset[vi];
-      } else {
-        wgt = a.mask[(size_t)f * M + m];
-      }
+      else
+        q.wgt = a.mask[(size_t)f * M + m];
     }
-    if (wgt == 0.f) continue;  // wave-uniform
+    if (q.wgt == 0.f) return;  // wave-uniform
+    q.on = true;
+    q.vi = vi;
     const float* px = a.markers + ((size_t)f * M + m) * 3;
-    const float x0 = px[0], x1 = px[1], x2 = px[2];
-
-    // posedirs rows of this vertex over lanes: k = lane + 64 r
+    q.x0 = px[0];
+    q.x1 = px[1];
+    q.x2 = px[2];
     const float* pt = a.PT + (size_t)vi * 3 * UUO_KB;
-    float p[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) p[c][r] = pt[c * UUO_KB + lane + 64 * r];
-      p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
+      for (int r = 0; r < 3; ++r) q.p[c][r] = pt[c * UUO_KB + lane + 64 * r];
+      q.p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
     }
-    const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
-                f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
-    float vp[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float part = fmaf(p[c][3], f3, fmaf(p[c][2], f2, fmaf(p[c][1], f1, p[c][0] * f0)));
-      const float offs = wave_sum(part);
-      float vs = a.vt[(size_t)vi * 3 + c];
-      float sb = 0.f;
-#pragma unroll
-      for (int l = 0; l < 10; ++l) sb = fmaf(a.ST[((size_t)vi * 3 + c) * 10 + l], L.beta[l], sb);
-      vp[c] = offs + (vs + sb);
-    }
-    // blended skinning matrix
-    float T[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    int wj[4];
-    float ww[4];
+    q.vt0 = a.vt[(size_t)vi * 3];
+    q.vt1 = a.vt[(size_t)vi * 3 + 1];
+    q.vt2 = a.vt[(size_t)vi * 3 + 2];
+    q.stv = (lane < 30) ? a.ST[(size_t)vi * 30 + lane] : 0.f;  // lane 10 c + l holds S[vi][c][l]
     if (SPARSE) {
+      q.wi = *reinterpret_cast<const int4*>(a.Wi + (size_t)vi * 4);
+      q.ww = *reinterpret_cast<const float4*>(a.Ww + (size_t)vi * 4);
+    }
+  };
+  const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
+              f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
+  const float beta_l = L.beta[lane % 10];
+  Item cur, nxt;
+  fetch(wave, cur);
+  for (int m = wave; m < M; m += BWD_NW) {
+    fetch(m + BWD_NW, nxt);
+    if (cur.on) {
+      const float wgt = cur.wgt, d2 = cur.d2;
+      const int vi = cur.vi;
+      const float x0 = cur.x0, x1 = cur.x1, x2 = cur.x2;
+      // v_posed of the touched vertex: template + shape blend (lanes 0..29 hold the 3x10 shape rows) + pose blend
+      const float sprod = cur.stv * beta_l;
+      float vp[3];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        wj[n] = a.Wi[(size_t)vi * 4 + n];
-        ww[n] = a.Ww[(size_t)vi * 4 + n];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
+      for (int c = 0; c < 3; ++c) {
+        float part = fmaf(cur.p[c][3], f3, fmaf(cur.p[c][2], f2, fmaf(cur.p[c][1], f1, cur.p[c][0] * f0)));
+        const float offs = wave_sum_fast(part);
+        const float sb = wave_sum_fast((lane >= 10 * c && lane < 10 * c + 10) ? sprod : 0.f);
+        const float vs = (c == 0) ? cur.vt0 : ((c == 1) ? cur.vt1 : cur.vt2);
+        vp[c] = offs + (vs + sb);
       }
-    } else {
-      for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
-        const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
+      // blended skinning matrix
+      float T[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
-      }
-    }
-    const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
-    const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
-    const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
-    const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
-    float g[3];
-    float loss_item;
-    if (a.stage == UUO_STAGE_MARKER) {
-      const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
-      const float e = rr - a.d0;
-      loss_item = wgt * (e * e);
-      const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
-      g[0] = sc * dx;
-      g[1] = sc * dy;
-      g[2] = sc * dz;
-    } else {
-      loss_item = wgt * d2;
-      const float sc = -a.cg * wgt;
-      g[0] = sc * dx;
-      g[1] = sc * dy;
-      g[2] = sc * dz;
-    }
-    // d v_posed = T_R^T g
-    float dvp[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc_dpf[r] += fmaf(p[2][r], dvp[2], fmaf(p[1][r], dvp[1], p[0][r] * dvp[0]));
-    if (lane < 10) {
-      const float* ps = a.ST + (size_t)vi * 30 + lane;
-      acc_db += fmaf(ps[20], dvp[2], fmaf(ps[10], dvp[1], ps[0] * dvp[0]));
-    }
-    if (lane < 12) {
-      const int r = lane >> 2, c = lane & 3;
-      const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
-      const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
-      const float val = gr * pc;
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+      int wj[4];
+      float ww[4];
       if (SPARSE) {
+        wj[0] = cur.wi.x; wj[1] = cur.wi.y; wj[2] = cur.wi.z; wj[3] = cur.wi.w;
+        ww[0] = cur.ww.x; ww[1] = cur.ww.y; ww[2] = cur.ww.z; ww[3] = cur.ww.w;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
+        }
       } else {
-        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
-          w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
+        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
+          const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
+#pragma unroll
+          for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
+        }
       }
+      const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
+      const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
+      const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
+      const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
+      float g[3];
+      float loss_item;
+      if (a.stage == UUO_STAGE_MARKER) {
+        const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float e = rr - a.d0;
+        loss_item = wgt * (e * e);
+        const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
+        g[0] = sc * dx;
+        g[1] = sc * dy;
+        g[2] = sc * dz;
+      } else {
+        loss_item = wgt * d2;
+        const float sc = -a.cg * wgt;
+        g[0] = sc * dx;
+        g[1] = sc * dy;
+        g[2] = sc * dz;
+      }
+      // d v_posed = T_R^T g
+      float dvp[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc_dpf[r] += fmaf(cur.p[2][r], dvp[2], fmaf(cur.p[1][r], dvp[1], cur.p[0][r] * dvp[0]));
+      {  // d beta (direct path): lane 10 c + l holds S[c][l]; fold the three coordinate groups onto lanes 0..9
+        const int cgrp = lane / 10;
+        const float contrib = (lane < 30) ? cur.stv * ((cgrp == 0) ? dvp[0] : ((cgrp == 1) ? dvp[1] : dvp[2])) : 0.f;
+        const float c1v = __shfl(contrib, lane + 10, 64), c2v = __shfl(contrib, lane + 20, 64);
+        if (lane < 10) acc_db += contrib + c1v + c2v;
+      }
+      if (lane < 12) {
+        const int r = lane >> 2, c = lane & 3;
+        const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
+        const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
+        const float val = gr * pc;
+        if (SPARSE) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
+        } else {
+          for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
+            w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
+        }
+      }
+      if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
+      acc_loss += loss_item;
     }
-    if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
-    acc_loss += loss_item;
+    cur = nxt;
   }
 
+  if (a.stop == 2) return;
   // ---- block reduction (fixed order -> deterministic)
 #pragma unroll
   for (int r = 0; r < 3; ++r) w_dpf[wave][lane + 64 * r] = acc_dpf[r];
@@ -247,6 +288,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   }
   __syncthreads();
 
+  if (a.stop == 3) return;
   // ---- phase 2: joints on lanes
   const UuoTree* tree = a.tree;
   const int j = tid;
@@ -313,12 +355,15 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   }
   __syncthreads();
 
-  // shape gradient of this frame: direct (blend shapes) + joint path
+  // shape gradient of this frame: direct (blend shapes) + joint path (240 threads: one (joint, beta) pair each)
+  if (tid < 240) {
+    const int jj = tid / 10, l = tid - jj * 10;
+    w_dpf[0][tid] = fmaf(tree->JS[jj][2][l], sdJ[jj][2], fmaf(tree->JS[jj][1][l], sdJ[jj][1], tree->JS[jj][0][l] * sdJ[jj][0]));
+  }
+  __syncthreads();
   if (tid < 10) {
     float acc = red[4 + tid];
-    for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc = fmaf(tree->JS[jj][c][tid], sdJ[jj][c], acc);
+    for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj) acc += w_dpf[0][jj * 10 + tid];
     a.frame_part[(size_t)f * UUO_FP + 4 + tid] = acc;
   }
   // body rotations
@@ -657,6 +702,8 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + lay.off_z : nullptr;
   a.g_trans = d_grad + lay.off_trans;
   a.frame_part = fit->frame_part;
+  static const int bwd_stop = getenv("UUO_BWD_STOP") ? atoi(getenv("UUO_BWD_STOP")) : 0;
+  a.stop = bwd_stop;
   a.dir = d_dir;
   a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
   if (m->nnz <= 4)

@@ -187,6 +187,27 @@ __device__ __forceinline__ void frame_skin_matrix(const FrameLds& L, int j, floa
   }
 }
 
+// Wave-wide sum on the VALU: four DPP row-rotate adds leave each 16-lane row's sum on all of its lanes, then four
+// v_readlane gather the rows (an LDS-crossbar butterfly of ds_bpermute costs ~100 cycles per step on the dependent
+// chain; this is ~10 short instructions).  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v += dpp_rot<0x128>(v);  // row_ror:8
+  v += dpp_rot<0x124>(v);  // row_ror:4
+  v += dpp_rot<0x122>(v);  // row_ror:2
+  v += dpp_rot<0x121>(v);  // row_ror:1
+  const int i = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -4,15 +4,19 @@ utils/smpl_utils.py:106-188, utils/aabb.py:5-25).  Host logic stays Python; ever
 nearest-neighbour query runs on the GPU through libuuo_hip.so."""
 from __future__ import annotations
 
+import contextlib
 import itertools
+import os
+import queue
 from collections.abc import Callable
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List
 
 import numpy as np
 import torch
 
 from .body_model import SMPL_JOINT_NAMES
-from .engine import PartProblem
+from .engine import PartProblem, set_workspace_slot
 from .losses import chamfer_distance
 from .transforms import compute_root_orient_z
 
@@ -132,37 +136,76 @@ def find_best_part_fits(
 
     vertex_labels = torch.argmax(smpl_inference.get_lbs_weights(), dim=-1)
     trans0 = torch.median(markers, dim=1)[0]
+    valid = torch.ones(num_frames, dtype=torch.bool, device=device)
+
+    def fit_subtree(slot: int, subtree, stream):
+        """One candidate body part (reference :416-597): L-BFGS over [z, trans, betas], then the ranking score and the
+        per-marker labels.  Candidates are independent solves: each worker thread has its own stream and workspace."""
+        set_workspace_slot(slot)
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+            prob = PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vertex_indices, config)
+            x = prob.pack(torch.zeros((1, 1, 1), device=device), trans0, o_betas)
+            stats = prob.solve(x, max_iter=st["num_iters"], lr=1.0,
+                               tolerance_grad=config["optimizer"]["tolerance_grad"],
+                               tolerance_change=config["optimizer"]["tolerance_change"])
+            z_angle, trans, betas_s = prob.unpack(x)
+            with torch.no_grad():
+                z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
+                verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
+                                       root_orient=z_root, trans=trans)["vertices"]
+                verts_sub = verts[:, vertex_indices].contiguous()
+                distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
+                # label of marker i = dominant joint of argmin_v mean_f |v - x_i| over ALL vertices (:592-597)
+                near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
+                labels = vertex_labels[near].clone()
+            out = {"stats": stats, "distance": distance, "betas": betas_s.clone(), "root_orient": z_root.clone(),
+                   "trans": trans.clone(), "labels": labels}
+            if stream is not None:
+                stream.synchronize()
+        return out
+
+    n_threads = min(len(subtrees), int(os.environ.get("UUO_SUBTREE_THREADS", "4")))
+    if n_threads > 1 and device.type == "cuda":
+        main_stream = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device=device) for _ in range(n_threads)]
+        for s_ in streams:
+            s_.wait_stream(main_stream)
+        free_slots = queue.Queue()
+        for i in range(n_threads):
+            free_slots.put(i)
+
+        def worker(subtree):
+            i = free_slots.get()
+            try:
+                return fit_subtree(i, subtree, streams[i])
+            finally:
+                free_slots.put(i)
+
+        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            results = list(pool.map(worker, subtrees))
+        for s_ in streams:
+            main_stream.wait_stream(s_)
+        set_workspace_slot(0)
+    else:
+        results = [fit_subtree(0, subtree, None) for subtree in subtrees]
+
     best = None
     best_distance = np.inf
     subtree_losses = []
     LAST_STATS["part"] = []
-    for subtree in subtrees:
-        vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
-        prob = PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vertex_indices, config)
-        x = prob.pack(torch.zeros((1, 1, 1), device=device), trans0, o_betas)
-        stats = prob.solve(x, max_iter=st["num_iters"], lr=1.0,
-                           tolerance_grad=config["optimizer"]["tolerance_grad"],
-                           tolerance_change=config["optimizer"]["tolerance_change"])
-        LAST_STATS["part"].append(stats)
-        z_angle, trans, betas_s = prob.unpack(x)
-        with torch.no_grad():
-            z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
-            verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
-                                   root_orient=z_root, trans=trans)["vertices"]
-            verts_sub = verts[:, vertex_indices].contiguous()
-            distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
-        subtree_losses.append([subtree, distance])
-        if distance < best_distance:
-            best_distance = distance
+    for subtree, res in zip(subtrees, results):  # candidate order decides ties, exactly as the sequential reference
+        LAST_STATS["part"].append(res["stats"])
+        subtree_losses.append([subtree, res["distance"]])
+        if res["distance"] < best_distance:
+            best_distance = res["distance"]
             best = {
-                "betas": betas_s.clone(), "markers_subset": markers_subset.clone(), "root_orient": z_root.clone(),
-                "trans": trans.clone(),
+                "betas": res["betas"], "markers_subset": markers_subset.clone(), "root_orient": res["root_orient"],
+                "trans": res["trans"],
                 "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
             }
-            # label of marker i = dominant joint of argmin_v mean_f |v - x_i| over ALL vertices (:592-597)
-            valid = torch.ones(num_frames, dtype=torch.bool, device=device)
-            near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
-            final_marker_labels[:, indices] = vertex_labels[near][None, :].to(final_marker_labels.dtype)
+            final_marker_labels[:, indices] = res["labels"][None, :].to(final_marker_labels.dtype)
 
     if len(subtree_losses) > 1:
         subtree_losses = sorted(subtree_losses, key=lambda e: e[1])
