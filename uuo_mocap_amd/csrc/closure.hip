@@ -654,7 +654,7 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
   if (rc) return rc;
   if (cull)  // exact search pruned by per-unit bounding boxes and the previous closure's assignment (kept in fit->nn)
-    return uuo_launch_nn_cull(s, p->F, p->M, m->V, m->VP / 16, p->d_markers, fit->verts, fit->bbox, fit->nn, fit->nn_flags);
+    return uuo_launch_nn_cull(s, p->F, p->M, m->V, (m->V + 15) / 16, p->d_markers, fit->verts, fit->bbox, fit->nn, fit->nn_flags);
   return uuo_launch_nn(s, p->F, p->M, m->V, p->d_markers, fit->verts, p->d_subset, p->n_subset, fit->nn);
 }
 
@@ -778,5 +778,15 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
 extern "C" int uuo_debug_nn_flags(uuo_fit_t* fit, int* h_out) {
   UUO_REQUIRE(fit && h_out, "uuo_debug_nn_flags: null argument");
   UUO_HIP_CHECK(hipMemcpy(h_out, fit->nn_flags, (size_t)fit->F * 8 * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// debug/test hook (not in the public header): vertices and unit boxes of the last closure evaluation
+extern "C" int uuo_debug_fit_buffers(uuo_fit_t* fit, float* h_verts, float* h_bbox) {
+  UUO_REQUIRE(fit, "uuo_debug_fit_buffers: null argument");
+  if (h_verts)
+    UUO_HIP_CHECK(hipMemcpy(h_verts, fit->verts, (size_t)fit->F * fit->model->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (h_bbox)
+    UUO_HIP_CHECK(hipMemcpy(h_bbox, fit->bbox, (size_t)fit->F * ((fit->model->V + 15) / 16) * 6 * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }

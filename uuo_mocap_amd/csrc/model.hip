@@ -33,7 +33,7 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
   const int nunits = VP / 16, ngroups = UUO_KP / 16;
   std::vector<float> P3((size_t)3 * nunits * ngroups * 256, 0.f), vt3((size_t)3 * VP, 0.f);
   auto baug = [&](int k, int v, int c) -> float {
-    if (v >= V) return 0.f;
+    if (v >= V) v = V - 1;  // padding vertices duplicate the last one: their positions never widen a unit's box
     if (k < UUO_NUM_POSE_FEATS) return P[(size_t)k * V * 3 + v * 3 + c];
     if (k < UUO_NUM_POSE_FEATS + UUO_NUM_BETAS) return S[((size_t)v * 3 + c) * 10 + (k - UUO_NUM_POSE_FEATS)];
     return 0.f;
@@ -45,8 +45,8 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
           for (int t = 0; t < 4; ++t)
             P3[((((size_t)c * nunits + u) * ngroups + g) * 64 + l) * 4 + t] =
                 baug(4 * (4 * g + t) + (l >> 4), 16 * u + (l & 15), c);
-  for (int v = 0; v < V; ++v)
-    for (int c = 0; c < 3; ++c) vt3[(size_t)c * VP + v] = vt[v * 3 + c];
+  for (int v = 0; v < VP; ++v)
+    for (int c = 0; c < 3; ++c) vt3[(size_t)c * VP + v] = vt[(v < V ? v : V - 1) * 3 + c];
 
   // per-vertex transposed posedirs rows PT[v][c][k] (contiguous 3*208 floats per vertex) for gather-LBS / backward
   std::vector<float> PT((size_t)V * 3 * UUO_KB, 0.f);
@@ -72,6 +72,11 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
     }
     if (n > max_nnz) max_nnz = n;
   }
+  for (int v = V; v < VP; ++v)
+    for (int n = 0; n < 4; ++n) {
+      Wi[(size_t)v * 4 + n] = Wi[(size_t)(V - 1) * 4 + n];
+      Ww[(size_t)v * 4 + n] = Ww[(size_t)(V - 1) * 4 + n];
+    }
   m->nnz = max_nnz;
 
   // kinematic tree + hoisted joint tables (J = Jt + JS.beta, with Jt = Jreg.v_template, JS = Jreg.shapedirs)

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
                     lz = row16_min(vok ? oz : UUO_BIG);
         const float hx = row16_max(vok ? ox : -UUO_BIG), hy = row16_max(vok ? oy : -UUO_BIG),
                     hz = row16_max(vok ? oz : -UUO_BIG);
-        if (j == 0 && f < F) {
-          float* pbx = bbox + ((size_t)f * nunits + u) * 6;
+        if (j == 0 && f < F && u * 16 < V) {
+          float* pbx = bbox + ((size_t)f * ((V + 15) / 16) + u) * 6;
           pbx[0] = lx; pbx[1] = ly; pbx[2] = lz;
           pbx[3] = hx; pbx[4] = hy; pbx[5] = hz;
         }
@@ -279,8 +279,461 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
 #undef SKIN_MFMA3
 }
 
+// ----------------------------------------------------------------------------------------------------
+// K_B2  skin, self-overlapped variant (sparse weights, the default path).
+// Same work unit as k_skin (16 frames x 16 vertices x 3 coordinates, 168 x v_mfma_f32_16x16x4_f32), but a wave
+// never leaves the matrix pipe idle between units:
+//   * every wave owns a CONTIGUOUS run of (frame tile, unit) tasks of one XCD's vertex range (balanced split:
+//     F=300 -> 1026 tasks per XCD over 256 waves = 4 or 5 each); a block's run touches at most two frame tiles,
+//     whose A operand tiles, skinning matrices and translations are staged in two LDS slots;
+//   * the skinning epilogue (and stores, bounding boxes) of unit t-1 is cut into 12 pieces that are placed between
+//     the MFMA groups of unit t, so its VALU / LDS / store work issues in the shadow of the 32-cycle MFMAs;
+//   * B operands stream through a 7-stage register ring (one stage = 4 K-steps x 3 coordinates = 12 MFMAs), refilled
+//     7 groups (~2 700 cycles) ahead and across the unit boundary, so L2 latency and the in-order vmcnt behind the
+//     epilogue's stores stay off the critical path;
+//   * stores go through raw buffer instructions (out-of-range lanes are dropped by the bounds check, no exec
+//     juggling inside the MFMA stream): one 12-byte store per vertex and frame.
+// XCD x (blockIdx & 7) works on units [x*nunits/8, (x+1)*nunits/8) for all frame tiles: 2.3 MB of the blend basis
+// per XCD L2.
+// ----------------------------------------------------------------------------------------------------
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+#define SK2_RING 7
+#define SK2_NPOS_LOG2 5  // 32 blocks per XCD: one 8-wave block per CU
+#define SK2_MAX_FT 31  // frame tiles per launch (a block's task run must stay within two frame tiles)
+
+struct Sk2Unit {   // one task (wave-uniform)
+  int u;           // unit
+  int i0;          // first frame (within the launch) of the tile; >= F marks "nothing to store"
+  int slot;        // LDS slot of the tile
+};
+
+// min / max over the 16 lanes of each DPP row for six values at once: v_min/v_max with a row-rotated DPP operand,
+// one rotate distance per call (8, 4, 2, 1 -> the box is on every lane).  The six chains are interleaved so that no
+// instruction reads a register written less than five instructions earlier (a DPP read needs two wait states after
+// a VALU write; the leading s_nop covers the producers of the first one).
+#define SK2_BOX_STEP(R, l0, l1, l2, h0, h1, h2)                           \
+  asm("s_nop 1\n"                                                         \
+      "v_min_f32_dpp %0, %0, %0 " R " row_mask:0xf bank_mask:0xf\n"       \
+      "v_min_f32_dpp %1, %1, %1 " R " row_mask:0xf bank_mask:0xf\n"       \
+      "v_min_f32_dpp %2, %2, %2 " R " row_mask:0xf bank_mask:0xf\n"       \
+      "v_max_f32_dpp %3, %3, %3 " R " row_mask:0xf bank_mask:0xf\n"       \
+      "v_max_f32_dpp %4, %4, %4 " R " row_mask:0xf bank_mask:0xf\n"       \
+      "v_max_f32_dpp %5, %5, %5 " R " row_mask:0xf bank_mask:0xf\n"       \
+      : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(h0), "+v"(h1), "+v"(h2))
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Sk2Epi {      // registers of the epilogue that runs in the shadow of the next unit's MFMAs
+  f32x4 R[6];        // skinning-matrix rows of two joints
+  f32x2 T[6];        // blended 3x4 transform of the frame in flight, row r = (T[2r], T[2r+1])
+  float4 tr;         // translation of that frame
+  float o[3];        // skinned vertex
+  float bx[6];       // box candidates (min xyz, max xyz)
+  // per-unit addresses (formed once when the unit's skin weights arrive): LDS byte address of the lane's four
+  // joints' matrices for frame 4*kq, of its translation, and the byte offsets of its first frame's vertex / box
+  unsigned wa[4], tra, vo, bo;
+};
+
+// One twelfth of one epilogue piece.  Piece = (frame register e = piece / 3, part = piece % 3): parts 0 and 1 blend the
+// skinning matrices of joints {0,1} / {2,3}, part 2 applies the transform, stores the vertex and the unit's box.
+// `k` (0..11) is the MFMA of the group after which the slice is issued.  FP32 MFMAs and VALU instructions share the
+// SIMD's FP32 datapath on gfx950 (they do not overlap, measured), so the slices are written for the fewest VALU
+// instructions: LDS addresses are per-unit bases plus immediate offsets, matrix rows are blended as register pairs
+// (v_pk_fma_f32 on adjacent registers), frames past F fall outside the buffers' ranges by construction and padding
+// vertices duplicate the last real one (model.hip), so neither needs a select.
+template <bool BBOX>
+__device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& E, const float4& ww, const f32x4& p0,
+                                          const f32x4& p1, const f32x4& p2, const char* sTb, const char* sTrb,
+                                          const unsigned v12, const unsigned n24, __amdgpu_buffer_rsrc_t rv,
+                                          __amdgpu_buffer_rsrc_t rb) {
+  const int e = piece / 3, part = piece - 3 * e;
+  if (part < 2) {
+    if (k == 0 || k == 1) {
+      const int n = 2 * part + k;
+      const f32x4* pt = reinterpret_cast<const f32x4*>(sTb + E.wa[n] + e * (UUO_NUM_JOINTS * 48));
+      E.R[3 * k + 0] = pt[0];
+      E.R[3 * k + 1] = pt[1];
+      E.R[3 * k + 2] = pt[2];
+    } else if (k >= 3 && k <= 8) {
+      const int h = (k - 3) / 3, row = (k - 3) - 3 * h;  // joint half, matrix row
+      const int n = 2 * part + h;                        // joint: weight = component n of ww
+      // v_pk_fma_f32 on register pairs: the weight is one half of an aligned pair of the float4 it was loaded into
+      // and is broadcast to both result lanes by op_sel / op_sel_hi; the matrix row halves are pairs of the ds_read
+      const f32x2 wp = (n < 2) ? f32x2{ww.x, ww.y} : f32x2{ww.z, ww.w};
+      const f32x4 r = E.R[3 * h + row];
+      const f32x2 rlo = __builtin_shufflevector(r, r, 0, 1), rhi = __builtin_shufflevector(r, r, 2, 3);
+      if (part == 0 && h == 0) {
+        if (n & 1) {
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(E.T[2 * row]) : "v"(wp), "v"(rlo));
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(E.T[2 * row + 1]) : "v"(wp), "v"(rhi));
+        } else {
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(E.T[2 * row]) : "v"(wp), "v"(rlo));
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(E.T[2 * row + 1]) : "v"(wp), "v"(rhi));
+        }
+      } else {
+        if (n & 1) {
+          asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(E.T[2 * row]) : "v"(wp), "v"(rlo));
+          asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(E.T[2 * row + 1]) : "v"(wp), "v"(rhi));
+        } else {
+          asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(E.T[2 * row]) : "v"(wp), "v"(rlo));
+          asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(E.T[2 * row + 1]) : "v"(wp), "v"(rhi));
+        }
+      }
+    }
+  } else {
+    if (k == 0) {
+      E.tr = *reinterpret_cast<const float4*>(sTrb + E.tra + e * 16);
+    } else if (k >= 1 && k <= 3) {
+      const int c = k - 1;
+      const float px = p0[e], py = p1[e], pz = p2[e];
+      E.o[c] = fmaf(E.T[2 * c + 1][0], pz, fmaf(E.T[2 * c][1], py, E.T[2 * c][0] * px)) + E.T[2 * c + 1][1];
+    } else if (k == 4) {
+      E.o[0] += E.tr.x; E.o[1] += E.tr.y; E.o[2] += E.tr.z;
+      u32x3 o = {__builtin_bit_cast(unsigned, E.o[0]), __builtin_bit_cast(unsigned, E.o[1]),
+                 __builtin_bit_cast(unsigned, E.o[2])};
+      __builtin_amdgcn_raw_buffer_store_b96(o, rv, E.vo + e * v12, 0, 0);
+    } else if (BBOX && k == 5) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) E.bx[c] = E.bx[3 + c] = E.o[c];
+    } else if (BBOX && k == 6) {
+      SK2_BOX_STEP("row_ror:8", E.bx[0], E.bx[1], E.bx[2], E.bx[3], E.bx[4], E.bx[5]);
+    } else if (BBOX && k == 7) {
+      SK2_BOX_STEP("row_ror:4", E.bx[0], E.bx[1], E.bx[2], E.bx[3], E.bx[4], E.bx[5]);
+    } else if (BBOX && k == 8) {
+      SK2_BOX_STEP("row_ror:2", E.bx[0], E.bx[1], E.bx[2], E.bx[3], E.bx[4], E.bx[5]);
+    } else if (BBOX && k == 9) {
+      SK2_BOX_STEP("row_ror:1", E.bx[0], E.bx[1], E.bx[2], E.bx[3], E.bx[4], E.bx[5]);
+    } else if (BBOX && k == 10) {
+      u32x3 lo = {__builtin_bit_cast(unsigned, E.bx[0]), __builtin_bit_cast(unsigned, E.bx[1]),
+                  __builtin_bit_cast(unsigned, E.bx[2])};
+      u32x3 hi = {__builtin_bit_cast(unsigned, E.bx[3]), __builtin_bit_cast(unsigned, E.bx[4]),
+                  __builtin_bit_cast(unsigned, E.bx[5])};
+      const unsigned boff = E.bo + e * n24;
+      __builtin_amdgcn_raw_buffer_store_b96(lo, rb, boff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b96(hi, rb, boff + 12u, 0, 0);
+    }
+  }
+}
+
+// per-unit addresses of the epilogue (see Sk2Epi): 24-bit multiplies (full rate), everything else folds into immediates
+__device__ __forceinline__ void sk2_unit_addresses(Sk2Epi& E, const Sk2Unit& P, const int4& wi, const int kq, const int j,
+                                                   const int V, const unsigned v12, const unsigned n24) {
+  const unsigned rowbase = (unsigned)(P.slot * UUO_FT + 4 * kq) * (UUO_NUM_JOINTS * 48);
+  E.wa[0] = __umul24((unsigned)wi.x, 48u) + rowbase;
+  E.wa[1] = __umul24((unsigned)wi.y, 48u) + rowbase;
+  E.wa[2] = __umul24((unsigned)wi.z, 48u) + rowbase;
+  E.wa[3] = __umul24((unsigned)wi.w, 48u) + rowbase;
+  E.tra = (unsigned)(P.slot * UUO_FT + 4 * kq) * 16u;
+  const unsigned f0 = (unsigned)(P.i0 + 4 * kq);
+  const int v = P.u * 16 + j;
+  E.vo = (__umul24(f0, v12) + (unsigned)v * 12u) | (v < V ? 0u : 0x80000000u);
+  E.bo = (__umul24(f0, n24) + (unsigned)P.u * 24u) | (j == 0 ? 0u : 0x80000000u);
+}
+
+__device__ unsigned long long g_sk2_stamps[2048 * 16];  // debug (UUO_SK2_VAR=9): per-wave shader-clock stamps
+
+template <bool BBOX, int VAR>
+__global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restrict__ P3v, const float* __restrict__ vt3,
+                                                            const int* __restrict__ Wi, const float* __restrict__ Ww,
+                                                            const float* __restrict__ pfaT, const float* __restrict__ A,
+                                                            const float* __restrict__ trans, float* __restrict__ verts,
+                                                            float* __restrict__ bbox, int F, int V, int VP, int nFT) {
+  __shared__ float4 sA[2 * UUO_KP * UUO_FT / 4];               // [slot][14][64]
+  __shared__ f32x4 sT[2 * UUO_FT * UUO_NUM_JOINTS * 3];        // [slot][i][j][3]
+  __shared__ float4 sTr[2 * UUO_FT];                            // [slot][i] translation
+  __shared__ int sQ[64];                                        // sQ[0] = next unclaimed task of the block
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned long long stamp0 = (VAR & 8) ? __builtin_readcyclecounter() : 0ull;
+  const int j = lane & 15, kq = lane >> 4;
+  const int nunits = VP / 16;      // units of the blend-basis table (padded)
+  const int nur = (V + 15) / 16;   // units that hold vertices: the box table's stride, the task space
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;  // grid = 8 XCDs x SK2_NPOS blocks
+  // Task space: slice x = units [x*nur/8, (x+1)*nur/8), tasks of a slice ordered (frame tile, unit), slices back to
+  // back.  XCD x (= blockIdx & 7) takes the x-th eighth of that list -- its own slice give or take a few tasks of
+  // the neighbour, so every XCD's L2 holds one slice of the basis and no XCD has more than ceil(total / 8) tasks
+  // (F = 300: 8 189 tasks, 1 023 or 1 024 per XCD, 31 or 32 per block, exactly 8 per SIMD).  The block's waves claim
+  // its tasks one at a time from a counter in LDS: the two waves of a SIMD do not share it evenly (the older wave
+  // wins the issue slot), a static split would leave the younger one with most of its units when its partner retires.
+  const int ntot = nFT * nur;
+  const int xlo = (int)(((unsigned)ntot * (unsigned)xcd) >> 3), xhi = (int)(((unsigned)ntot * (unsigned)(xcd + 1)) >> 3);
+  const int tb0 = xlo + (((xhi - xlo) * pos) >> SK2_NPOS_LOG2), tb1 = xlo + (((xhi - xlo) * (pos + 1)) >> SK2_NPOS_LOG2);
+  if (tb1 <= tb0) return;  // block-uniform
+  // The block's tasks lie in at most two of three segments (checked on the host, sk2_fits): (slice a, tile ftA),
+  // (slice a, tile ftA + 1), (slice a + 1, tile 0).  Segment 1 uses LDS slot 0, the other one slot 1.
+  int xa = 0;
+  while (xa < 7 && nFT * (((xa + 1) * nur) >> 3) <= tb0) ++xa;
+  const int ua0 = (xa * nur) >> 3, ub0 = ((xa + 1) * nur) >> 3;
+  const int nua = ub0 - ua0;
+  const int Sa = nFT * ua0, Sb = nFT * ub0;          // first task of slice a / slice a + 1
+  const int ftA = (tb0 - Sa) / nua;
+  const int g1 = Sa + ftA * nua;                     // first task of (slice a, ftA)
+  const int g2 = (g1 + nua < Sb) ? g1 + nua : Sb;    // end of segment 1
+  const int ftB = (tb1 - 1 < Sb) ? ftA + 1 : 0;      // frame tile of slot 1
+  const int nslots = (tb1 > g2) ? 2 : 1;
+
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(verts, 0, F * V * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(bbox, 0, BBOX ? F * nur * 24 : 0, 0x00020000);
+  // the blend basis, template and skin weights are addressed through buffer resources: one address VGPR each,
+  // everything else scalar
+  const unsigned cplane = (unsigned)nunits * SKIN_GROUPS * 1024u;  // bytes per coordinate plane
+  const __amdgpu_buffer_rsrc_t rp =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(P3v), 0, (int)(3u * cplane), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwi = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(Wi), 0, VP * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ww), 0, VP * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vt3), 0, VP * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(g_sk2_stamps, 0, (VAR & 8) ? 2048 * 16 * 8 : 0, 0x00020000);
+  const unsigned lane16 = lane * 16, j16 = j * 16, j4 = j * 4;
+#define SK2_LDB(c, ubase, g) \
+  __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, lane16, (ubase) + (c)*cplane + (g)*1024u, 0))
+#define SK2_DECODE(U, t_)                                                        \
+  {                                                                              \
+    const bool s1_ = (t_) < g2;                                                  \
+    const int base_ = s1_ ? g1 : ((t_) < Sb ? g2 : Sb);                          \
+    (U).u = (((t_) < Sb) ? ua0 : ub0) + (t_)-base_;                              \
+    (U).i0 = (s1_ ? ftA : ftB) * UUO_FT;                                         \
+    (U).slot = s1_ ? 0 : 1;                                                      \
+  }
+
+  const unsigned long long stampS = (VAR & 8) ? __builtin_readcyclecounter() : 0ull;
+  // stage the block's (one or two) frame tiles; every load is issued before the first LDS store (one round trip),
+  // and before the wave's B stream so that the tiles are not queued behind 21 KB of basis rows per wave
+  constexpr int NA = UUO_KP * UUO_FT / 4, NT = UUO_FT * UUO_NUM_JOINTS * 3;  // float4 per slot: 896 + 1152
+  constexpr int PER = (2 * (NA + NT) + SKIN_WAVES * 64 - 1) / (SKIN_WAVES * 64);  // 8 per thread
+  float4 tmp[PER];
+  float4 trv = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float4* gA0 = reinterpret_cast<const float4*>(pfaT + (size_t)ftA * UUO_KP * UUO_FT);
+    const float4* gA1 = reinterpret_cast<const float4*>(pfaT + (size_t)ftB * UUO_KP * UUO_FT);
+    const float4* gT0 = reinterpret_cast<const float4*>(A + (size_t)ftA * UUO_FT * UUO_NUM_JOINTS * 12);
+    const float4* gT1 = reinterpret_cast<const float4*>(A + (size_t)ftB * UUO_FT * UUO_NUM_JOINTS * 12);
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + r * SKIN_WAVES * 64;  // [0, 2 NA): A tiles of slot 0, 1; then the skinning matrices
+      tmp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NA) tmp[r] = gA0[i];
+      else if (i < 2 * NA) { if (nslots > 1) tmp[r] = gA1[i - NA]; }
+      else if (i < 2 * NA + NT) tmp[r] = gT0[i - 2 * NA];
+      else if (i < 2 * NA + 2 * NT) { if (nslots > 1) tmp[r] = gT1[i - 2 * NA - NT]; }
+    }
+    if (tid < 2 * UUO_FT) {
+      const int f = ((tid < UUO_FT) ? ftA : ftB) * UUO_FT + (tid & (UUO_FT - 1));
+      if (trans && f < F && (tid < UUO_FT || nslots > 1))
+        trv = make_float4(trans[(size_t)f * 3], trans[(size_t)f * 3 + 1], trans[(size_t)f * 3 + 2], 0.f);
+    }
+  }
+
+  // first task of the wave: its B stream (L2 / HBM latency) is started before the LDS tiles are written
+  int t_cur = tb0 + wave;
+  const bool active = t_cur < tb1;  // wave-uniform
+  if (!active) t_cur = tb0;
+  Sk2Unit cur, prv, nxt;
+  SK2_DECODE(cur, t_cur);
+  prv.u = cur.u; prv.i0 = F; prv.slot = 0;  // nothing to store for the first unit's "previous" epilogue
+  nxt = cur;
+  unsigned pb = (unsigned)cur.u * (SKIN_GROUPS * 1024u);
+  float tn0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, cur.u * 64, 0));
+  float tn1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 4 + cur.u * 64, 0));
+  float tn2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 8 + cur.u * 64, 0));
+  f32x4 rbuf[3][SK2_RING];
+#pragma unroll
+  for (int s = 0; s < SK2_RING; ++s) {
+    rbuf[0][s] = SK2_LDB(0, pb, s);
+    rbuf[1][s] = SK2_LDB(1, pb, s);
+    rbuf[2][s] = SK2_LDB(2, pb, s);
+  }
+
+  if (tid < 64) sQ[tid] = (tid == 0) ? tb0 + SKIN_WAVES : 0;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int i = tid + r * SKIN_WAVES * 64;
+    if (i < 2 * NA) sA[i] = tmp[r];
+    else if (i < 2 * (NA + NT)) sT[i - 2 * NA] = __builtin_bit_cast(f32x4, tmp[r]);
+  }
+  if (tid < 2 * UUO_FT) sTr[tid] = trv;
+  __syncthreads();
+  const unsigned long long stamp1 = (VAR & 8) ? __builtin_readcyclecounter() : 0ull;
+  if (!active) return;  // wave-uniform
+
+  int4 wi = make_int4(0, 0, 0, 0);                // skin weights of the unit whose epilogue is running
+  float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 wn_i = wi;
+  float4 wn_w = ww;
+  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;  // accumulators of the previous unit
+  Sk2Epi E;
+  const char* sTb = reinterpret_cast<const char*>(sT);
+  const char* sTrb = reinterpret_cast<const char*>(sTr);
+  const unsigned v12 = (unsigned)V * 12u, n24 = (unsigned)nur * 24u;  // bytes per frame of vertices / boxes
+  sk2_unit_addresses(E, prv, wi, kq, j, V, v12, n24);
+  int nunits_done = 0;
+  bool more = true;
+
+  while (more) {
+    // claim the next task: lane 0 adds 1 to the block's counter, the other lanes add 0 to private words (no exec
+    // juggling, no bank conflict); the result is consumed a few groups later
+    const int claimed = __hip_atomic_fetch_add(&sQ[lane], lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned pbn = pb;
+    int t_nxt = t_cur;
+    const float4* pa = sA + cur.slot * (UUO_KP * UUO_FT / 4) + lane;
+    f32x4 acc0 = {tn0, tn0, tn0, tn0}, acc1 = {tn1, tn1, tn1, tn1}, acc2 = {tn2, tn2, tn2, tn2};
+    float4 ra[2];
+    ra[0] = pa[0];
+    // The unit is written as 14 groups x 12 (MFMA, slice) pairs with a scheduling fence after every pair, so the
+    // previous unit's epilogue is spread evenly through the MFMA stream (loads and LDS reads get their latency
+    // covered, the refills stay 7 groups ahead).
+#pragma unroll
+    for (int g = 0; g < SKIN_GROUPS; ++g) {
+      const int st = g % SK2_RING;
+      const float4 av = ra[g & 1];
+      const int part = g % 3;
+      const int k_aread = (g < 12 && part == 2) ? 11 : 9;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int ks = k / 3, c = k - 3 * ks;
+        const float a = (ks == 0) ? av.x : (ks == 1) ? av.y : (ks == 2) ? av.z : av.w;
+        if (VAR & 4) {
+          asm volatile("" ::"v"(a), "v"(rbuf[c][st][ks]));
+        } else if (c == 0) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rbuf[0][st][ks], acc0, 0, 0, 0);
+        } else if (c == 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rbuf[1][st][ks], acc1, 0, 0, 0);
+        } else {
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rbuf[2][st][ks], acc2, 0, 0, 0);
+        }
+        if (!(VAR & 1) && g < 12) sk2_slice<BBOX>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb);
+        if (k == k_aread && g + 1 < SKIN_GROUPS) ra[(g + 1) & 1] = pa[(g + 1) * 64];
+        if (g == 2 && k == 11) {  // the claim has landed: decode the next task (or keep re-reading this one)
+          const int t_n = __builtin_amdgcn_readfirstlane(claimed);
+          more = t_n < tb1;
+          t_nxt = more ? t_n : t_cur;
+          SK2_DECODE(nxt, t_nxt);
+          pbn = (unsigned)nxt.u * (SKIN_GROUPS * 1024u);
+        }
+        // Loads that the next unit needs at its very first group are issued early: vmcnt retires in order, so
+        // waiting for them also waits for every ring refill issued before them -- at g = 3 those are due anyway.
+        if (g == 3 && k == 10) {
+          wn_i = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rwi, j16, cur.u * 256, 0));
+          wn_w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rww, j16, cur.u * 256, 0));
+          tn0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, nxt.u * 64, 0));
+          tn1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 4 + nxt.u * 64, 0));
+          tn2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 8 + nxt.u * 64, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(VAR & 2)) {  // refill the ring stage this group has just consumed: 7 groups (~2 700 cycles) of lead
+        const unsigned ub = (g + SK2_RING < SKIN_GROUPS) ? pb : pbn;
+        const int gg = (g + SK2_RING) % SKIN_GROUPS;
+        rbuf[0][st] = SK2_LDB(0, ub, gg);
+        rbuf[1][st] = SK2_LDB(1, ub, gg);
+        rbuf[2][st] = SK2_LDB(2, ub, gg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (VAR & 8) {  // stamp of this unit's end, written straight to memory by lane 0 (other lanes out of range)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const unsigned long long c = __builtin_readcyclecounter();
+      const u32x2 cv = {(unsigned)c, (unsigned)(c >> 32)};
+      const unsigned so = (unsigned)(((blockIdx.x * SKIN_WAVES + wave) * 16 + 2 + (nunits_done < 8 ? nunits_done : 7)) * 8);
+      __builtin_amdgcn_raw_buffer_store_b64(cv, rst, so | (lane == 0 ? 0u : 0x80000000u), 0, 0);
+    }
+    ++nunits_done;
+    q0 = acc0; q1 = acc1; q2 = acc2;
+    wi = wn_i; ww = wn_w;
+    prv = cur; cur = nxt; pb = pbn; t_cur = t_nxt;
+    sk2_unit_addresses(E, prv, wi, kq, j, V, v12, n24);
+  }
+#undef SK2_LDB
+#undef SK2_DECODE
+  // epilogue of the wave's last unit
+#pragma unroll
+  for (int g = 0; g < 12; ++g) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sk2_slice<BBOX>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb);
+  }
+  if ((VAR & 8) && lane == 0) {
+    unsigned long long* o = g_sk2_stamps + (size_t)(blockIdx.x * SKIN_WAVES + wave) * 16;
+    o[0] = stamp0; o[1] = stamp1;
+    o[10] = __builtin_readcyclecounter();
+    o[11] = (unsigned long long)nunits_done;
+    o[12] = stampS;
+  }
+}
+
+// true when every block's tasks of k_skin2 lie in at most two of the three segments it can address (see the kernel)
+static bool sk2_fits(int nFT, int nur, int npos) {
+  if (nur < 8) return false;
+  const int ntot = nFT * nur;
+  for (int x = 0; x < 8; ++x) {
+    const int xlo = (int)(((long)ntot * x) >> 3), xhi = (int)(((long)ntot * (x + 1)) >> 3);
+    for (int pos = 0; pos < npos; ++pos) {
+      const int tb0 = xlo + (((xhi - xlo) * pos) >> SK2_NPOS_LOG2), tb1 = xlo + (((xhi - xlo) * (pos + 1)) >> SK2_NPOS_LOG2);
+      if (tb1 <= tb0) continue;
+      int xa = 0;
+      while (xa < 7 && nFT * (((xa + 1) * nur) >> 3) <= tb0) ++xa;
+      const int ua0 = (xa * nur) >> 3, ub0 = ((xa + 1) * nur) >> 3, nua = ub0 - ua0;
+      const int Sa = nFT * ua0, Sb = nFT * ub0;
+      const int ftA = (tb0 - Sa) / nua;
+      const int g1 = Sa + ftA * nua;
+      const int g2 = (g1 + nua < Sb) ? g1 + nua : Sb;
+      const bool seg2 = tb1 > g2 && g2 < Sb;   // tasks of (slice a, ftA + 1)
+      const bool seg3 = tb1 > Sb;              // tasks of (slice a + 1, tile 0)
+      if (seg2 && seg3) return false;
+      if (seg2 && tb1 > g2 + nua) return false;                              // would reach tile ftA + 2
+      if (seg3 && (xa >= 7 || tb1 - Sb > (((xa + 2) * nur) >> 3) - ub0)) return false;  // past tile 0 of slice a + 1
+    }
+  }
+  return true;
+}
+
+static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
+                              const float* trans, float* verts, float* bbox);
+
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
                     float* verts, float* bbox) {
+  static const int force_v1 = getenv("UUO_SKIN_V1") ? atoi(getenv("UUO_SKIN_V1")) : 0;  // ablation / comparison only
+  const int nur = (m->V + 15) / 16;  // units with vertices = stride of the box table
+  const int npos = 1 << SK2_NPOS_LOG2;  // 8 XCDs x 32 CUs, one 8-wave block per CU
+  if (m->nnz > 4 || force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+  const int nFT_all = (F + UUO_FT - 1) / UUO_FT;
+  for (int ft0 = 0; ft0 < nFT_all; ft0 += SK2_MAX_FT) {
+    const int nFT = (nFT_all - ft0 < SK2_MAX_FT) ? nFT_all - ft0 : SK2_MAX_FT;
+    const int f0 = ft0 * UUO_FT;
+    const int Fl = (F - f0 < nFT * UUO_FT) ? F - f0 : nFT * UUO_FT;
+    if (!sk2_fits(nFT, nur, npos)) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+    const float* pf = pfaT + (size_t)ft0 * UUO_KP * UUO_FT;
+    const float* pA = A + (size_t)f0 * UUO_NUM_JOINTS * 12;
+    const float* pt = trans ? trans + (size_t)f0 * 3 : nullptr;
+    float* pv = verts + (size_t)f0 * m->V * 3;
+    static const int var2 = getenv("UUO_SK2_VAR") ? atoi(getenv("UUO_SK2_VAR")) : 0;  // ablation (timing) only
+#define SK2_LAUNCH(BB, VAR)                                                                             \
+  hipLaunchKernelGGL((k_skin2<BB, VAR>), dim3(8 * npos), dim3(SKIN_WAVES * 64), 0, s,                   \
+                     reinterpret_cast<const float4*>(m->P3), m->vt3, m->Wi, m->Ww, pf, pA, pt, pv,      \
+                     (BB) ? bbox + (size_t)f0 * nur * 6 : (float*)nullptr, Fl, m->V, m->VP, nFT)
+    if (!bbox) SK2_LAUNCH(false, 0);
+    else if (var2 == 1) SK2_LAUNCH(true, 1);
+    else if (var2 == 2) SK2_LAUNCH(true, 2);
+    else if (var2 == 4) SK2_LAUNCH(true, 4);
+    else if (var2 == 16) SK2_LAUNCH(false, 0);
+    else if (var2 == 8) SK2_LAUNCH(true, 8);
+    else if (var2 == 9) SK2_LAUNCH(true, 9);
+    else if (var2 == 10) SK2_LAUNCH(true, 10);
+    else if (var2 == 11) SK2_LAUNCH(true, 11);
+    else if (var2 == 12) SK2_LAUNCH(true, 12);
+    else if (var2 == 24) SK2_LAUNCH(false, 8);
+    else SK2_LAUNCH(true, 0);
+#undef SK2_LAUNCH
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int uuo_debug_skin_stamps(unsigned long long* h_out) {  // 2048 waves x 8 stamps (UUO_SK2_VAR=9)
+  UUO_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sk2_stamps), sizeof(unsigned long long) * 2048 * 16));
+  return 0;
+}
+
+static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
+                              const float* trans, float* verts, float* bbox) {
   const int nFT = (F + UUO_FT - 1) / UUO_FT;
   const int nunits = m->VP / 16;
   // vertex ranges per frame tile: one resident round of <= 256 blocks, every wave gets at least one unit

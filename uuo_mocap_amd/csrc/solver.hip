@@ -1044,7 +1044,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
   A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
-  A((void**)&fit->bbox, (size_t)F * (model->VP / 16) * 6 * sizeof(float));
+  A((void**)&fit->bbox, (size_t)F * ((model->V + 15) / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));
   A((void**)&fit->mask, (size_t)F * M * sizeof(float));

@@ -95,7 +95,7 @@ struct uuo_fit {
   float* pfaT = nullptr;            // [nFT][14][64][4]: A operand (pose features | betas) in MFMA-operand order
   float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
-  float* bbox = nullptr;            // [F][VP/16][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
+  float* bbox = nullptr;            // [F][ceil(V/16)][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
