@@ -40,13 +40,14 @@ def parse():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
     ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation")
+    ap.add_argument("--inflight", type=int, default=1, help="sequences fitted concurrently per GPU (parallel.fit_many)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=3, help="closure evaluations per stage type timed on the CPU")
     return ap.parse_args()
 
 
 def fit_once(smpl, seq, cfg, dev):
-    from uuo_mocap_amd.multimodal import LAST_RUN_STATS, multimodal_video_mocap
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
 
     import contextlib
     import io
@@ -54,7 +55,7 @@ def fit_once(smpl, seq, cfg, dev):
     with contextlib.redirect_stdout(io.StringIO()):  # the reference prints stage banners unconditionally
         out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
                                      save_stages=False, smpl_inference=smpl)
-    return out, copy.deepcopy(dict(LAST_RUN_STATS))
+    return out, copy.deepcopy(dict(last_run_stats()))
 
 
 def eval_counts(stats):
@@ -169,14 +170,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        fit_once(smpl, seqs[i], cfg, dev)
+    from uuo_mocap_amd.parallel import fit_many
+
+    fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
     barrier()
     t0 = time.perf_counter()
-    all_stats = []
-    for i in range(args.warmup, n_seq):
-        _, st = fit_once(smpl, seqs[i], cfg, dev)
-        all_stats.append(st)
+    all_stats = [st for _, st in fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev),
+                                          inflight=args.inflight, device=dev)]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -217,7 +217,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.yaml full fit, F=%d frames x M=%d markers, synthetic SMPL-shaped model, one "
                                    "sequence per step per GPU" % (args.config, F, M if not limb else 10),
-                       "frames": F, "markers": M, "sequences_per_gpu": args.steps},
+                       "frames": F, "markers": M, "sequences_per_gpu": args.steps,
+                       "sequences_in_flight": args.inflight},
             "closure_evals_per_step": total_evals / max(args.steps, 1), "closure_evals_last_step": n_eval,
             "frame_evals_per_s": world * total_evals * F / elapsed if world == 1 else None,
             "roofline": roofline,

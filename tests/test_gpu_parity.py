@@ -41,9 +41,10 @@ def test_native_library_loaded():
 
 
 # ------------------------------------------------------------------------------------------------ SMPL forward
-@pytest.mark.parametrize("F,shared_betas", [(8, False), (45, True), (70, False)])
+@pytest.mark.parametrize("F,shared_betas", [(1, True), (8, False), (17, False), (45, True), (70, False), (520, True)])
 def test_smpl_forward_matches_oracle(smpl, oracle_smpl, tables, dev, F, shared_betas):
-    """vertices within 1e-4 m (north_star tolerance); observed ~1e-6."""
+    """vertices within 1e-4 m (north_star tolerance); observed ~1e-6.  F = 1 / 17 are ragged frame tiles, F = 520 is
+    more than the 31 frame tiles one skin launch covers (two launches)."""
     g = torch.Generator().manual_seed(F)
     rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
     betas = torch.randn(1 if shared_betas else F, 10, generator=g)
@@ -490,3 +491,108 @@ def test_packaged_configs_run_end_to_end(smpl, dev, cfg_name, limb, F, M):
     verts = smpl(out["pose_body"].to(dev), out["betas"].to(dev), out["root_orient"].to(dev), out["trans"].to(dev))["vertices"]
     score = weighted_chamfer_distance(markers, verts, get_marker_mask(markers))[0].item()
     assert np.isfinite(score) and score < 0.05, score  # mean squared marker-to-surface distance stays small (m^2)
+
+
+# ------------------------------------------------------------------------------------------------ skin kernel variants
+def _closure_buffers(prob, F, V):
+    import ctypes
+
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+    nur = (V + 15) // 16
+    verts = np.zeros((F, V, 3), np.float32)
+    bbox = np.zeros((F, nur, 6), np.float32)
+    lib.uuo_debug_fit_buffers.restype = ctypes.c_int
+    lib.uuo_debug_fit_buffers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    torch.cuda.synchronize()
+    assert lib.uuo_debug_fit_buffers(prob.fit, verts.ctypes.data, bbox.ctypes.data) == 0
+    return verts, bbox
+
+
+@pytest.mark.parametrize("F", [16, 33, 300])
+def test_unit_boxes_bound_their_vertices_exactly(smpl, dev, F):
+    """The pruned nearest-neighbour search is exact only if every unit's box is the exact fp32 min / max of the
+    unit's 16 vertices as stored: compare the box table of a chamfer closure with numpy min / max of its vertices
+    (bit-exact), and the vertices with the standalone forward (round-off)."""
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    seq = make_sequence(smpl.tables, seed=3, num_frames=F, num_markers=20)
+    cfg = packaged_config("video_mocap")
+    markers = _t(seq.markers.get_points(), dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    trans = torch.median(markers, dim=1)[0]
+    prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, cfg)
+    x = prob.pack(trans, torch.zeros(F, 1, 1, device=dev), o_betas, o_pose)
+    prob.evaluate(x)
+    V = 6890
+    verts, bbox = _closure_buffers(prob, F, V)
+    nur = bbox.shape[1]
+    vp = np.empty((F, nur * 16, 3), np.float32)
+    vp[:, :V] = verts
+    vp[:, V:] = verts[:, V - 1:V]  # padding lanes repeat the last vertex
+    vp = vp.reshape(F, nur, 16, 3)
+    ref = np.concatenate([vp.min(2), vp.max(2)], -1)
+    assert np.array_equal(ref, bbox)
+    fwd = smpl(o_pose, o_betas.expand(F, 10), root, trans)["vertices"].cpu().numpy()
+    # the closure re-normalises the rotations (6D Gram-Schmidt, Rz(0)): equal to round-off, not bitwise
+    np.testing.assert_allclose(fwd, verts, atol=2e-5, rtol=0)
+
+
+def test_skin_kernel_variants_agree_bitwise(smpl, dev, tmp_path):
+    """The generic skin kernel (UUO_SKIN_V1=1: static schedule, used for dense skin weights or shapes the pipelined
+    kernel cannot tile) and the default pipelined kernel issue the same MFMA / FMA chains per vertex: bit-equal
+    vertices.  The variant is chosen per process, so the generic one runs in a child process."""
+    import subprocess
+    import sys
+
+    F = 37
+    g = torch.Generator().manual_seed(5)
+    rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
+    betas = torch.randn(F, 10, generator=g)
+    trans = torch.randn(F, 3, generator=g)
+    np.savez(tmp_path / "in.npz", rot=rot.numpy(), betas=betas.numpy(), trans=trans.numpy())
+    out = smpl(rot[:, 1:].to(dev), betas.to(dev), rot[:, :1].to(dev), trans.to(dev))["vertices"].cpu().numpy()
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from uuo_mocap_amd.body_model import synthetic_smpl\n"
+        "from uuo_mocap_amd.smpl import SmplInference\n"
+        "d = np.load(%r)\n"
+        "dev = torch.device('cuda:0')\n"
+        "s = SmplInference(dev, tables=synthetic_smpl(0))\n"
+        "rot = torch.from_numpy(d['rot']).to(dev)\n"
+        "o = s(rot[:, 1:], torch.from_numpy(d['betas']).to(dev), rot[:, :1], torch.from_numpy(d['trans']).to(dev))\n"
+        "np.save(%r, o['vertices'].cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), str(tmp_path / "v1.npy"))
+    env = dict(os.environ, UUO_SKIN_V1="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    v1 = np.load(tmp_path / "v1.npy")
+    assert np.array_equal(out, v1)
+
+
+def test_sequences_in_flight_give_identical_fits(smpl, dev):
+    """parallel.fit_many overlaps independent sequences on one GPU (own threads, streams, workspace groups); each fit
+    must be the one it would have been alone."""
+    from uuo_mocap_amd.multimodal import multimodal_video_mocap
+    from uuo_mocap_amd.parallel import fit_many
+
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = 15
+    seqs = [make_sequence(smpl.tables, seed=20 + i, num_frames=24, num_markers=12) for i in range(3)]
+
+    def fit(sq):
+        import copy
+
+        out = multimodal_video_mocap(sq.img_smpl, copy.deepcopy(sq.markers), dev, cfg, offset=0, print_options=[],
+                                     save_stages=False, smpl_inference=smpl)
+        return {k: np.asarray(out[k]) for k in ("trans", "pose_body", "betas", "root_orient")}
+
+    alone = fit_many(seqs, fit, inflight=1, device=dev)
+    together = fit_many(seqs, fit, inflight=3, device=dev)
+    for a, b in zip(alone, together):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k

@@ -53,6 +53,7 @@ struct BwdArgs {
 #define BWD_NW 4  // waves per frame block (8 waves needs <= 128 VGPRs for 2 blocks/CU and spills: 43 -> 73 us)
 template <bool SPARSE>
 __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
+  __builtin_amdgcn_s_setprio(2);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
   __shared__ float spf[UUO_KB];
@@ -500,6 +501,7 @@ struct FinArgs {
 };
 
 __global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ double sh[32][32];
   const int tid = threadIdx.x;
   const int comp = tid & 31, grp = tid >> 5;  // 32 groups of frames, components 0..UUO_FP-1

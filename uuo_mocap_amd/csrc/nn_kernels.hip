@@ -104,6 +104,7 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
 __global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int mper, const float* __restrict__ x,
                                                   const float* __restrict__ verts, const float* __restrict__ bbox,
                                                   unsigned long long* __restrict__ packed, int* __restrict__ stats) {
+  __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ float sbox[CULL_MAXU * 6];
   __shared__ float smx[CULL_MG * 3];
   __shared__ float sub[CULL_MG];

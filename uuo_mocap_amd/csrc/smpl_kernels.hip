@@ -13,6 +13,7 @@
 __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree* __restrict__ tree, int F,
                                                    float* __restrict__ pfaT, float* __restrict__ A,
                                                    float* __restrict__ jposed) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   const int f = blockIdx.x;
   const int l = threadIdx.x;

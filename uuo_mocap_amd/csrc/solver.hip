@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
                                                   const float* __restrict__ gp, const float* __restrict__ d, float t,
                                                   size_t stride, int chunk_len,
                                                   double* __restrict__ part /* [chunks][LB_ROWS][3] */) {
+  __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   // The new pair y = g - g_prev, s = t d is formed on the fly (and stored to the candidate slot by the first row
   // group), so no separate pass writes it before the dots.
   const int chunk = blockIdx.x;
@@ -182,20 +183,28 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int c
   float* sn = S + (size_t)cand * stride;
   const bool writer = (blockIdx.y == 0 && wave == 0);
   const int e0 = chunk * chunk_len;
-  const int e1 = min((int)stride, e0 + chunk_len);  // chunk_len is a multiple of 256; padding beyond n is zero
+  const int e1 = min((int)stride, e0 + chunk_len);  // chunk_len is a multiple of 256; entries past n are masked below
   double a00 = 0.0, a01 = 0.0, a02 = 0.0, a10 = 0.0, a11 = 0.0, a12 = 0.0;
   for (int i = e0 + lane * 4; i < e1; i += 256) {
-    const float4 vg = *reinterpret_cast<const float4*>(g + i);
+    float4 vg = *reinterpret_cast<const float4*>(g + i);
     const float4 vp = *reinterpret_cast<const float4*>(gp + i);
     const float4 vd = *reinterpret_cast<const float4*>(d + i);
-    const float4 vy = make_float4(vg.x - vp.x, vg.y - vp.y, vg.z - vp.z, vg.w - vp.w);
-    const float4 vs = make_float4(vd.x * t, vd.y * t, vd.z * t, vd.w * t);
+    float4 vy = make_float4(vg.x - vp.x, vg.y - vp.y, vg.z - vp.z, vg.w - vp.w);
+    float4 vs = make_float4(vd.x * t, vd.y * t, vd.z * t, vd.w * t);
+    float4 r0 = c0 == 1 ? vs : (c0 == 2 ? vy : *reinterpret_cast<const float4*>(src0 + i));
+    float4 r1 = c1 == 1 ? vs : (c1 == 2 ? vy : *reinterpret_cast<const float4*>(src1 + i));
+    if (i + 4 > n) {
+      // The rows are read in 16-byte pieces up to the chunk's end; entries past n belong to whatever problem used
+      // the workspace before (a larger one leaves its gradient there) and must not reach the dot products.
+#define LB_MASK(c, k_)                                                       \
+      if (i + k_ >= n) { vg.c = 0.f; vy.c = 0.f; vs.c = 0.f; r0.c = 0.f; r1.c = 0.f; }
+      LB_MASK(x, 0) LB_MASK(y, 1) LB_MASK(z, 2) LB_MASK(w, 3)
+#undef LB_MASK
+    }
     if (writer) {
       *reinterpret_cast<float4*>(yn + i) = vy;
       *reinterpret_cast<float4*>(sn + i) = vs;
     }
-    const float4 r0 = c0 == 1 ? vs : (c0 == 2 ? vy : *reinterpret_cast<const float4*>(src0 + i));
-    const float4 r1 = c1 == 1 ? vs : (c1 == 2 ? vy : *reinterpret_cast<const float4*>(src1 + i));
 #define LB_ACC(c)                                   \
     a00 += (double)r0.c * (double)vy.c;             \
     a01 += (double)r0.c * (double)vs.c;             \
@@ -240,6 +249,7 @@ __device__ __forceinline__ int tri_index(int i, int j, int k) {  // j >= i, row-
 
 __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist, int cand,
                                                    const double* __restrict__ part, LbDev* __restrict__ st, int stop) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ double U[LB_TRI];
   __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH];
   __shared__ double rd[LB_ROWS * 3];
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const floa
                                                        const float* __restrict__ Y, const float* __restrict__ g,
                                                        size_t stride, LbDev* __restrict__ st, float* __restrict__ d,
                                                        const float* __restrict__ x, float t, float* __restrict__ xt) {
+  __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass
   __shared__ double scy[LB_MAXH + 8], scs[LB_MAXH + 8];
   __shared__ int sslot[LB_MAXH + 8];

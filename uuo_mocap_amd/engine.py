@@ -27,6 +27,9 @@ STOP_REASONS = ["max_iter", "max_eval", "tolerance_grad", "tolerance_change(step
 _tls = threading.local()
 
 
+WORKSPACE_GROUP_STRIDE = 64  # slots per group
+
+
 def set_workspace_slot(slot: int):
     """Selects which per-(F, M) workspace the calling thread uses.  Independent solves that run concurrently
     (one host thread + one HIP stream each, e.g. the yaw hypotheses of multimodal_video_mocap) must use
@@ -34,8 +37,19 @@ def set_workspace_slot(slot: int):
     _tls.slot = int(slot)
 
 
+def set_workspace_group(group: int):
+    """Selects the block of workspace slots the calling thread's slots index into.  One group per sequence in
+    flight (parallel.fit_many): two sequences fitted concurrently never meet in a workspace.  Worker threads do not
+    inherit it: the code that spawns them passes `workspace_group()` on."""
+    _tls.group = int(group)
+
+
+def workspace_group() -> int:
+    return getattr(_tls, "group", 0)
+
+
 def workspace_slot() -> int:
-    return getattr(_tls, "slot", 0)
+    return workspace_group() * WORKSPACE_GROUP_STRIDE + getattr(_tls, "slot", 0)
 
 
 def _require_cuda(t: torch.Tensor, name: str):

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .body_model import SMPL_JOINT_NAMES
-from .engine import PartProblem, set_workspace_slot
+from .engine import PartProblem, set_workspace_group, set_workspace_slot, workspace_group
 from .losses import chamfer_distance
 from .transforms import compute_root_orient_z
 
@@ -138,9 +138,12 @@ def find_best_part_fits(
     trans0 = torch.median(markers, dim=1)[0]
     valid = torch.ones(num_frames, dtype=torch.bool, device=device)
 
+    group = workspace_group()  # worker threads do not inherit thread-locals
+
     def fit_subtree(slot: int, subtree, stream):
         """One candidate body part (reference :416-597): L-BFGS over [z, trans, betas], then the ranking score and the
         per-marker labels.  Candidates are independent solves: each worker thread has its own stream and workspace."""
+        set_workspace_group(group)
         set_workspace_slot(slot)
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         with ctx:

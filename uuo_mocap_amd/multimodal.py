@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict
 
@@ -16,7 +17,7 @@ import numpy as np
 import torch
 
 from . import markers_utils, optimization
-from .engine import set_workspace_slot
+from .engine import set_workspace_group, set_workspace_slot, workspace_group
 from .markers_utils import find_best_part_fits, get_aabb, get_aabb_volume, segment_rigid
 from .optimization import (compute_marker_labels_from_coords, compute_nearest_points, get_marker_mask,
                            optim_chamfer, optim_markers, weighted_chamfer_distance)
@@ -25,6 +26,13 @@ from .transforms import compute_root_orient_z, normalize_rot
 
 #: per-stage solver statistics of the most recent call (n_iter / n_eval / device ms per solve)
 LAST_RUN_STATS: Dict = {}
+_tls_stats = threading.local()
+
+
+def last_run_stats() -> Dict:
+    """Solver statistics of the calling thread's last multimodal_video_mocap call (LAST_RUN_STATS is the
+    process-wide copy, ambiguous when sequences are fitted concurrently)."""
+    return getattr(_tls_stats, "last", {})
 
 
 def pad(sequence, offset):
@@ -143,9 +151,12 @@ def multimodal_video_mocap(
     if config["recompute_marker_labels"] and run_marker:
         raise NotImplementedError("recompute_marker_labels is False in every shipped config")
 
+    group = workspace_group()  # worker threads do not inherit thread-locals
+
     def fit_hypothesis(index: int, root_orient_angle: float, stream):
         """One yaw hypothesis (reference multimodal.py:463-574): chamfer L-BFGS -> placement -> marker L-BFGS.
         Hypotheses are independent, so each runs on its own host thread, HIP stream and solver workspace."""
+        set_workspace_group(group)
         set_workspace_slot(index)
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         local = {}
@@ -299,4 +310,5 @@ def multimodal_video_mocap(
         output["chain"] = filter_output["chain"]
     LAST_RUN_STATS.clear()
     LAST_RUN_STATS.update(stats)
+    _tls_stats.last = stats
     return output

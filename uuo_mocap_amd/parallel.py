@@ -65,3 +65,44 @@ def fit_sharded(sequence_ids: Sequence[int], fit_fn: Callable[[int], Dict], devi
     for part in gathered:
         merged.update(part)
     return merged, elapsed
+
+
+def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None) -> List:
+    """Fits independent sequences `fit_fn(item)` on ONE GPU with up to `inflight` of them in progress at a time
+    (each on its own host thread, HIP stream and workspace group).  Sequences are independent in the reference
+    (test/test.py:57-112 loops over them); overlapping them fills the GPU while another sequence is in a phase
+    with fewer than four hypotheses alive (part stage, the hypotheses' ragged ends, the final marker stage).
+    Results come back in the order of `items`."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .engine import set_workspace_group, set_workspace_slot
+
+    if inflight <= 1 or len(items) <= 1:
+        return [fit_fn(it) for it in items]
+    use_cuda = device is not None and torch.device(device).type == "cuda"
+    main = torch.cuda.current_stream(device) if use_cuda else None
+    free_groups = list(range(1, inflight + 1))  # group 0 stays with the calling thread
+    import threading
+
+    lock = threading.Lock()
+
+    def run(it):
+        with lock:
+            g = free_groups.pop()
+        try:
+            set_workspace_group(g)
+            set_workspace_slot(0)
+            if use_cuda:
+                st = torch.cuda.Stream(device=device)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    out = fit_fn(it)
+                st.synchronize()
+                return out
+            return fit_fn(it)
+        finally:
+            with lock:
+                free_groups.append(g)
+
+    with ThreadPoolExecutor(max_workers=inflight) as pool:
+        return list(pool.map(run, items))
