@@ -808,8 +808,10 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
       UUO_HIP_CHECK(hipMalloc((void**)&ref.pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
       UUO_HIP_CHECK(hipMalloc((void**)&ref.A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
       UUO_HIP_CHECK(hipMalloc((void**)&ref.jp, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 3 * sizeof(float)));
-      UUO_HIP_CHECK(hipMemset(ref.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
-      UUO_HIP_CHECK(hipMemset(ref.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      // on the caller's stream: a null-stream memset is not ordered with torch's non-blocking streams and could land
+      // after the first pose_prep has written the tiles
+      UUO_HIP_CHECK(hipMemsetAsync(ref.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float), s));
+      UUO_HIP_CHECK(hipMemsetAsync(ref.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float), s));
       ref.cap = nFT;
     }
     sc = ref;

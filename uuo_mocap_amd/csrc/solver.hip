@@ -652,6 +652,8 @@ static int lbws_create(int n, int hist, LbWs** out) {
   if (e == hipSuccess) e = hipMemset(w->S, 0, (size_t)w->cap * n * sizeof(float));
   if (e == hipSuccess) e = hipMemset(w->Y, 0, (size_t)w->cap * n * sizeof(float));
   if (e == hipSuccess) e = hipMemset(w->vecs, 0, (size_t)LB_NVEC * n * sizeof(float));
+  // null-stream memsets are not ordered with the (non-blocking) stream the first solve runs on
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     lbws_destroy(w);
     uuo_set_error(std::string("lbfgs workspace: ") + hipGetErrorString(e));
@@ -1068,6 +1070,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
     uuo_fit_destroy(fit);
     return -12;
   }
+  UUO_HIP_CHECK(hipDeviceSynchronize());  // the zero fills above ran on the null stream
   *out = fit;
   return 0;
 }
