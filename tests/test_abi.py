@@ -90,5 +90,14 @@ def test_segment_rigid_and_subtrees_match_oracle(tables):
 
     pts = make_sequence(tables, seed=9, num_frames=20, num_markers=14).markers.get_points()
     assert MU.segment_rigid(pts) == stages_ref.segment_rigid(pts)
+    # the all-pairs evaluation of the rigidity matrix is bit-equal to the reference's per-pair loop
+    rng = np.random.default_rng(3)
+    for F, M in ((300, 50), (20, 14), (7, 3), (1, 4)):
+        p = (rng.standard_normal((F, M, 3)) * 0.4).astype(np.float32)
+        loop = np.zeros((M, M))
+        for i in range(M):
+            for j in range(M):
+                loop[i, j] = np.std(np.linalg.norm(p[:, i] - p[:, j], axis=-1))
+        assert np.array_equal(MU.rigid_distance_matrix(p), loop)
     for k in (2, 5, 12, 24):
         assert MU.get_sub_hierachies(tables.parents, k) == stages_ref.get_sub_hierarchies(tables.parents, k)

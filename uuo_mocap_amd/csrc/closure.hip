@@ -498,6 +498,8 @@ struct FinArgs {
   const float* dir_betas;  // optional direction entries of the shared parameters
   const float* dir_z;
   double* stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
+  unsigned long long* rep_host;  // optional zero-copy report (UuoEvalReport)
+  unsigned long long rep_seq;
 };
 
 __global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
@@ -559,6 +561,15 @@ __global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
       a.stats[2] = sm;
       a.stats[3] = s1;
       a.stats[4] = s2;
+      if (a.rep_host) {
+        // the solver's read-back block {max|d| bits, pad, out[9]} starts one word before stats; words 1..5 are
+        // the values just written, the rest was left by the direction kernels of this iteration
+        const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats) - 1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a.rep_host[i] = blk[i];
+        __threadfence_system();
+        __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -664,7 +675,8 @@ int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return va
 
 // closure evaluation proper; the marker mask must be current (uuo_ensure_mask)
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
-                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats) {
+                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
+                          const UuoEvalReport* report) {
   int rc = 0;
   const uuo_model* m = fit->model;
   const int F = p->F, M = p->M;
@@ -728,6 +740,8 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   fa.dir_betas = d_dir ? d_dir + lay.off_betas : nullptr;
   fa.dir_z = (d_dir && p->stage == UUO_STAGE_PART) ? d_dir + lay.off_z : nullptr;
   fa.stats = d_stats;
+  fa.rep_host = (report && d_stats) ? report->host : nullptr;
+  fa.rep_seq = report ? report->seq : 0ull;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;

@@ -213,6 +213,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// fp64 wave sum on the VALU: four row-rotate steps on both halves of the double (DPP), then the four row totals
+// are read with v_readlane -- no LDS traffic (the __shfl_xor version is 12 ds_bpermute per call)
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false),
+                          __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_d_fast(double v) {
+  v += dpp_rot_d<0x128>(v);
+  v += dpp_rot_d<0x124>(v);
+  v += dpp_rot_d<0x122>(v);
+  v += dpp_rot_d<0x121>(v);
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

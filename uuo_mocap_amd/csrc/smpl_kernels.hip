@@ -325,7 +325,7 @@ struct Sk2Unit {   // one task (wave-uniform)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Sk2Epi {      // registers of the epilogue that runs in the shadow of the next unit's MFMAs
-  f32x4 R[6];        // skinning-matrix rows of two joints
+  f32x4 R[3];        // skinning-matrix rows of the joint being blended
   f32x2 T[6];        // blended 3x4 transform of the frame in flight, row r = (T[2r], T[2r+1])
   float4 tr;         // translation of that frame
   float o[3];        // skinned vertex
@@ -349,19 +349,19 @@ __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& 
                                           __amdgpu_buffer_rsrc_t rb) {
   const int e = piece / 3, part = piece - 3 * e;
   if (part < 2) {
-    if (k == 0 || k == 1) {
-      const int n = 2 * part + k;
+    if (k == 0 || k == 5) {
+      const int n = 2 * part + (k == 5 ? 1 : 0);
       const f32x4* pt = reinterpret_cast<const f32x4*>(sTb + E.wa[n] + e * (UUO_NUM_JOINTS * 48));
-      E.R[3 * k + 0] = pt[0];
-      E.R[3 * k + 1] = pt[1];
-      E.R[3 * k + 2] = pt[2];
-    } else if (k >= 3 && k <= 8) {
-      const int h = (k - 3) / 3, row = (k - 3) - 3 * h;  // joint half, matrix row
+      E.R[0] = pt[0];
+      E.R[1] = pt[1];
+      E.R[2] = pt[2];
+    } else if ((k >= 2 && k <= 4) || (k >= 7 && k <= 9)) {
+      const int h = (k >= 7) ? 1 : 0, row = (k >= 7) ? k - 7 : k - 2;  // joint of the pair, matrix row
       const int n = 2 * part + h;                        // joint: weight = component n of ww
       // v_pk_fma_f32 on register pairs: the weight is one half of an aligned pair of the float4 it was loaded into
       // and is broadcast to both result lanes by op_sel / op_sel_hi; the matrix row halves are pairs of the ds_read
       const f32x2 wp = (n < 2) ? f32x2{ww.x, ww.y} : f32x2{ww.z, ww.w};
-      const f32x4 r = E.R[3 * h + row];
+      const f32x4 r = E.R[row];
       const f32x2 rlo = __builtin_shufflevector(r, r, 0, 1), rhi = __builtin_shufflevector(r, r, 2, 3);
       if (part == 0 && h == 0) {
         if (n & 1) {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void sk2_unit_addresses(Sk2Epi& E, const Sk2Unit& P, 
 __device__ unsigned long long g_sk2_stamps[2048 * 16];  // debug (UUO_SK2_VAR=9): per-wave shader-clock stamps
 
 template <bool BBOX, int VAR>
-__global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restrict__ P3v, const float* __restrict__ vt3,
+__global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_skin2(const float4* __restrict__ P3v, const float* __restrict__ vt3,
                                                             const int* __restrict__ Wi, const float* __restrict__ Ww,
                                                             const float* __restrict__ pfaT, const float* __restrict__ A,
                                                             const float* __restrict__ trans, float* __restrict__ verts,
@@ -558,8 +558,6 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restr
 
   int4 wi = make_int4(0, 0, 0, 0);                // skin weights of the unit whose epilogue is running
   float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
-  int4 wn_i = wi;
-  float4 wn_w = ww;
   f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;  // accumulators of the previous unit
   Sk2Epi E;
   const char* sTb = reinterpret_cast<const char*>(sT);
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restr
       const int st = g % SK2_RING;
       const float4 av = ra[g & 1];
       const int part = g % 3;
-      const int k_aread = (g < 12 && part == 2) ? 11 : 9;
+      const int k_aread = (g < 12 && part == 2) ? 11 : 10;
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
         const int ks = k / 3, c = k - 3 * ks;
@@ -610,11 +608,13 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restr
           SK2_DECODE(nxt, t_nxt);
           pbn = (unsigned)nxt.u * (SKIN_GROUPS * 1024u);
         }
-        // Loads that the next unit needs at its very first group are issued early: vmcnt retires in order, so
-        // waiting for them also waits for every ring refill issued before them -- at g = 3 those are due anyway.
-        if (g == 3 && k == 10) {
-          wn_i = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rwi, j16, cur.u * 256, 0));
-          wn_w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rww, j16, cur.u * 256, 0));
+        // Loads that the next unit needs at its very first group: this unit's skin weights (its epilogue runs during
+        // the next unit; the previous epilogue read the old ones for the last time in piece 10) and the next
+        // template values.  vmcnt retires in order, so waiting for them at the unit boundary also waits for the ring
+        // refills issued before them -- those are the next unit's first groups and are due then anyway.
+        if (g == 11 && k == 10) {
+          wi = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rwi, j16, cur.u * 256, 0));
+          ww = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rww, j16, cur.u * 256, 0));
           tn0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, nxt.u * 64, 0));
           tn1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 4 + nxt.u * 64, 0));
           tn2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 8 + nxt.u * 64, 0));
@@ -639,7 +639,6 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin2(const float4* __restr
     }
     ++nunits_done;
     q0 = acc0; q1 = acc1; q2 = acc2;
-    wi = wn_i; ww = wn_w;
     prv = cur; cur = nxt; pb = pbn; t_cur = t_nxt;
     sk2_unit_addresses(E, prv, wi, kq, j, V, v12, n24);
   }

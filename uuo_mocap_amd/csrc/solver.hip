@@ -136,93 +136,151 @@ __global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* _
   }
 }
 
-// rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
-// grid = (element chunks, row groups of 8); wave w handles rows 2w, 2w+1 of its group; 16-byte loads (rows are
-// padded to a multiple of 64 floats and the padding is zero), the three right-hand vectors are loaded once per
-// position and reused for both rows.
-__device__ __forceinline__ const float* lb_row_ptr(int row, int nact, int count, int head, int cap, int cand,
-                                                   const float* S, const float* Y, const float* g, size_t stride,
-                                                   int* out_row) {
-  if (row < nact) {
-    const int slot = (row < count) ? (head + row) % cap : cand;
-    *out_row = slot;
-    return S + (size_t)slot * stride;
-  }
-  if (row < 2 * nact) {
-    const int r2 = row - nact;
-    const int slot = (r2 < count) ? (head + r2) % cap : cand;
-    *out_row = LB_MAXH + slot;
-    return Y + (size_t)slot * stride;
-  }
-  *out_row = 2 * LB_MAXH;
-  return g;
+// History layout.  S and Y are stored in column blocks of LB_CW floats: element i of slot j lives at
+//   ((i / LB_CW) * capL + j) * LB_CW + i % LB_CW            (capL = allocated slots)
+// so that all the slots of one column block are one contiguous region (capL x 2 KB).  Both passes over the history --
+// the row-wise dots below and the column-wise combination in k_lb_direction -- then stream contiguous memory:
+// a block reads capL consecutive 2-KB pieces instead of 2-KB (or 512-byte) pieces 260 KB apart, which is what
+// HBM pages and the MALL like; the first version (row-major history) reached ~2.5 TB/s however many solves ran.
+#define LB_CW 512
+__device__ __host__ __forceinline__ size_t lb_hist_off(int slot, int i, int capL) {
+  return ((size_t)(i / LB_CW) * capL + slot) * LB_CW + (i % LB_CW);
 }
 
-__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int head, int count, int cand, float* __restrict__ S,
-                                                  float* __restrict__ Y, const float* __restrict__ g,
-                                                  const float* __restrict__ gp, const float* __restrict__ d, float t,
-                                                  size_t stride, int chunk_len,
-                                                  double* __restrict__ part /* [chunks][LB_ROWS][3] */) {
+// rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
+// grid = (column groups, LB_DRS row splits).  A block walks the column blocks of its group; per column block every
+// wave loads the three right-hand vectors (y_new = g - g_prev and s_new = t d are formed on the fly and stored to
+// the candidate slot by split 0) and the 512-column pieces of its rows (row r belongs to wave r mod 4*LB_DRS), all
+// loads of a column block in flight together.  Per-lane fp64 accumulators, one wave reduction per row at the end.
+#define LB_DRS 16                        // row splits
+#define LB_DRW ((LB_ROWS + 4 * LB_DRS - 1) / (4 * LB_DRS))  // rows per wave (7)
+__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int head, int count, int cand,
+                                                  float* __restrict__ S, float* __restrict__ Y,
+                                                  const float* __restrict__ g, const float* __restrict__ gp,
+                                                  const float* __restrict__ d, float t, int ncb, int gcb,
+                                                  double* __restrict__ part /* [groups][LB_ROWS][3] */) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
-  // The new pair y = g - g_prev, s = t d is formed on the fly (and stored to the candidate slot by the first row
-  // group), so no separate pass writes it before the dots.
-  const int chunk = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nact = count + 1;  // active slots incl. the candidate
-  const int nrows = 2 * nact + 1;
-  const int row0 = blockIdx.y * 8 + wave * 2;
-  if (row0 >= nrows) return;
-  const bool two = (row0 + 1) < nrows;
-  int out0, out1 = 0;
-  const float* src0 = lb_row_ptr(row0, nact, count, head, cap, cand, S, Y, g, stride, &out0);
-  const float* src1 = two ? lb_row_ptr(row0 + 1, nact, count, head, cap, cand, S, Y, g, stride, &out1) : src0;
-  // rows that ARE the candidate (not yet in memory): 1 = s_new, 2 = y_new
-  const int c0 = (out0 == cand) ? 1 : (out0 == LB_MAXH + cand ? 2 : 0);
-  const int c1 = (out1 == cand) ? 1 : (out1 == LB_MAXH + cand ? 2 : 0);
-  float* yn = Y + (size_t)cand * stride;
-  float* sn = S + (size_t)cand * stride;
-  const bool writer = (blockIdx.y == 0 && wave == 0);
-  const int e0 = chunk * chunk_len;
-  const int e1 = min((int)stride, e0 + chunk_len);  // chunk_len is a multiple of 256; entries past n are masked below
-  double a00 = 0.0, a01 = 0.0, a02 = 0.0, a10 = 0.0, a11 = 0.0, a12 = 0.0;
-  for (int i = e0 + lane * 4; i < e1; i += 256) {
-    float4 vg = *reinterpret_cast<const float4*>(g + i);
-    const float4 vp = *reinterpret_cast<const float4*>(gp + i);
-    const float4 vd = *reinterpret_cast<const float4*>(d + i);
-    float4 vy = make_float4(vg.x - vp.x, vg.y - vp.y, vg.z - vp.z, vg.w - vp.w);
-    float4 vs = make_float4(vd.x * t, vd.y * t, vd.z * t, vd.w * t);
-    float4 r0 = c0 == 1 ? vs : (c0 == 2 ? vy : *reinterpret_cast<const float4*>(src0 + i));
-    float4 r1 = c1 == 1 ? vs : (c1 == 2 ? vy : *reinterpret_cast<const float4*>(src1 + i));
-    if (i + 4 > n) {
-      // The rows are read in 16-byte pieces up to the chunk's end; entries past n belong to whatever problem used
-      // the workspace before (a larger one leaves its gradient there) and must not reach the dot products.
-#define LB_MASK(c, k_)                                                       \
-      if (i + k_ >= n) { vg.c = 0.f; vy.c = 0.f; vs.c = 0.f; r0.c = 0.f; r1.c = 0.f; }
+  const int grp = blockIdx.x, rs = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wg = rs * 4 + wave;  // wave's index among the 4 * LB_DRS row owners
+  // Stored rows: S slots then Y slots of the `count` pairs already in the history; wave wg owns rows wg + 64 q.
+  // Rows past the end are clamped to row 0 and their result dropped, so the loop below has no per-row branches
+  // and all its loads issue back to back.  The three rows that are not in memory yet (s_new, y_new, g) belong to
+  // wave 0 of split 0, which also stores the new pair.
+  const int nmem = 2 * count;
+  const float* rptr[LB_DRW];
+  int rout[LB_DRW];
+#pragma unroll
+  for (int q = 0; q < LB_DRW; ++q) {
+    const int r = wg + q * 4 * LB_DRS;
+    const bool ok = r < nmem;
+    const int rr = ok ? r : 0;
+    const bool isY = rr >= count;
+    const int slot = (head + (isY ? rr - count : rr)) % cap;
+    rptr[q] = (isY ? Y : S) + (size_t)slot * LB_CW + lane * 4;
+    rout[q] = ok ? (isY ? LB_MAXH + slot : slot) : -1;
+  }
+  const bool special = (rs == 0 && wave == 0);
+  double acc[LB_DRW][3], sp[3][3];
+#pragma unroll
+  for (int q = 0; q < LB_DRW; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
+#pragma unroll
+  for (int a_ = 0; a_ < 3; ++a_) sp[a_][0] = sp[a_][1] = sp[a_][2] = 0.0;
+
+  const int cb0 = grp * gcb, cb1 = min(ncb, cb0 + gcb);
+  // software pipeline over the group's column blocks: the loads of block cb + 1 are issued before block cb is
+  // consumed (6 + 2 * LB_DRW float4 per lane in flight per stage)
+  float4 ng[2], np_[2], nd[2], nr[LB_DRW][2];
+  auto issue = [&](int cb) {
+    const int ibase = cb * LB_CW;
+    const size_t cboff = (size_t)cb * capL * LB_CW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = ibase + h * 256 + lane * 4;  // vectors are padded to a multiple of LB_CW: in-bounds loads
+      ng[h] = *reinterpret_cast<const float4*>(g + i);
+      np_[h] = *reinterpret_cast<const float4*>(gp + i);
+      nd[h] = *reinterpret_cast<const float4*>(d + i);
+    }
+#pragma unroll
+    for (int q = 0; q < LB_DRW; ++q) {
+      nr[q][0] = *reinterpret_cast<const float4*>(rptr[q] + cboff);
+      nr[q][1] = *reinterpret_cast<const float4*>(rptr[q] + cboff + 256);
+    }
+  };
+  if (cb0 < cb1) issue(cb0);
+  for (int cb = cb0; cb < cb1; ++cb) {
+    const int ibase = cb * LB_CW;
+    float4 vg[2], vy[2], vs[2], rv[LB_DRW][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      vg[h] = ng[h];
+      vy[h] = make_float4(ng[h].x - np_[h].x, ng[h].y - np_[h].y, ng[h].z - np_[h].z, ng[h].w - np_[h].w);
+      vs[h] = make_float4(nd[h].x * t, nd[h].y * t, nd[h].z * t, nd[h].w * t);
+    }
+#pragma unroll
+    for (int q = 0; q < LB_DRW; ++q) {
+      rv[q][0] = nr[q][0];
+      rv[q][1] = nr[q][1];
+    }
+    if (cb + 1 < cb1) issue(cb + 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = ibase + h * 256 + lane * 4;
+      // Entries past n belong to whatever problem used the work vectors before (a larger one leaves its gradient
+      // there) and must reach neither the dot products nor the stored pair.
+#define LB_MASK(c, k_) { const bool in_ = i + k_ < n; vg[h].c = in_ ? vg[h].c : 0.f; vy[h].c = in_ ? vy[h].c : 0.f; vs[h].c = in_ ? vs[h].c : 0.f; }
       LB_MASK(x, 0) LB_MASK(y, 1) LB_MASK(z, 2) LB_MASK(w, 3)
 #undef LB_MASK
     }
-    if (writer) {
-      *reinterpret_cast<float4*>(yn + i) = vy;
-      *reinterpret_cast<float4*>(sn + i) = vs;
-    }
-#define LB_ACC(c)                                   \
-    a00 += (double)r0.c * (double)vy.c;             \
-    a01 += (double)r0.c * (double)vs.c;             \
-    a02 += (double)r0.c * (double)vg.c;             \
-    a10 += (double)r1.c * (double)vy.c;             \
-    a11 += (double)r1.c * (double)vs.c;             \
-    a12 += (double)r1.c * (double)vg.c;
-    LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
+#pragma unroll
+    for (int q = 0; q < LB_DRW; ++q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 r = rv[q][h];
+#define LB_ACC(c)                                         \
+        acc[q][0] += (double)r.c * (double)vy[h].c;       \
+        acc[q][1] += (double)r.c * (double)vs[h].c;       \
+        acc[q][2] += (double)r.c * (double)vg[h].c;
+        LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
 #undef LB_ACC
+      }
+    }
+    if (special) {  // wave-uniform: the new pair's own rows and g, and the store of the pair
+      float* yn = Y + ((size_t)cb * capL + cand) * LB_CW + lane * 4;
+      float* sn = S + ((size_t)cb * capL + cand) * LB_CW + lane * 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<float4*>(yn + h * 256) = vy[h];
+        *reinterpret_cast<float4*>(sn + h * 256) = vs[h];
+#define LB_SP(c)                                                                                           \
+        {                                                                                                  \
+          const double y_ = (double)vy[h].c, s_ = (double)vs[h].c, g_ = (double)vg[h].c;                   \
+          sp[0][0] += s_ * y_; sp[0][1] += s_ * s_; sp[0][2] += s_ * g_;                                   \
+          sp[1][0] += y_ * y_; sp[1][1] += y_ * s_; sp[1][2] += y_ * g_;                                   \
+          sp[2][0] += g_ * y_; sp[2][1] += g_ * s_; sp[2][2] += g_ * g_;                                   \
+        }
+        LB_SP(x) LB_SP(y) LB_SP(z) LB_SP(w)
+#undef LB_SP
+      }
+    }
   }
-  a00 = wave_sum_d(a00); a01 = wave_sum_d(a01); a02 = wave_sum_d(a02);
-  a10 = wave_sum_d(a10); a11 = wave_sum_d(a11); a12 = wave_sum_d(a12);
-  if (lane == 0) {
-    double* o = part + ((size_t)chunk * LB_ROWS + out0) * 3;
-    o[0] = a00; o[1] = a01; o[2] = a02;
-    if (two) {
-      double* o1 = part + ((size_t)chunk * LB_ROWS + out1) * 3;
-      o1[0] = a10; o1[1] = a11; o1[2] = a12;
+#pragma unroll
+  for (int q = 0; q < LB_DRW; ++q) {
+    const double a0 = wave_sum_d_fast(acc[q][0]), a1 = wave_sum_d_fast(acc[q][1]), a2 = wave_sum_d_fast(acc[q][2]);
+    if (lane == 0 && rout[q] >= 0) {
+      double* o = part + ((size_t)grp * LB_ROWS + rout[q]) * 3;
+      o[0] = a0; o[1] = a1; o[2] = a2;
+    }
+  }
+  if (special) {
+    const int orow[3] = {cand, LB_MAXH + cand, 2 * LB_MAXH};  // s_new, y_new, g
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_) {
+      const double a0 = wave_sum_d_fast(sp[a_][0]), a1 = wave_sum_d_fast(sp[a_][1]), a2 = wave_sum_d_fast(sp[a_][2]);
+      if (lane == 0) {
+        double* o = part + ((size_t)grp * LB_ROWS + orow[a_]) * 3;
+        o[0] = a0; o[1] = a1; o[2] = a2;
+      }
     }
   }
 }
@@ -491,16 +549,18 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
   }
 }
 
-__global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const float* __restrict__ S,
+__global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
                                                        const float* __restrict__ Y, const float* __restrict__ g,
-                                                       size_t stride, LbDev* __restrict__ st, float* __restrict__ d,
+                                                       LbDev* __restrict__ st, float* __restrict__ d,
                                                        const float* __restrict__ x, float t, float* __restrict__ xt) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
-  // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass
-  __shared__ double scy[LB_MAXH + 8], scs[LB_MAXH + 8];
-  __shared__ int sslot[LB_MAXH + 8];
+  // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass.
+  // One block per column block of the history (LB_CW columns, two per thread): the slots it combines are one
+  // contiguous region; 16 slots (32 loads of 8 bytes per thread) are in flight at a time.
+  __shared__ double scy[LB_MAXH + 16], scs[LB_MAXH + 16];
+  __shared__ int sslot[LB_MAXH + 16];
   const int k = st->count, head = st->head;
-  for (int j = threadIdx.x; j < LB_MAXH + 8; j += 256) {
+  for (int j = threadIdx.x; j < LB_MAXH + 16; j += 256) {
     const bool on = j < k;
     const int sj = on ? (head + j) % cap : 0;
     sslot[j] = sj;
@@ -508,21 +568,25 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const floa
     scs[j] = on ? st->cs[sj] : 0.0;
   }
   __syncthreads();
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 2;  // two elements per thread (rows are 8-byte aligned)
+  const int cb = blockIdx.x;
+  const int c = threadIdx.x * 2;       // column pair inside the block
+  const int i = cb * LB_CW + c;
   float mx = 0.f;
   if (i < n) {
     const float2 gv = *reinterpret_cast<const float2*>(g + i);
     double acc0 = st->cg * (double)gv.x, acc1 = st->cg * (double)gv.y;
-    for (int j0 = 0; j0 < k; j0 += 8) {
-      float2 yv[8], sv[8];
+    const float* Sb = S + (size_t)cb * capL * LB_CW + c;
+    const float* Yb = Y + (size_t)cb * capL * LB_CW + c;
+    for (int j0 = 0; j0 < k; j0 += 16) {
+      float2 yv[16], sv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
-        const size_t off = (size_t)sslot[j0 + u] * stride + i;
-        yv[u] = *reinterpret_cast<const float2*>(Y + off);
-        sv[u] = *reinterpret_cast<const float2*>(S + off);
+      for (int u = 0; u < 16; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
+        const size_t off = (size_t)sslot[j0 + u] * LB_CW;
+        yv[u] = *reinterpret_cast<const float2*>(Yb + off);
+        sv[u] = *reinterpret_cast<const float2*>(Sb + off);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         acc0 += scy[j0 + u] * (double)yv[u].x + scs[j0 + u] * (double)sv[u].x;
         acc1 += scy[j0 + u] * (double)yv[u].y + scs[j0 + u] * (double)sv[u].y;
       }
@@ -546,15 +610,17 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, const floa
 struct Objective {
   int n = 0;
   bool fused_stats = false;  // eval() also writes {loss, g.d, max|g|, sum|g|, g.g} to stats_dev
-  virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev) = 0;
+  virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev,
+                   const UuoEvalReport* report) = 0;
   virtual ~Objective() {}
 };
 
 struct StageObjective : Objective {
   uuo_fit* fit;
   const uuo_problem_t* p;
-  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev) override {
-    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr, dir, stats_dev);
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev,
+           const UuoEvalReport* report) override {
+    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr, dir, stats_dev, report);
   }
 };
 
@@ -594,7 +660,8 @@ __global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const f
 
 struct TestObjective : Objective {
   int kind;
-  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*) override {
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*,
+           const UuoEvalReport*) override {
     hipLaunchKernelGGL(k_test_objective, dim3(1), dim3(256), 0, s, kind, n, x, loss_dev, grad);
     UUO_HIP_CHECK(hipGetLastError());
     return 0;
@@ -610,7 +677,8 @@ struct LbWs {
   double* part = nullptr;
   LbDev* st = nullptr;
   float* loss_dev = nullptr;
-  double* h_out = nullptr;  // pinned
+  double* h_out = nullptr;  // pinned, device-visible: read-back block + sequence word
+  unsigned long long seq = 0;
   int nchunks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -630,7 +698,7 @@ static int lbws_destroy(LbWs* w) {
 static int lbws_create(int n, int hist, LbWs** out) {
   UUO_REQUIRE(hist >= 1 && hist <= LB_MAXH - 4, "lbfgs: history_size must be in [1,100]");
   LbWs* w = new LbWs();
-  n = (n + 255) / 256 * 256;  // row stride: 16-byte loads never straddle rows, padding stays zero
+  n = (n + LB_CW - 1) / LB_CW * LB_CW;  // whole column blocks: 16-byte loads of the work vectors stay in bounds
   w->n_cap = n;
   w->cap = hist + 1;
   w->nchunks = LB_MAXCHUNK;
@@ -645,7 +713,8 @@ static int lbws_create(int n, int hist, LbWs** out) {
   A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
   A((void**)&w->st, sizeof(LbDev));
   A((void**)&w->loss_dev, 16 * sizeof(float));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 32 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) std::memset(w->h_out, 0, 32 * sizeof(double));
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
   if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
@@ -715,8 +784,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   const double lr = opt->lr, tol_grad = opt->tolerance_grad, tol_change = opt->tolerance_change;
   const double c1 = 1e-4, c2 = 0.9;
   const size_t stride = (size_t)w->n_cap;
-  const int nchunks = std::max(1, std::min(LB_MAXCHUNK, (n + 2047) / 2048));
-  const int chunk_len = (((n + nchunks - 1) / nchunks) + 255) / 256 * 256;
+  const int ncb = (n + LB_CW - 1) / LB_CW;                 // column blocks of the history holding this problem
+  const int gcb = (ncb + LB_MAXCHUNK - 1) / LB_MAXCHUNK;   // column blocks per dot-kernel group
+  const int nchunks = (ncb + gcb - 1) / gcb;               // groups = partial sums per Gram entry (<= LB_MAXCHUNK)
   const int nb = (n + 255) / 256;
   const int nstat = std::min(64, nb);
   auto vec = [&](int i) { return w->vecs + (size_t)i * stride; };
@@ -740,11 +810,36 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   double* stats_dev = reinterpret_cast<double*>((char*)w->st + offsetof(LbDev, out));
   int evals_total = 0;
 
-  // evaluate at x_eval into gradient vector gv; statistics against d (or none); read back
+  // evaluate at x_eval into gradient vector gv; statistics against d (or none); read back.
+  // Stage closures report through pinned memory: their finalize kernel copies the read-back block into w->h_out and
+  // then publishes a sequence number that this thread polls -- no copy command, no stream synchronisation.  A stuck
+  // or failed stream is caught by a periodic hipStreamQuery.
+  static const int poll_mode = getenv("UUO_LBFGS_POLL") ? atoi(getenv("UUO_LBFGS_POLL")) : 1;
+  unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(w->h_out);
   auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
     const float* dir = with_dir ? d : (const float*)nullptr;
-    int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr);
+    const bool poll = obj.fused_stats && poll_mode != 0;
+    UuoEvalReport rep;
+    if (poll) {
+      rep.host = rep_words;
+      rep.seq = ++w->seq;
+    }
+    int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr, poll ? &rep : nullptr);
     if (rc) return rc;
+    if (poll) {
+      unsigned long spins = 0;
+      while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls: has the stream died or drained without reporting?
+          const hipError_t q = hipStreamQuery(s);
+          if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
+            uuo_set_error(std::string("lbfgs: closure evaluation did not report: ") + hipGetErrorString(q));
+            return -5;
+          }
+        }
+      }
+      return 0;
+    }
     if (!obj.fused_stats) {
       hipLaunchKernelGGL(k_lb_stats, dim3(nstat), dim3(256), 0, s, n, gv, dir, w->part);
       hipLaunchKernelGGL(k_lb_stats_final, dim3(1), dim3(64), 0, s, nstat, w->part, w->loss_dev, w->st);
@@ -801,12 +896,12 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       } else {
         const int cand = (head + count) % cap;
         const int nrows = 2 * (count + 1) + 1;
-        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, (nrows + 7) / 8), dim3(256), 0, s, n, cap, head, count, cand, w->S,
-                           w->Y, g, vec(ipg), d, (float)t_prev_iter, stride, chunk_len, w->part);
+        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, LB_DRS), dim3(256), 0, s, n, cap, w->cap, head, count, cand, w->S,
+                           w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part);
         static const int small_stop = getenv("UUO_SMALL_STOP") ? atoi(getenv("UUO_SMALL_STOP")) : 0;  // ablation only
         hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        hipLaunchKernelGGL(k_lb_direction, dim3((n + 511) / 512), dim3(256), 0, s, n, cap, w->S, w->Y, g, stride, w->st,
-                           d, xcur, (float)t, xoth);
+        hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(256), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
+                           (float)t, xoth);
       }
       UUO_HIP_CHECK(hipGetLastError());
       prev_loss = loss;
@@ -1167,5 +1262,26 @@ extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
   }
   *ms_out = total / iters;
   lbws_destroy(w);
+  return 0;
+}
+
+// debug hook (not in the public header): host-side cost of `count` launches of a one-thread kernel on `stream`
+// followed by a stream synchronisation; returns microseconds of host time spent enqueueing and in total
+extern "C" int uuo_debug_launch_rate(void* stream, int count, double* us_enqueue, double* us_total) {
+  UUO_REQUIRE(count > 0 && us_enqueue && us_total, "uuo_debug_launch_rate: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LbDev* st = nullptr;
+  UUO_HIP_CHECK(hipMalloc((void**)&st, sizeof(LbDev)));
+  hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, st);
+  UUO_HIP_CHECK(hipStreamSynchronize(s));
+  timespec t0, t1, t2;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < count; ++i) hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, st);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  UUO_HIP_CHECK(hipStreamSynchronize(s));
+  clock_gettime(CLOCK_MONOTONIC, &t2);
+  *us_enqueue = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+  *us_total = (t2.tv_sec - t0.tv_sec) * 1e6 + (t2.tv_nsec - t0.tv_nsec) * 1e-3;
+  (void)hipFree(st);
   return 0;
 }

@@ -130,5 +130,13 @@ int uuo_launch_finalize(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& 
 // closure internals shared with the solver (closure.hip)
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p);
 int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p);
+// Optional zero-copy report of a closure evaluation: the finalize kernel copies the 80-byte block that starts 8 bytes
+// before d_stats (the solver's {max|d| bits, pad, out[9]}) into `host` (pinned, device-visible) and then publishes
+// `seq` in host[10]; the solver polls that word instead of enqueueing a copy and synchronising the stream.
+struct UuoEvalReport {
+  unsigned long long* host = nullptr;  // [11]
+  unsigned long long seq = 0;
+};
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
-                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats);
+                          float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
+                          const UuoEvalReport* report = nullptr);

@@ -5,6 +5,7 @@ nearest-neighbour query runs on the GPU through libuuo_hip.so."""
 from __future__ import annotations
 
 import contextlib
+import functools
 import itertools
 import os
 import queue
@@ -43,16 +44,29 @@ def get_aabb_volume(aabb: torch.Tensor) -> torch.Tensor:
     return d[:, 0] * d[:, 1] * d[:, 2]
 
 
+def rigid_distance_matrix(points: np.ndarray) -> np.ndarray:
+    """mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1)) for every marker pair, as the
+    reference's double loop computes it (markers/markers_utils.py:254-259), evaluated for all pairs at once.  The
+    values are bit-equal to the per-pair calls: the norm is sqrt((dx*dx + dy*dy) + dz*dz) in the input precision and
+    np.std reduces the contiguous frame axis of each pair with the same pairwise summation as the 1-D call."""
+    pts = np.asarray(points)
+    P = np.ascontiguousarray(pts.transpose(1, 2, 0))  # [M, 3, F]
+    d = P[:, None, 0, :] - P[None, :, 0, :]
+    s = d * d
+    d = P[:, None, 1, :] - P[None, :, 1, :]
+    s += d * d
+    d = P[:, None, 2, :] - P[None, :, 2, :]
+    s += d * d
+    np.sqrt(s, out=s)
+    return np.std(s, axis=-1).astype(np.float64)
+
+
 def segment_rigid(points: np.ndarray) -> List[List[int]]:
     """Clusters markers that keep their mutual distance over time (std of the pairwise distance, average-linkage
     agglomerative clustering cut at 5 mm).  points [F, M, 3] -> list of marker-id lists."""
     from sklearn.cluster import AgglomerativeClustering
 
-    num_markers = points.shape[1]
-    mat = np.zeros((num_markers, num_markers))
-    for i in range(num_markers):  # per-pair 1-D reductions, so the fp32 values match the reference's exactly
-        for j in range(num_markers):
-            mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1))
+    mat = rigid_distance_matrix(points)
     labels = AgglomerativeClustering(n_clusters=None, distance_threshold=0.005, metric="precomputed",
                                      linkage="average").fit(mat).labels_
     return [np.where(labels == v)[0].tolist() for v in np.unique(labels).tolist()]
@@ -60,13 +74,21 @@ def segment_rigid(points: np.ndarray) -> List[List[int]]:
 
 def get_sub_hierachies(parents, num_bones: int) -> List[List[int]]:
     """All connected sub-trees of the kinematic tree with exactly `num_bones` joints, enumerated in the reference's
-    order (it decides which candidate wins ties).  Name keeps the reference's spelling."""
+    order (it decides which candidate wins ties).  Name keeps the reference's spelling.  The enumeration depends on
+    the tree and the size only, so it is memoised (the batch runner asks for the same one for every sequence)."""
     parents_np = parents if isinstance(parents, np.ndarray) else parents.detach().cpu().numpy()
-    n = int(parents_np.shape[0])
+    key = (tuple(int(v) for v in parents_np.tolist()), int(num_bones))
+    return [list(st) for st in _sub_hierarchies_cached(key)]
+
+
+@functools.lru_cache(maxsize=64)
+def _sub_hierarchies_cached(key):
+    parents_t, num_bones = key
+    n = len(parents_t)
     num_bones = min(num_bones, n)
     kids: Dict[int, List[int]] = {i: [] for i in range(n)}
     for i in range(1, n):
-        kids[int(parents_np[i])].append(i)
+        kids[int(parents_t[i])].append(i)
     rooted: Dict[int, List[List[int]]] = {}
     for node in reversed(range(n)):  # children carry larger ids, so they are finished first
         options = [[]]
@@ -76,17 +98,23 @@ def get_sub_hierachies(parents, num_bones: int) -> List[List[int]]:
             if cand not in options:
                 options.append(cand)
         rooted[node] = options
-    return [st for node in reversed(range(n)) for st in rooted[node] if len(st) == num_bones]
+    return tuple(tuple(st) for node in reversed(range(n)) for st in rooted[node] if len(st) == num_bones)
 
 
 def remove_approximately_redundant_hierarchies(subtrees_list: List[List[int]], similarity_threshold: float = 0.9):
-    kept = [subtrees_list[0]]
-    for st in subtrees_list[1:]:
+    kept = _retained_hierarchies_cached(tuple(tuple(st) for st in subtrees_list), float(similarity_threshold))
+    print("Retained", str(len(kept)) + "/" + str(len(subtrees_list)), "elements")
+    return [list(st) for st in kept]
+
+
+@functools.lru_cache(maxsize=64)
+def _retained_hierarchies_cached(subtrees, similarity_threshold):
+    kept = [subtrees[0]]
+    for st in subtrees[1:]:
         limit = len(st) * similarity_threshold
         if all(len(set(st) & set(k)) <= limit for k in kept):
             kept.append(st)
-    print("Retained", str(len(kept)) + "/" + str(len(subtrees_list)), "elements")
-    return kept
+    return tuple(kept)
 
 
 def find_best_part_fits(
