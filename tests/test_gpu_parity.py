@@ -596,3 +596,24 @@ def test_sequences_in_flight_give_identical_fits(smpl, dev):
     for a, b in zip(alone, together):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 33, 64, 65, 99, 100])
+def test_direction_coefficients_block_inverse_vs_serial(dev, k):
+    """k_lb_small solves the two triangular recurrences of the L-BFGS two-loop recursion block-wise (inverses of the
+    16 x 16 diagonal blocks); the serial right-looking kernel it replaced stays in the library as the reference.
+    Same Gram data -> same coefficients to fp64 round-off, at block boundaries and at a full history."""
+    import ctypes
+
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+    lib.uuo_debug_small_coeffs.restype = ctypes.c_int
+    lib.uuo_debug_small_coeffs.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for seed in (1, 7):
+        ref = np.zeros(209)
+        new = np.zeros(209)
+        assert lib.uuo_debug_small_coeffs(k, 1, seed, ref.ctypes.data) == 0
+        assert lib.uuo_debug_small_coeffs(k, 0, seed, new.ctypes.data) == 0
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(ref - new).max() <= 1e-12 * scale, (k, seed, np.abs(ref - new).max() / scale)

@@ -305,7 +305,7 @@ __device__ __forceinline__ int tri_index(int i, int j, int k) {  // j >= i, row-
   return i * k - (i * (i - 1)) / 2 + (j - i);
 }
 
-__global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist, int cand,
+__global__ __launch_bounds__(256) void k_lb_small_ref(int nchunks, int cap, int hist, int cand,
                                                    const double* __restrict__ part, LbDev* __restrict__ st, int stop) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ double U[LB_TRI];
@@ -536,6 +536,276 @@ __global__ __launch_bounds__(256) void k_lb_small(int nchunks, int cap, int hist
   __syncthreads();
   if (tid == 0) {
     const double gsum = (wv[LB_MAXH - 4] + wv[LB_MAXH - 3]) + (wv[LB_MAXH - 2] + wv[LB_MAXH - 1]);
+    const double gg = rd[(2 * LB_MAXH) * 3 + 2];
+    st->cg = cg;
+    st->Hdiag = Hdiag;
+    st->head = head;
+    st->count = count;
+    st->dmax_bits = 0u;
+    LbOut* o = reinterpret_cast<LbOut*>(st->out);
+    o->gtd_dir = cg * gg + gsum;
+    o->accepted = accept ? 1.0 : 0.0;
+    o->ys = ys;
+  }
+}
+
+// Same computation as k_lb_small_ref with the dependent chains cut from 2k steps to 2 * ceil(k / 16) block steps:
+// the inverses of the 16 x 16 diagonal blocks of U are computed first (every column of every block is an independent
+// back-substitution of at most 16 steps: 112 lanes at once), after which a block of the triangular solves is a
+// 16 x 16 mat-vec (values fetched with v_readlane inside the block's DPP row) followed by the same right-looking
+// update as before.  8 waves: wave 0 runs the two solves, waves 1-2 invert the blocks, waves 3-5 hold Y.Y^T.
+#define LB_NB ((LB_MAXH + 15) / 16)
+__global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist, int cand,
+                                                   const double* __restrict__ part, LbDev* __restrict__ st, int stop) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  __shared__ double U[LB_TRI];
+  __shared__ double Xl[LB_NB][16][16];  // inverses of the diagonal blocks of U (upper triangular, [row][col])
+  __shared__ double rinvL[LB_MAXH + 8];
+  __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH];
+  __shared__ double rd[LB_ROWS * 3];
+  __shared__ int slot_of[LB_MAXH];
+  __shared__ double wpart[3][LB_MAXH + 24];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int head = st->head, count = st->count;
+  const int nact = count + 1;
+  // ---- reduce the partial dots of the active rows (fixed chunk order -> deterministic)
+  for (int e = tid; e < LB_ROWS * 3; e += 512) {
+    const int row = e / 3;
+    const int slot = (row < LB_MAXH) ? row : row - LB_MAXH;
+    bool active = (row == 2 * LB_MAXH);
+    if (!active && slot < cap) {
+      const int rel = (slot - head + cap) % cap;
+      active = (rel < count) || (slot == cand);
+    }
+    double acc = 0.0;
+    if (active) {
+      double v[LB_MAXCHUNK];
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) v[c] = (c < nchunks) ? part[(size_t)c * LB_ROWS * 3 + e] : 0.0;
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) acc += v[c];
+    }
+    rd[e] = acc;
+  }
+  __syncthreads();
+  // ---- candidate row / column of the Gram matrices
+  const double ys = rd[cand * 3 + 0];              // s_new . y_new
+  const double yy = rd[(LB_MAXH + cand) * 3 + 0];  // y_new . y_new
+  for (int r = tid; r < nact; r += 512) {
+    const int slot = (r < count) ? (head + r) % cap : cand;
+    st->SY[slot * LB_MAXH + cand] = rd[slot * 3 + 0];              // s_slot . y_new
+    st->SY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 1];  // s_new . y_slot
+    st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];
+    st->YY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 0];
+    Sg[slot] = rd[slot * 3 + 2];
+    Yg[slot] = rd[(LB_MAXH + slot) * 3 + 2];
+  }
+  __threadfence_block();
+  __syncthreads();
+  const bool accept = ys > 1e-10;
+  double Hdiag = st->Hdiag;
+  if (accept) {
+    if (count == hist)
+      head = (head + 1) % cap;  // drop the oldest; the candidate slot becomes the newest
+    else
+      count += 1;
+    Hdiag = ys / yy;
+  }
+  const int k = count;
+  for (int j = tid; j < k; j += 512) slot_of[j] = (head + j) % cap;
+  __syncthreads();
+  if (stop == 1) return;
+  // ---- stage U in LDS (logical order); waves 3..5 fetch their rows of Y.Y^T into registers meanwhile
+  const int j0 = lane, j1 = lane + 64;
+  double yv0[LB_YR], yv1[LB_YR];  // waves 3..5: rows i = (wave-3) + 3 r of YY, columns j0 / j1
+  if (wave >= 3 && wave <= 5) {
+    const int sl0 = (j0 < k) ? slot_of[j0] : 0, sl1 = (j1 < k) ? slot_of[j1] : 0;
+#pragma unroll
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 3) + 3 * r;
+      const int si = (i < k) ? slot_of[i] : 0;
+      yv0[r] = (i < k && j0 < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
+      yv1[r] = (i < k && j1 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
+    }
+  } else {
+    const int wrow = (wave < 3) ? wave : wave - 3;  // 5 staging waves: 0,1,2,6,7 -> 0..4
+    constexpr int RB = 16;  // rows per wave pass, all loads in flight at once
+    for (int i0 = wrow * RB; i0 < k; i0 += 5 * RB) {
+      double v[RB][2];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          v[r][h] = (i < k && j >= i && j < k) ? st->SY[slot_of[i] * LB_MAXH + slot_of[j]] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          if (i < k && j >= i && j < k) U[tri_index(i, j, k)] = v[r][h];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (stop == 2) return;
+  if (tid < k) rinvL[tid] = 1.0 / U[tri_index(tid, tid, k)];
+  __syncthreads();
+  const int nblk = (k + 15) >> 4;
+  // ---- inverses of the diagonal blocks: lane (b, c) solves T x = e_c by back-substitution, T = U[lo:hi, lo:hi]
+  if (wave >= 1 && wave <= 2) {
+    const int idx = (wave - 1) * 64 + lane;
+    const int b = idx >> 4, c = idx & 15;
+    if (b < nblk) {
+      const int lo = b << 4;
+      const int nb = min(16, k - lo);
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = 0.0;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) {
+        if (r < nb && r <= c && c < nb) {
+          if (r == c) {
+            x[r] = rinvL[lo + r];
+          } else {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = r + 1; m < 16; ++m)
+              if (m <= c) acc = fma(U[tri_index(lo + r, lo + m, k)], x[m], acc);
+            x[r] = -acc * rinvL[lo + r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Xl[b][r][c] = x[r];
+    }
+  }
+  __syncthreads();
+  if (stop == 3) return;
+  double a0 = 0.0, a1 = 0.0;
+  if (wave == 0) {
+    const double sg0 = (j0 < k) ? Sg[slot_of[j0]] : 0.0, sg1 = (j1 < k) ? Sg[slot_of[j1]] : 0.0;
+    double r0 = 0.0, r1 = 0.0;
+    // ---- loop 1 (newest -> oldest):  U al = -S.g  (upper triangular), blocks from the last to the first
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int lo = b << 4, hi = min(lo + 16, k);
+      const bool inhi = lo >= 64;
+      const int base = lo & 63;                 // first lane of the block's DPP row
+      const int t = (lane - base) & 15;         // this lane's row inside the block (meaningful for block lanes)
+      const bool mine = lane >= base && lane < base + 16;
+      double xrow[16];                          // row t of the block inverse
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) xrow[s_] = mine ? Xl[b][t][s_] : 0.0;
+      const double rhs = inhi ? (-sg1 - r1) : (-sg0 - r0);
+      double mya = 0.0;
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) mya = fma(xrow[s_], bcast_lane_d(rhs, base + s_), mya);
+      if (mine) {
+        if (inhi) a1 = mya; else a0 = mya;
+      }
+      // rows above the block (right-looking update with the block's al values)
+      if (lo > 0) {
+        double ablk[16], un[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) ablk[s_] = bcast_lane_d(mya, base + s_);
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j0 < lo && lo + s_ < hi) ? U[tri_index(j0, lo + s_, k)] : 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) r0 = fma(ablk[s_], un[s_], r0);
+        if (lo > 64) {
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j1 < lo && lo + s_ < hi) ? U[tri_index(j1, lo + s_, k)] : 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) r1 = fma(ablk[s_], un[s_], r1);
+        }
+      }
+    }
+    if (j0 < k) al[j0] = a0;
+    if (j1 < k) al[j1] = a1;
+  }
+  __syncthreads();
+  if (stop == 4) return;
+  const double cg = -Hdiag;
+  for (int j = tid; j < k; j += 512) cy_s[j] = -Hdiag * al[j];
+  __syncthreads();
+  // ---- w = YY cy: YY is symmetric, so lane j accumulates sum_i YY[i][j] cy_i over the rows its wave fetched
+  if (wave >= 3 && wave <= 5) {
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 3) + 3 * r;
+      const double c = (i < k) ? cy_s[i] : 0.0;
+      acc0 = fma(yv0[r], c, acc0);
+      acc1 = fma(yv1[r], c, acc1);
+    }
+    wpart[wave - 3][j0] = acc0;
+    if (j1 < LB_MAXH) wpart[wave - 3][j1] = acc1;
+  }
+  __syncthreads();
+  for (int j = tid; j < k; j += 512) wv[j] = (wpart[0][j] + wpart[1][j]) + wpart[2][j];
+  __syncthreads();
+  if (stop == 5) return;
+  if (wave == 0) {
+    // ---- loop 2 (oldest -> newest):  U^T cs = D al - (cg Y.g + YY cy)  (lower triangular), blocks first to last
+    const double v0 = (j0 < k) ? a0 * U[tri_index(j0, j0, k)] - (cg * Yg[slot_of[j0]] + wv[j0]) : 0.0;
+    const double v1 = (j1 < k) ? a1 * U[tri_index(j1, j1, k)] - (cg * Yg[slot_of[j1]] + wv[j1]) : 0.0;
+    double q0 = 0.0, q1 = 0.0, c0 = 0.0, c1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      const int lo = b << 4, hi = min(lo + 16, k);
+      const bool inhi = lo >= 64;
+      const int base = lo & 63;
+      const int t = (lane - base) & 15;
+      const bool mine = lane >= base && lane < base + 16;
+      double xcol[16];  // column t of the block inverse = row t of its transpose
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) xcol[s_] = mine ? Xl[b][s_][t] : 0.0;
+      const double rhs = inhi ? (v1 - q1) : (v0 - q0);
+      double myc = 0.0;
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) myc = fma(xcol[s_], bcast_lane_d(rhs, base + s_), myc);
+      if (mine) {
+        if (inhi) c1 = myc; else c0 = myc;
+      }
+      // rows below the block
+      if (hi < k) {
+        double cblk[16], un[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) cblk[s_] = bcast_lane_d(myc, base + s_);
+        if (hi <= 64) {
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j0 >= hi && j0 < k && lo + s_ < hi) ? U[tri_index(lo + s_, j0, k)] : 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) q0 = fma(cblk[s_], un[s_], q0);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j1 >= hi && j1 < k && lo + s_ < hi) ? U[tri_index(lo + s_, j1, k)] : 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) q1 = fma(cblk[s_], un[s_], q1);
+      }
+    }
+    if (j0 < k) cs_s[j0] = c0;
+    if (j1 < k) cs_s[j1] = c1;
+  }
+  __syncthreads();
+  // ---- publish: coefficients by slot, g.d from the Gram data
+  double gpart = 0.0;
+  for (int j = tid; j < k; j += 512) {
+    const int sj = slot_of[j];
+    gpart += cy_s[j] * Yg[sj] + cs_s[j] * Sg[sj];
+    st->cy[sj] = cy_s[j];
+    st->cs[sj] = cs_s[j];
+  }
+  gpart = wave_sum_d(gpart);
+  if (lane == 0) wpart[0][LB_MAXH + wave] = gpart;  // free tail of the scratch rows
+  __syncthreads();
+  if (tid == 0) {
+    double gsum = 0.0;
+    for (int w_ = 0; w_ < 8; ++w_) gsum += wpart[0][LB_MAXH + w_];
     const double gg = rd[(2 * LB_MAXH) * 3 + 2];
     st->cg = cg;
     st->Hdiag = Hdiag;
@@ -899,7 +1169,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, LB_DRS), dim3(256), 0, s, n, cap, w->cap, head, count, cand, w->S,
                            w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part);
         static const int small_stop = getenv("UUO_SMALL_STOP") ? atoi(getenv("UUO_SMALL_STOP")) : 0;  // ablation only
-        hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
+        static const int small_ref = getenv("UUO_SMALL_REF") ? atoi(getenv("UUO_SMALL_REF")) : 0;  // comparison only
+        if (small_ref)
+          hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
+        else
+          hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(256), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
                            (float)t, xoth);
       }
@@ -1253,7 +1527,10 @@ extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
     const double one = 1.0;
     UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
     UUO_HIP_CHECK(hipEventRecord(w->ev0, nullptr));
-    hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop);
+    if (stop >= 100)
+      hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 100);
+    else
+      hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop);
     UUO_HIP_CHECK(hipEventRecord(w->ev1, nullptr));
     UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
     float ms = 0.f;
@@ -1283,5 +1560,54 @@ extern "C" int uuo_debug_launch_rate(void* stream, int count, double* us_enqueue
   *us_enqueue = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
   *us_total = (t2.tv_sec - t0.tv_sec) * 1e6 + (t2.tv_nsec - t0.tv_nsec) * 1e-3;
   (void)hipFree(st);
+  return 0;
+}
+
+// debug/test hook (not in the public header): direction coefficients of one k_lb_small call on a synthetic history
+// of k pairs (deterministic pseudo-random Gram data, moderately conditioned), with the reference (serial) or the
+// block-inverse kernel; out = [cs(LB_MAXH) | cy(LB_MAXH) | g.d]
+extern "C" int uuo_debug_small_coeffs(int k, int use_ref, int seed, double* out) {
+  UUO_REQUIRE(k >= 1 && k <= LB_MAXH - 4 && out, "uuo_debug_small_coeffs: bad arguments");
+  LbWs* w = nullptr;
+  int rc = lbws_create(4096, LB_MAXH - 4, &w);
+  if (rc) return rc;
+  auto rnd = [&](unsigned a, unsigned b) {
+    unsigned long long z = (unsigned long long)(a * 1315423911u + b * 2654435761u + (unsigned)seed * 97u) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) / 9007199254740992.0 - 0.5;
+  };
+  std::vector<double> SY((size_t)LB_MAXH * LB_MAXH, 0.0), YY((size_t)LB_MAXH * LB_MAXH, 0.0);
+  for (int i = 0; i < LB_MAXH; ++i)
+    for (int j = 0; j < LB_MAXH; ++j) {
+      SY[(size_t)i * LB_MAXH + j] = (i == j) ? 1.0 + 0.5 * rnd(i, i) + 0.02 * i : 0.3 * rnd(i, j) / (1.0 + 0.2 * std::abs(i - j));
+      const double yy = (i == j) ? 3.0 + rnd(i + 500, i) : 0.4 * rnd(std::min(i, j) + 900, std::max(i, j)) / (1.0 + 0.1 * std::abs(i - j));
+      YY[(size_t)i * LB_MAXH + j] = yy;
+    }
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, SY), SY.data(), SY.size() * sizeof(double), hipMemcpyHostToDevice));
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, YY), YY.data(), YY.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double> part((size_t)LB_MAXCHUNK * LB_ROWS * 3, 0.0);
+  for (int r = 0; r < LB_ROWS; ++r)
+    for (int c = 0; c < 3; ++c) part[(size_t)r * 3 + c] = (r == k - 1 && c == 0) ? 1.3 : 0.7 * rnd(r + 2000, c);  // chunk 0 only
+  part[(size_t)(LB_MAXH + k - 1) * 3 + 0] = 2.9;  // y_new . y_new
+  UUO_HIP_CHECK(hipMemcpy(w->part, part.data(), part.size() * sizeof(double), hipMemcpyHostToDevice));
+  const int cap = LB_MAXH - 3, hist = LB_MAXH - 4;
+  const int head = 0, count = k - 1;
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, head), &head, sizeof(int), hipMemcpyHostToDevice));
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, count), &count, sizeof(int), hipMemcpyHostToDevice));
+  const double one = 1.0;
+  UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
+  if (use_ref)
+    hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
+  else
+    hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
+  UUO_HIP_CHECK(hipDeviceSynchronize());
+  UUO_HIP_CHECK(hipMemcpy(out, (char*)w->st + offsetof(LbDev, cs), LB_MAXH * sizeof(double), hipMemcpyDeviceToHost));
+  UUO_HIP_CHECK(hipMemcpy(out + LB_MAXH, (char*)w->st + offsetof(LbDev, cy), LB_MAXH * sizeof(double), hipMemcpyDeviceToHost));
+  LbOut o;
+  UUO_HIP_CHECK(hipMemcpy(&o, (char*)w->st + offsetof(LbDev, out), sizeof(LbOut), hipMemcpyDeviceToHost));
+  out[2 * LB_MAXH] = o.gtd_dir;
+  lbws_destroy(w);
   return 0;
 }
