@@ -203,11 +203,11 @@ def main():
         skin_flops = SKIN_FLOPS_PER_FRAME * F
         achieved = skin_flops / (skin_ms * 1e-3) / 1e12
         # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r1_pmc_summary.json):
-        # FETCH_SIZE 16 724 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 27 962 KB, at F=300
-        traffic = (16724 * 2 + 27962) * 1024 if (F == 300) else None
+        # FETCH_SIZE 15 259 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 390 KB, at F=300
+        traffic = (15259 * 2 + 30390) * 1024 if (F == 300) else None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                    "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin<true>",
+                    "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
                     "kernel_ms": skin_ms, "flops_per_launch": skin_flops,
                     "chamfer_closure_ms": closure_ms, "closure_frame_evals_per_s": F / (closure_ms * 1e-3)}
         result = {
