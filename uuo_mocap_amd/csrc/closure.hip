@@ -39,6 +39,7 @@ struct BwdArgs {
   float* g_trans;
   const float* dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
   int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat vector (-1 = absent)
+  const float* frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
   float* frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
                       //              16 g.d, 17 sum|g|, 18 g.g, 19 max|g| over this frame's gradient entries
 };
@@ -70,7 +71,14 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   const int f = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int F = a.F, M = a.M;
-  frame_forward(a.src, a.tree, f, L);
+  if (a.frames) {  // block-uniform
+    constexpr int NW = sizeof(FrameLds) / 4;
+    float* dst_l = reinterpret_cast<float*>(&L);
+    for (int i = tid; i < NW; i += BWD_NW * 64) dst_l[i] = a.frames[(size_t)f * NW + i];
+    __syncthreads();
+  } else {
+    frame_forward(a.src, a.tree, f, L);
+  }
   if (tid < UUO_NUM_JOINTS) frame_skin_matrix(L, tid, sA + tid * 12);
   if (tid < UUO_KB) {
     float v = 0.f;
@@ -661,7 +669,7 @@ static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay,
 static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src) {
   if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
   const uuo_model* m = fit->model;
-  int rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr);
+  int rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
   if (rc) return rc;
   const bool cull = (p->d_subset == nullptr) && (m->VP / 16) <= 512 && p->M <= 512;
   rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
@@ -716,6 +724,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + lay.off_z : nullptr;
   a.g_trans = d_grad + lay.off_trans;
   a.frame_part = fit->frame_part;
+  a.frames = (p->stage == UUO_STAGE_MARKER) ? nullptr : fit->frames;
   static const int bwd_stop = getenv("UUO_BWD_STOP") ? atoi(getenv("UUO_BWD_STOP")) : 0;
   a.stop = bwd_stop;
   a.dir = d_dir;

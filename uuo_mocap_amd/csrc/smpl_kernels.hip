@@ -12,12 +12,17 @@
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree* __restrict__ tree, int F,
                                                    float* __restrict__ pfaT, float* __restrict__ A,
-                                                   float* __restrict__ jposed) {
+                                                   float* __restrict__ jposed, float* __restrict__ frames) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   const int f = blockIdx.x;
   const int l = threadIdx.x;
   frame_forward(src, tree, f, L);
+  if (frames) {  // the backward kernel of this closure starts from these instead of redoing the kinematic chain
+    constexpr int NW = sizeof(FrameLds) / 4;
+    const float* src_l = reinterpret_cast<const float*>(&L);
+    for (int i = l; i < NW; i += 64) frames[(size_t)f * NW + i] = src_l[i];
+  }
   // A operand in MFMA order: lane (k&3)*16 + i of group (k>>4) holds A[i][k] at slot (k>>2)&3  (see model.hip)
   const int ft = f / UUO_FT, i = f % UUO_FT;
   float* tile = pfaT + (size_t)ft * UUO_KP * UUO_FT;
@@ -43,8 +48,8 @@ __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree*
 }
 
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
-                         float* jposed) {
-  hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, src, m->tree, F, pfaT, A, jposed);
+                         float* jposed, float* frames) {
+  hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, src, m->tree, F, pfaT, A, jposed, frames);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

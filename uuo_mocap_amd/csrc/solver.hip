@@ -1429,6 +1429,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   A((void**)&fit->bbox, (size_t)F * ((model->V + 15) / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));
+  A((void**)&fit->frames, (size_t)F * sizeof(FrameLds));
   A((void**)&fit->mask, (size_t)F * M * sizeof(float));
   A((void**)&fit->scalars, 64 * sizeof(float));
   A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
@@ -1446,7 +1447,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
 
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
-  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->mask, fit->scalars, fit->vecs};
+  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);

@@ -99,6 +99,8 @@ struct uuo_fit {
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
+  float* frames = nullptr;          // [F][sizeof(FrameLds)/4]: per-frame rotations / joints / world transforms left by
+                                    // k_pose_prep for the backward kernel of the same closure
   float* mask = nullptr;            // [F][M] 0/1
   float* scalars = nullptr;         // device scalars block (see solver)
   float* vecs = nullptr;            // one work vector of n_max floats (timing helper gradient)
@@ -109,7 +111,7 @@ struct uuo_fit {
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
-                         float* joints_posed);
+                         float* joints_posed, float* frames = nullptr);
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox);
 int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
