@@ -51,6 +51,7 @@ struct BwdArgs {
 // Phase 2: joints on lanes -- A -> G, reverse kinematic sweep (parents pull from children in a fixed
 // order, so the result is deterministic), Gram-Schmidt backward, priors, parameter gradients.
 // ----------------------------------------------------------------------------------------------------
+#define BWD_SLOTS 16  // (wave, 16-lane group) pairs: items in flight per block
 #define BWD_NW 4  // waves per frame block (8 waves needs <= 128 VGPRs for 2 blocks/CU and spills: 43 -> 73 us)
 template <bool SPARSE>
 __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
@@ -58,9 +59,9 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
   __shared__ float spf[UUO_KB];
-  __shared__ float w_dA[BWD_NW][UUO_NUM_JOINTS * 12];
-  __shared__ float w_dpf[BWD_NW][UUO_KB];
-  __shared__ float w_red[BWD_NW][16];
+  __shared__ float w_dA[BWD_SLOTS][UUO_NUM_JOINTS * 12];  // private accumulators: one per (wave, 16-lane group)
+  __shared__ float w_dpf[BWD_SLOTS][UUO_KB];
+  __shared__ float w_red[BWD_SLOTS][16];
   __shared__ float sdA[UUO_NUM_JOINTS * 12];
   __shared__ float sdpf[UUO_KB];
   __shared__ float red[16];
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     }
     spf[tid] = v;
   }
-  for (int i = tid; i < BWD_NW * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
+  for (int i = tid; i < BWD_SLOTS * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
+  for (int i = tid; i < BWD_SLOTS * UUO_KB; i += BWD_NW * 64) (&w_dpf[0][0])[i] = 0.f;
+  for (int i = tid; i < BWD_SLOTS * 16; i += BWD_NW * 64) (&w_red[0][0])[i] = 0.f;
   if (tid < 28 * 4) (&sstat[0][0])[tid] = 0.f;
   __syncthreads();
 
@@ -120,105 +123,111 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     }
   }
 
-  // Items are software-pipelined: every global load of item m + BWD_NW (assignment key, marker, the vertex's
-  // posedirs rows, template, shape rows, skin weights) is issued before item m is processed, so the L2/MALL
-  // round trips of the gather overlap the arithmetic and the wave reductions of the previous item.
-  struct Item {
-    float p[3][4];
-    float x0, x1, x2, wgt, d2, vt0, vt1, vt2, stv;
-    int vi;
-    int4 wi;
-    float4 ww;
-    bool on;
-  };
-  auto fetch = [&](int m, Item& q) {
-    q.on = false;
-    q.wgt = 1.f;
-    q.d2 = 0.f;
-    if (m >= M) return;
-    int vi;
-    if (a.stage == UUO_STAGE_MARKER) {
-      q.wgt = a.mask[(size_t)f * M + m];
-      vi = a.assign[m];
-    } else {
-      const unsigned long long key = a.nn[(size_t)f * M + m];
-      q.d2 = __uint_as_float((unsigned)(key >> 32));
-      vi = (int)(unsigned)(key & 0xFFFFFFFFull);
-      if (a.stage == UUO_STAGE_PART)
-        vi = a.subset[vi];
-      else
-        q.wgt = a.mask[(size_t)f * M + m];
-    }
-    if (q.wgt == 0.f) return;  // wave-uniform
-    q.on = true;
-    q.vi = vi;
-    const float* px = a.markers + ((size_t)f * M + m) * 3;
-    q.x0 = px[0];
-    q.x1 = px[1];
-    q.x2 = px[2];
-    const float* pt = a.PT + (size_t)vi * 3 * UUO_KB;
+  if constexpr (SPARSE) {
+    // Four items per wave, one per 16-lane group: the per-item scalar work (blended transform, residual, dv) used
+    // to be computed redundantly by all 64 lanes for ONE item at a time; now the four DPP rows of a wave carry four
+    // items, each sub-lane owning 13 of the 208 pose-blend rows (k = sl + 16 t), and the sums are row reductions
+    // that stay inside the DPP row (no v_readlane).  M = 50 -> 4 rounds per block instead of 13 per wave.
+    const int gq = lane >> 4, sl = lane & 15;
+    const int slot = wave * 4 + gq;  // 0..15
+    float fk[13];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int t = 0; t < 13; ++t) fk[t] = spf[sl + 16 * t];
+    const float beta_s = (sl < 10) ? L.beta[sl] : 0.f;
+    float acc_pf[13];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) q.p[c][r] = pt[c * UUO_KB + lane + 64 * r];
-      q.p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
-    }
-    q.vt0 = a.vt[(size_t)vi * 3];
-    q.vt1 = a.vt[(size_t)vi * 3 + 1];
-    q.vt2 = a.vt[(size_t)vi * 3 + 2];
-    q.stv = (lane < 30) ? a.ST[(size_t)vi * 30 + lane] : 0.f;  // lane 10 c + l holds S[vi][c][l]
-    if (SPARSE) {
+    for (int t = 0; t < 13; ++t) acc_pf[t] = 0.f;
+    float acc_db16 = 0.f, acc_dt16 = 0.f, acc_loss16 = 0.f;
+    float* my_dA = &w_dA[slot][0];
+    struct Item16 {
+      float p[3][13];
+      float x0, x1, x2, wgt, d2, vt0, vt1, vt2, st0, st1, st2;
+      int4 wi;
+      float4 ww;
+    };
+    auto fetch16 = [&](int m, Item16& q) {
+      // items past M (or masked out) are processed with weight 0 on vertex 0: every contribution is scaled by it
+      const bool in = m < M;
+      const int mm = in ? m : 0;
+      float wgt = in ? 1.f : 0.f;
+      float d2 = 0.f;
+      int vi;
+      if (a.stage == UUO_STAGE_MARKER) {
+        wgt *= a.mask[(size_t)f * M + mm];
+        vi = a.assign[mm];
+      } else {
+        const unsigned long long key = a.nn[(size_t)f * M + mm];
+        d2 = __uint_as_float((unsigned)(key >> 32));
+        vi = (int)(unsigned)(key & 0xFFFFFFFFull);
+        if (a.stage == UUO_STAGE_PART)
+          vi = a.subset[vi];
+        else
+          wgt *= a.mask[(size_t)f * M + mm];
+      }
+      if ((unsigned)vi >= (unsigned)a.V) vi = 0;  // never happens for a completed search; keeps the gather in bounds
+      q.wgt = wgt;
+      q.d2 = d2;
+      const float* px = a.markers + ((size_t)f * M + mm) * 3;
+      q.x0 = px[0]; q.x1 = px[1]; q.x2 = px[2];
+      const float* pt = a.PT + (size_t)vi * 3 * UUO_KB + sl;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 13; ++t) q.p[c][t] = pt[c * UUO_KB + 16 * t];
+      q.vt0 = a.vt[(size_t)vi * 3];
+      q.vt1 = a.vt[(size_t)vi * 3 + 1];
+      q.vt2 = a.vt[(size_t)vi * 3 + 2];
+      const float* ps = a.ST + (size_t)vi * 30 + (sl < 10 ? sl : 0);
+      q.st0 = (sl < 10) ? ps[0] : 0.f;
+      q.st1 = (sl < 10) ? ps[10] : 0.f;
+      q.st2 = (sl < 10) ? ps[20] : 0.f;
       q.wi = *reinterpret_cast<const int4*>(a.Wi + (size_t)vi * 4);
       q.ww = *reinterpret_cast<const float4*>(a.Ww + (size_t)vi * 4);
-    }
-  };
-  const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
-              f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
-  const float beta_l = L.beta[lane % 10];
-  Item cur, nxt;
-  fetch(wave, cur);
-  for (int m = wave; m < M; m += BWD_NW) {
-    fetch(m + BWD_NW, nxt);
-    if (cur.on) {
+    };
+    auto row_sum = [](float v) {  // sum over the 16 lanes of the DPP row, left on every lane of the row
+      v += dpp_rot<0x128>(v);
+      v += dpp_rot<0x124>(v);
+      v += dpp_rot<0x122>(v);
+      v += dpp_rot<0x121>(v);
+      return v;
+    };
+    const int rounds = (M + BWD_SLOTS - 1) / BWD_SLOTS;
+    Item16 cur, nxt;
+    fetch16(slot, cur);
+    for (int r = 0; r < rounds; ++r) {
+      if (r + 1 < rounds) fetch16(slot + BWD_SLOTS * (r + 1), nxt);  // block-uniform
       const float wgt = cur.wgt, d2 = cur.d2;
-      const int vi = cur.vi;
-      const float x0 = cur.x0, x1 = cur.x1, x2 = cur.x2;
-      // v_posed of the touched vertex: template + shape blend (lanes 0..29 hold the 3x10 shape rows) + pose blend
-      const float sprod = cur.stv * beta_l;
       float vp[3];
+      {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float part = fmaf(cur.p[c][3], f3, fmaf(cur.p[c][2], f2, fmaf(cur.p[c][1], f1, cur.p[c][0] * f0)));
-        const float offs = wave_sum_fast(part);
-        const float sb = wave_sum_fast((lane >= 10 * c && lane < 10 * c + 10) ? sprod : 0.f);
-        const float vs = (c == 0) ? cur.vt0 : ((c == 1) ? cur.vt1 : cur.vt2);
-        vp[c] = offs + (vs + sb);
+        for (int t = 0; t < 13; ++t) {
+          s0 = fmaf(cur.p[0][t], fk[t], s0);
+          s1 = fmaf(cur.p[1][t], fk[t], s1);
+          s2 = fmaf(cur.p[2][t], fk[t], s2);
+        }
+        vp[0] = row_sum(s0) + (cur.vt0 + row_sum(cur.st0 * beta_s));
+        vp[1] = row_sum(s1) + (cur.vt1 + row_sum(cur.st1 * beta_s));
+        vp[2] = row_sum(s2) + (cur.vt2 + row_sum(cur.st2 * beta_s));
       }
-      // blended skinning matrix
       float T[12];
 #pragma unroll
       for (int e = 0; e < 12; ++e) T[e] = 0.f;
-      int wj[4];
-      float ww[4];
-      if (SPARSE) {
-        wj[0] = cur.wi.x; wj[1] = cur.wi.y; wj[2] = cur.wi.z; wj[3] = cur.wi.w;
-        ww[0] = cur.ww.x; ww[1] = cur.ww.y; ww[2] = cur.ww.z; ww[3] = cur.ww.w;
+      const int wj[4] = {cur.wi.x, cur.wi.y, cur.wi.z, cur.wi.w};
+      const float ww[4] = {cur.ww.x, cur.ww.y, cur.ww.z, cur.ww.w};
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-#pragma unroll
-          for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
-        }
-      } else {
-        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
-          const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
-#pragma unroll
-          for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
-        }
+      for (int n = 0; n < 4; ++n) {
+        const float4* pa4 = reinterpret_cast<const float4*>(sA + wj[n] * 12);
+        const float4 r0 = pa4[0], r1 = pa4[1], r2 = pa4[2];
+        const float w = ww[n];
+        T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
+        T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
+        T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
       }
       const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
       const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
       const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
-      const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
+      const float dx = cur.x0 - vx, dy = cur.x1 - vy, dz = cur.x2 - vz;
       float g[3];
       float loss_item;
       if (a.stage == UUO_STAGE_MARKER) {
@@ -226,73 +235,211 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
         const float e = rr - a.d0;
         loss_item = wgt * (e * e);
         const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
-        g[0] = sc * dx;
-        g[1] = sc * dy;
-        g[2] = sc * dz;
+        g[0] = sc * dx; g[1] = sc * dy; g[2] = sc * dz;
       } else {
         loss_item = wgt * d2;
         const float sc = -a.cg * wgt;
-        g[0] = sc * dx;
-        g[1] = sc * dy;
-        g[2] = sc * dz;
+        g[0] = sc * dx; g[1] = sc * dy; g[2] = sc * dz;
       }
-      // d v_posed = T_R^T g
       float dvp[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc_dpf[r] += fmaf(cur.p[2][r], dvp[2], fmaf(cur.p[1][r], dvp[1], cur.p[0][r] * dvp[0]));
-      {  // d beta (direct path): lane 10 c + l holds S[c][l]; fold the three coordinate groups onto lanes 0..9
-        const int cgrp = lane / 10;
-        const float contrib = (lane < 30) ? cur.stv * ((cgrp == 0) ? dvp[0] : ((cgrp == 1) ? dvp[1] : dvp[2])) : 0.f;
-        const float c1v = __shfl(contrib, lane + 10, 64), c2v = __shfl(contrib, lane + 20, 64);
-        if (lane < 10) acc_db += contrib + c1v + c2v;
-      }
-      if (lane < 12) {
-        const int r = lane >> 2, c = lane & 3;
-        const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
-        const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
+      for (int t = 0; t < 13; ++t)
+        acc_pf[t] += fmaf(cur.p[2][t], dvp[2], fmaf(cur.p[1][t], dvp[1], cur.p[0][t] * dvp[0]));
+      acc_db16 += fmaf(cur.st2, dvp[2], fmaf(cur.st1, dvp[1], cur.st0 * dvp[0]));  // sub-lanes 0..9: d beta (direct path)
+      if (sl < 12) {
+        const int rr_ = sl >> 2, cc_ = sl & 3;
+        const float gr = (rr_ == 0) ? g[0] : ((rr_ == 1) ? g[1] : g[2]);
+        const float pc = (cc_ == 0) ? vp[0] : ((cc_ == 1) ? vp[1] : ((cc_ == 2) ? vp[2] : 1.f));
         const float val = gr * pc;
-        if (SPARSE) {
 #pragma unroll
-          for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
-        } else {
-          for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
-            w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
-        }
+        for (int n = 0; n < 4; ++n) my_dA[wj[n] * 12 + sl] += ww[n] * val;
       }
-      if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
-      acc_loss += loss_item;
+      acc_dt16 += (sl == 0) ? g[0] : ((sl == 1) ? g[1] : g[2]);  // sub-lanes 0..2
+      acc_loss16 += loss_item;                                     // sub-lane 0 is the one that is stored
+      cur = nxt;
     }
-    cur = nxt;
+#pragma unroll
+    for (int t = 0; t < 13; ++t) w_dpf[slot][sl + 16 * t] = acc_pf[t];
+    if (sl == 0) w_red[slot][0] = acc_loss16;
+    if (sl < 3) w_red[slot][1 + sl] = acc_dt16;
+    if (sl < 10) w_red[slot][4 + sl] = acc_db16;
+  } else {
+  // Items are software-pipelined: every global load of item m + BWD_NW (assignment key, marker, the vertex's
+    // posedirs rows, template, shape rows, skin weights) is issued before item m is processed, so the L2/MALL
+    // round trips of the gather overlap the arithmetic and the wave reductions of the previous item.
+    struct Item {
+      float p[3][4];
+      float x0, x1, x2, wgt, d2, vt0, vt1, vt2, stv;
+      int vi;
+      int4 wi;
+      float4 ww;
+      bool on;
+    };
+    auto fetch = [&](int m, Item& q) {
+      q.on = false;
+      q.wgt = 1.f;
+      q.d2 = 0.f;
+      if (m >= M) return;
+      int vi;
+      if (a.stage == UUO_STAGE_MARKER) {
+        q.wgt = a.mask[(size_t)f * M + m];
+        vi = a.assign[m];
+      } else {
+        const unsigned long long key = a.nn[(size_t)f * M + m];
+        q.d2 = __uint_as_float((unsigned)(key >> 32));
+        vi = (int)(unsigned)(key & 0xFFFFFFFFull);
+        if (a.stage == UUO_STAGE_PART)
+          vi = a.subset[vi];
+        else
+          q.wgt = a.mask[(size_t)f * M + m];
+      }
+      if (q.wgt == 0.f) return;  // wave-uniform
+      q.on = true;
+      q.vi = vi;
+      const float* px = a.markers + ((size_t)f * M + m) * 3;
+      q.x0 = px[0];
+      q.x1 = px[1];
+      q.x2 = px[2];
+      const float* pt = a.PT + (size_t)vi * 3 * UUO_KB;
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) {
+  #pragma unroll
+        for (int r = 0; r < 3; ++r) q.p[c][r] = pt[c * UUO_KB + lane + 64 * r];
+        q.p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
+      }
+      q.vt0 = a.vt[(size_t)vi * 3];
+      q.vt1 = a.vt[(size_t)vi * 3 + 1];
+      q.vt2 = a.vt[(size_t)vi * 3 + 2];
+      q.stv = (lane < 30) ? a.ST[(size_t)vi * 30 + lane] : 0.f;  // lane 10 c + l holds S[vi][c][l]
+      if (SPARSE) {
+        q.wi = *reinterpret_cast<const int4*>(a.Wi + (size_t)vi * 4);
+        q.ww = *reinterpret_cast<const float4*>(a.Ww + (size_t)vi * 4);
+      }
+    };
+    const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
+                f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
+    const float beta_l = L.beta[lane % 10];
+    Item cur, nxt;
+    fetch(wave, cur);
+    for (int m = wave; m < M; m += BWD_NW) {
+      fetch(m + BWD_NW, nxt);
+      if (cur.on) {
+        const float wgt = cur.wgt, d2 = cur.d2;
+        const int vi = cur.vi;
+        const float x0 = cur.x0, x1 = cur.x1, x2 = cur.x2;
+        // v_posed of the touched vertex: template + shape blend (lanes 0..29 hold the 3x10 shape rows) + pose blend
+        const float sprod = cur.stv * beta_l;
+        float vp[3];
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float part = fmaf(cur.p[c][3], f3, fmaf(cur.p[c][2], f2, fmaf(cur.p[c][1], f1, cur.p[c][0] * f0)));
+          const float offs = wave_sum_fast(part);
+          const float sb = wave_sum_fast((lane >= 10 * c && lane < 10 * c + 10) ? sprod : 0.f);
+          const float vs = (c == 0) ? cur.vt0 : ((c == 1) ? cur.vt1 : cur.vt2);
+          vp[c] = offs + (vs + sb);
+        }
+        // blended skinning matrix
+        float T[12];
+  #pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        int wj[4];
+        float ww[4];
+        if (SPARSE) {
+          wj[0] = cur.wi.x; wj[1] = cur.wi.y; wj[2] = cur.wi.z; wj[3] = cur.wi.w;
+          ww[0] = cur.ww.x; ww[1] = cur.ww.y; ww[2] = cur.ww.z; ww[3] = cur.ww.w;
+  #pragma unroll
+          for (int n = 0; n < 4; ++n) {
+  #pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
+          }
+        } else {
+          for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
+            const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
+  #pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
+          }
+        }
+        const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
+        const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
+        const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
+        const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
+        float g[3];
+        float loss_item;
+        if (a.stage == UUO_STAGE_MARKER) {
+          const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
+          const float e = rr - a.d0;
+          loss_item = wgt * (e * e);
+          const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
+          g[0] = sc * dx;
+          g[1] = sc * dy;
+          g[2] = sc * dz;
+        } else {
+          loss_item = wgt * d2;
+          const float sc = -a.cg * wgt;
+          g[0] = sc * dx;
+          g[1] = sc * dy;
+          g[2] = sc * dz;
+        }
+        // d v_posed = T_R^T g
+        float dvp[3];
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
+  #pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc_dpf[r] += fmaf(cur.p[2][r], dvp[2], fmaf(cur.p[1][r], dvp[1], cur.p[0][r] * dvp[0]));
+        {  // d beta (direct path): lane 10 c + l holds S[c][l]; fold the three coordinate groups onto lanes 0..9
+          const int cgrp = lane / 10;
+          const float contrib = (lane < 30) ? cur.stv * ((cgrp == 0) ? dvp[0] : ((cgrp == 1) ? dvp[1] : dvp[2])) : 0.f;
+          const float c1v = __shfl(contrib, lane + 10, 64), c2v = __shfl(contrib, lane + 20, 64);
+          if (lane < 10) acc_db += contrib + c1v + c2v;
+        }
+        if (lane < 12) {
+          const int r = lane >> 2, c = lane & 3;
+          const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
+          const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
+          const float val = gr * pc;
+          if (SPARSE) {
+  #pragma unroll
+            for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
+          } else {
+            for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
+              w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
+          }
+        }
+        if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
+        acc_loss += loss_item;
+      }
+      cur = nxt;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) w_dpf[wave][lane + 64 * r] = acc_dpf[r];
+    if (lane < UUO_KB - 192) w_dpf[wave][lane + 192] = acc_dpf[3];
+    if (lane == 0) w_red[wave][0] = acc_loss;
+    if (lane < 3) w_red[wave][1 + lane] = acc_dt;
+    if (lane < 10) w_red[wave][4 + lane] = acc_db;
   }
 
   if (a.stop == 2) return;
-  // ---- block reduction (fixed order -> deterministic)
-#pragma unroll
-  for (int r = 0; r < 3; ++r) w_dpf[wave][lane + 64 * r] = acc_dpf[r];
-  if (lane < UUO_KB - 192) w_dpf[wave][lane + 192] = acc_dpf[3];
-  if (lane == 0) w_red[wave][0] = acc_loss;
-  if (lane < 3) w_red[wave][1 + lane] = acc_dt;
-  if (lane < 10) w_red[wave][4 + lane] = acc_db;
+  // ---- block reduction over the accumulation slots (fixed order -> deterministic)
   __syncthreads();
   if (tid < UUO_KB) {
     float acc = w_dpf[0][tid];
 #pragma unroll
-    for (int w = 1; w < BWD_NW; ++w) acc += w_dpf[w][tid];
+    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dpf[w][tid];
     sdpf[tid] = acc;
   }
   for (int i = tid; i < UUO_NUM_JOINTS * 12; i += BWD_NW * 64) {
     float acc = w_dA[0][i];
 #pragma unroll
-    for (int w = 1; w < BWD_NW; ++w) acc += w_dA[w][i];
+    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dA[w][i];
     sdA[i] = acc;
   }
   if (tid < 14) {
     float acc = w_red[0][tid];
 #pragma unroll
-    for (int w = 1; w < BWD_NW; ++w) acc += w_red[w][tid];
+    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_red[w][tid];
     red[tid] = acc;
   }
   __syncthreads();
