@@ -555,19 +555,34 @@ __global__ __launch_bounds__(256) void k_lb_small_ref(int nchunks, int cap, int 
 // 16 x 16 mat-vec (values fetched with v_readlane inside the block's DPP row) followed by the same right-looking
 // update as before.  8 waves: wave 0 runs the two solves, waves 1-2 invert the blocks, waves 3-5 hold Y.Y^T.
 #define LB_NB ((LB_MAXH + 15) / 16)
+#define LB_US (LB_MAXH + 1)  // padded row stride of the LDS copy of S.Y^T (bank spread)
 __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist, int cand,
                                                    const double* __restrict__ part, LbDev* __restrict__ st, int stop) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
-  __shared__ double U[LB_TRI];
-  __shared__ double Xl[LB_NB][16][16];  // inverses of the diagonal blocks of U (upper triangular, [row][col])
+  __shared__ double Us[LB_MAXH * LB_US];  // S.Y^T by SLOT (one contiguous copy of the device matrix); U(i,j) logical
+                                          // = Us[slot(i)][slot(j)] for i <= j
+  __shared__ double Xl[LB_NB][16][16];    // inverses of the diagonal blocks of U (upper triangular, [row][col])
   __shared__ double rinvL[LB_MAXH + 8];
+  __shared__ double bl[2][16];  // block values handed from the 16 owning lanes to the whole wave (wave 0 only)
   __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH];
   __shared__ double rd[LB_ROWS * 3];
-  __shared__ int slot_of[LB_MAXH];
+  __shared__ int slot_of[LB_MAXH + 24];
   __shared__ double wpart[3][LB_MAXH + 24];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int head = st->head, count = st->count;
   const int nact = count + 1;
+  // ---- S.Y^T as it stands before this iteration's column: issued first, consumed after the partial sums
+  constexpr int NSY = LB_MAXH * LB_MAXH / 2;               // double2 elements
+  constexpr int PSY = (NSY + 511) / 512;                   // per thread (11)
+  double2 sycopy[PSY];
+  {
+    const double2* src = reinterpret_cast<const double2*>(st->SY);
+#pragma unroll
+    for (int r = 0; r < PSY; ++r) {
+      const int e = tid + 512 * r;
+      sycopy[r] = (e < NSY) ? src[e] : make_double2(0.0, 0.0);
+    }
+  }
   // ---- reduce the partial dots of the active rows (fixed chunk order -> deterministic)
   for (int e = tid; e < LB_ROWS * 3; e += 512) {
     const int row = e / 3;
@@ -587,21 +602,33 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
     }
     rd[e] = acc;
   }
+#pragma unroll
+  for (int r = 0; r < PSY; ++r) {
+    const int e = tid + 512 * r;
+    if (e < NSY) {
+      const int row = (2 * e) / LB_MAXH, col = (2 * e) - row * LB_MAXH;  // LB_MAXH is even: pairs never straddle rows
+      Us[row * LB_US + col] = sycopy[r].x;
+      Us[row * LB_US + col + 1] = sycopy[r].y;
+    }
+  }
   __syncthreads();
-  // ---- candidate row / column of the Gram matrices
+  // ---- candidate row / column of the Gram matrices (device copy for the next iterations, LDS copy for this one)
   const double ys = rd[cand * 3 + 0];              // s_new . y_new
   const double yy = rd[(LB_MAXH + cand) * 3 + 0];  // y_new . y_new
   for (int r = tid; r < nact; r += 512) {
     const int slot = (r < count) ? (head + r) % cap : cand;
-    st->SY[slot * LB_MAXH + cand] = rd[slot * 3 + 0];              // s_slot . y_new
-    st->SY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 1];  // s_new . y_slot
+    const double sy_col = rd[slot * 3 + 0];              // s_slot . y_new
+    const double sy_row = rd[(LB_MAXH + slot) * 3 + 1];  // s_new . y_slot
+    st->SY[slot * LB_MAXH + cand] = sy_col;
+    st->SY[cand * LB_MAXH + slot] = sy_row;
+    Us[slot * LB_US + cand] = sy_col;
+    Us[cand * LB_US + slot] = sy_row;
     st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];
     st->YY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 0];
     Sg[slot] = rd[slot * 3 + 2];
     Yg[slot] = rd[(LB_MAXH + slot) * 3 + 2];
   }
   __threadfence_block();
-  __syncthreads();
   const bool accept = ys > 1e-10;
   double Hdiag = st->Hdiag;
   if (accept) {
@@ -612,14 +639,16 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
     Hdiag = ys / yy;
   }
   const int k = count;
-  for (int j = tid; j < k; j += 512) slot_of[j] = (head + j) % cap;
+  // logical index -> slot, arithmetically (head + i < 2 cap): no LDS look-up on the solves' dependent chains
+  auto slotf = [&](int i) { const int v = head + i; return (v >= cap) ? v - cap : v; };
+  for (int j = tid; j < LB_MAXH + 24; j += 512) slot_of[j] = (j < k) ? slotf(j) : 0;
   __syncthreads();
   if (stop == 1) return;
-  // ---- stage U in LDS (logical order); waves 3..5 fetch their rows of Y.Y^T into registers meanwhile
+  // ---- waves 3..5 fetch their rows of Y.Y^T into registers for the mat-vec between the two solves
   const int j0 = lane, j1 = lane + 64;
+  const int sl0 = (j0 < k) ? slotf(j0) : 0, sl1 = (j1 < k) ? slotf(j1) : 0;
   double yv0[LB_YR], yv1[LB_YR];  // waves 3..5: rows i = (wave-3) + 3 r of YY, columns j0 / j1
   if (wave >= 3 && wave <= 5) {
-    const int sl0 = (j0 < k) ? slot_of[j0] : 0, sl1 = (j1 < k) ? slot_of[j1] : 0;
 #pragma unroll
     for (int r = 0; r < LB_YR; ++r) {
       const int i = (wave - 3) + 3 * r;
@@ -627,59 +656,33 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
       yv0[r] = (i < k && j0 < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
       yv1[r] = (i < k && j1 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
     }
-  } else {
-    const int wrow = (wave < 3) ? wave : wave - 3;  // 5 staging waves: 0,1,2,6,7 -> 0..4
-    constexpr int RB = 16;  // rows per wave pass, all loads in flight at once
-    for (int i0 = wrow * RB; i0 < k; i0 += 5 * RB) {
-      double v[RB][2];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int j = lane + 64 * h;
-          v[r][h] = (i < k && j >= i && j < k) ? st->SY[slot_of[i] * LB_MAXH + slot_of[j]] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int j = lane + 64 * h;
-          if (i < k && j >= i && j < k) U[tri_index(i, j, k)] = v[r][h];
-        }
-      }
-    }
   }
-  __syncthreads();
   if (stop == 2) return;
-  if (tid < k) rinvL[tid] = 1.0 / U[tri_index(tid, tid, k)];
+  if (tid < k) rinvL[tid] = 1.0 / Us[slotf(tid) * (LB_US + 1)];
   __syncthreads();
   const int nblk = (k + 15) >> 4;
-  // ---- inverses of the diagonal blocks: lane (b, c) solves T x = e_c by back-substitution, T = U[lo:hi, lo:hi]
+  // ---- inverses of the diagonal blocks: lane (b, c) solves T x = e_c by back-substitution, T = U[lo:hi, lo:hi].
+  // Rows r > c and columns beyond the block contribute zeros (masked products), so the code has no divergent branch.
   if (wave >= 1 && wave <= 2) {
     const int idx = (wave - 1) * 64 + lane;
     const int b = idx >> 4, c = idx & 15;
     if (b < nblk) {
       const int lo = b << 4;
       const int nb = min(16, k - lo);
+      const bool colok = c < nb;
       double x[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = 0.0;
-#pragma unroll
       for (int r = 15; r >= 0; --r) {
-        if (r < nb && r <= c && c < nb) {
-          if (r == c) {
-            x[r] = rinvL[lo + r];
-          } else {
-            double acc = 0.0;
+        // x_r = (delta_rc - sum_{m > r} T_rm x_m) / T_rr, kept only for r <= c
+        const int srow = slotf(min(lo + r, k - 1)) * LB_US;
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int m = r + 1; m < 16; ++m)
-              if (m <= c) acc = fma(U[tri_index(lo + r, lo + m, k)], x[m], acc);
-            x[r] = -acc * rinvL[lo + r];
-          }
+        for (int m = r + 1; m < 16; m += 2) {
+          acc0 = fma(Us[srow + slotf(min(lo + m, k - 1))], x[m], acc0);
+          if (m + 1 < 16) acc1 = fma(Us[srow + slotf(min(lo + m + 1, k - 1))], x[m + 1], acc1);
         }
+        const double rhs = ((r == c) ? 1.0 : 0.0) - (acc0 + acc1);
+        x[r] = (colok && r <= c && r < nb) ? rhs * rinvL[lo + r] : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) Xl[b][r][c] = x[r];
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
   if (stop == 3) return;
   double a0 = 0.0, a1 = 0.0;
   if (wave == 0) {
-    const double sg0 = (j0 < k) ? Sg[slot_of[j0]] : 0.0, sg1 = (j1 < k) ? Sg[slot_of[j1]] : 0.0;
+    const double sg0 = (j0 < k) ? Sg[sl0] : 0.0, sg1 = (j1 < k) ? Sg[sl1] : 0.0;
     double r0 = 0.0, r1 = 0.0;
     // ---- loop 1 (newest -> oldest):  U al = -S.g  (upper triangular), blocks from the last to the first
     for (int b = nblk - 1; b >= 0; --b) {
@@ -698,31 +701,46 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
       const int base = lo & 63;                 // first lane of the block's DPP row
       const int t = (lane - base) & 15;         // this lane's row inside the block (meaningful for block lanes)
       const bool mine = lane >= base && lane < base + 16;
-      double xrow[16];                          // row t of the block inverse
+      double xrow[16], un0[16], un1[16];
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) xrow[s_] = mine ? Xl[b][t][s_] : 0.0;
+      for (int s_ = 0; s_ < 16; ++s_) {
+        xrow[s_] = Xl[b][t][s_];                // row t of the block inverse (t is arbitrary but in range off the block)
+        const int sc = slotf(min(lo + s_, k - 1));  // wave-uniform
+        const double u0 = Us[sl0 * LB_US + sc], u1 = Us[sl1 * LB_US + sc];  // unconditional reads, masked values
+        un0[s_] = (j0 < lo && lo + s_ < hi) ? u0 : 0.0;                 // rows above the block
+        un1[s_] = (lo > 64 && j1 < lo && lo + s_ < hi) ? u1 : 0.0;
+      }
       const double rhs = inhi ? (-sg1 - r1) : (-sg0 - r0);
-      double mya = 0.0;
+      // the block's 16 right-hand sides go through LDS (one write, broadcast reads): LDS operations of one wave
+      // complete in order, so no barrier is needed, only a compiler fence
+      if (mine) bl[0][t] = rhs;
+      __builtin_amdgcn_wave_barrier();
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;  // four partial sums: short dependent chains
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) mya = fma(xrow[s_], bcast_lane_d(rhs, base + s_), mya);
+      for (int s_ = 0; s_ < 16; s_ += 4) {
+        m0 = fma(xrow[s_], bl[0][s_], m0);
+        m1 = fma(xrow[s_ + 1], bl[0][s_ + 1], m1);
+        m2 = fma(xrow[s_ + 2], bl[0][s_ + 2], m2);
+        m3 = fma(xrow[s_ + 3], bl[0][s_ + 3], m3);
+      }
+      const double mya = (m0 + m1) + (m2 + m3);
       if (mine) {
         if (inhi) a1 = mya; else a0 = mya;
       }
-      // rows above the block (right-looking update with the block's al values)
-      if (lo > 0) {
-        double ablk[16], un[16];
+      if (lo > 0) {  // right-looking update of the rows above with the block's al values
+        if (mine) bl[1][t] = mya;
+        __builtin_amdgcn_wave_barrier();
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) ablk[s_] = bcast_lane_d(mya, base + s_);
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j0 < lo && lo + s_ < hi) ? U[tri_index(j0, lo + s_, k)] : 0.0;
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) r0 = fma(ablk[s_], un[s_], r0);
-        if (lo > 64) {
-#pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j1 < lo && lo + s_ < hi) ? U[tri_index(j1, lo + s_, k)] : 0.0;
-#pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) r1 = fma(ablk[s_], un[s_], r1);
+        for (int s_ = 0; s_ < 16; s_ += 2) {
+          const double ab0 = bl[1][s_], ab1 = bl[1][s_ + 1];
+          p0 = fma(ab0, un0[s_], p0);
+          p1 = fma(ab1, un0[s_ + 1], p1);
+          p2 = fma(ab0, un1[s_], p2);
+          p3 = fma(ab1, un1[s_ + 1], p3);
         }
+        r0 += p0 + p1;
+        r1 += p2 + p3;
       }
     }
     if (j0 < k) al[j0] = a0;
@@ -752,8 +770,8 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
   if (stop == 5) return;
   if (wave == 0) {
     // ---- loop 2 (oldest -> newest):  U^T cs = D al - (cg Y.g + YY cy)  (lower triangular), blocks first to last
-    const double v0 = (j0 < k) ? a0 * U[tri_index(j0, j0, k)] - (cg * Yg[slot_of[j0]] + wv[j0]) : 0.0;
-    const double v1 = (j1 < k) ? a1 * U[tri_index(j1, j1, k)] - (cg * Yg[slot_of[j1]] + wv[j1]) : 0.0;
+    const double v0 = (j0 < k) ? a0 * Us[sl0 * LB_US + sl0] - (cg * Yg[sl0] + wv[j0]) : 0.0;
+    const double v1 = (j1 < k) ? a1 * Us[sl1 * LB_US + sl1] - (cg * Yg[sl1] + wv[j1]) : 0.0;
     double q0 = 0.0, q1 = 0.0, c0 = 0.0, c1 = 0.0;
     for (int b = 0; b < nblk; ++b) {
       const int lo = b << 4, hi = min(lo + 16, k);
@@ -761,31 +779,44 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
       const int base = lo & 63;
       const int t = (lane - base) & 15;
       const bool mine = lane >= base && lane < base + 16;
-      double xcol[16];  // column t of the block inverse = row t of its transpose
+      double xcol[16], un0[16], un1[16];
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) xcol[s_] = mine ? Xl[b][s_][t] : 0.0;
+      for (int s_ = 0; s_ < 16; ++s_) {
+        xcol[s_] = Xl[b][s_][t];               // column t of the block inverse = row t of its transpose
+        const int sr = slotf(min(lo + s_, k - 1)) * LB_US;  // wave-uniform
+        const double u0 = Us[sr + sl0], u1 = Us[sr + sl1];
+        un0[s_] = (hi <= 64 && j0 >= hi && j0 < k && lo + s_ < hi) ? u0 : 0.0;   // rows below the block
+        un1[s_] = (j1 >= hi && j1 < k && lo + s_ < hi) ? u1 : 0.0;
+      }
       const double rhs = inhi ? (v1 - q1) : (v0 - q0);
-      double myc = 0.0;
+      if (mine) bl[0][t] = rhs;
+      __builtin_amdgcn_wave_barrier();
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) myc = fma(xcol[s_], bcast_lane_d(rhs, base + s_), myc);
+      for (int s_ = 0; s_ < 16; s_ += 4) {
+        m0 = fma(xcol[s_], bl[0][s_], m0);
+        m1 = fma(xcol[s_ + 1], bl[0][s_ + 1], m1);
+        m2 = fma(xcol[s_ + 2], bl[0][s_ + 2], m2);
+        m3 = fma(xcol[s_ + 3], bl[0][s_ + 3], m3);
+      }
+      const double myc = (m0 + m1) + (m2 + m3);
       if (mine) {
         if (inhi) c1 = myc; else c0 = myc;
       }
-      // rows below the block
       if (hi < k) {
-        double cblk[16], un[16];
+        if (mine) bl[1][t] = myc;
+        __builtin_amdgcn_wave_barrier();
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) cblk[s_] = bcast_lane_d(myc, base + s_);
-        if (hi <= 64) {
-#pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j0 >= hi && j0 < k && lo + s_ < hi) ? U[tri_index(lo + s_, j0, k)] : 0.0;
-#pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) q0 = fma(cblk[s_], un[s_], q0);
+        for (int s_ = 0; s_ < 16; s_ += 2) {
+          const double cb0 = bl[1][s_], cb1 = bl[1][s_ + 1];
+          p0 = fma(cb0, un0[s_], p0);
+          p1 = fma(cb1, un0[s_ + 1], p1);
+          p2 = fma(cb0, un1[s_], p2);
+          p3 = fma(cb1, un1[s_ + 1], p3);
         }
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) un[s_] = (j1 >= hi && j1 < k && lo + s_ < hi) ? U[tri_index(lo + s_, j1, k)] : 0.0;
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) q1 = fma(cblk[s_], un[s_], q1);
+        q0 += p0 + p1;
+        q1 += p2 + p3;
       }
     }
     if (j0 < k) cs_s[j0] = c0;
