@@ -209,6 +209,12 @@ def main():
                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                     "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
                     "kernel_ms": skin_ms, "flops_per_launch": skin_flops,
+                    # SURVEY 8d asks for the HBM fraction as well: algorithmic bytes of the launch (blend basis once +
+                    # vertices + unit boxes written) over its duration against the 8 TB/s spec; small by construction
+                    # (the kernel is FP32-bound at ~80 FLOP/B)
+                    "algorithmic_bytes": 18688848 + F * (6890 * 12 + 431 * 24),
+                    "achieved_hbm_GBps": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 1e9,
+                    "achieved_hbm_frac": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 8.0e12,
                     "chamfer_closure_ms": closure_ms, "closure_frame_evals_per_s": F / (closure_ms * 1e-3)}
         result = {
             "metric": "mocap frames/sec fitted (300-frame seq, 50 markers)",

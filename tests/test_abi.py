@@ -101,3 +101,67 @@ def test_segment_rigid_and_subtrees_match_oracle(tables):
         assert np.array_equal(MU.rigid_distance_matrix(p), loop)
     for k in (2, 5, 12, 24):
         assert MU.get_sub_hierachies(tables.parents, k) == stages_ref.get_sub_hierarchies(tables.parents, k)
+
+
+def test_matrix_to_axis_angle_round_trip():
+    """poses[F,72] of the runner's output: axis-angle through the quaternion route (pytorch3d semantics)."""
+    from oracle import p3d_ref
+    from uuo_mocap_amd import transforms as T
+
+    g = torch.Generator().manual_seed(4)
+    aa = torch.randn(200, 3, generator=g)
+    aa = aa / aa.norm(dim=-1, keepdim=True) * (torch.rand(200, 1, generator=g) * 3.0)  # angles in [0, 3) rad
+    aa[0] = 0.0
+    aa[1] = torch.tensor([1e-8, 0.0, 0.0])
+    R = p3d_ref.axis_angle_to_matrix(aa)
+    back = T.matrix_to_axis_angle(R)
+    # the quaternion is not sign-standardised (pytorch3d 0.7.4), so the vector may describe the same rotation with
+    # an angle in (pi, 2 pi): compare the rotations
+    torch.testing.assert_close(p3d_ref.axis_angle_to_matrix(back), R, atol=2e-6, rtol=0)
+    torch.testing.assert_close(T.matrix_to_quaternion(R), p3d_ref.matrix_to_quaternion(R))
+
+
+def test_runner_conventions(tmp_path, tables):
+    """Counterpart of the reference's test/test.py: argument names, directory layout, skip-if-exists, output keys
+    and shapes, per-stage files (the fit itself is replaced by a stub: no GPU here)."""
+    from uuo_mocap_amd import runner
+    from uuo_mocap_amd.synthetic import make_sequence
+
+    root = tmp_path / "data"
+    seq = make_sequence(tables, seed=2, num_frames=6, num_markers=5)
+    for subject, name in (("s01", "walk"), ("s01", "run"), ("s02", "walk")):
+        d = root / "cmu_kitchen_pilot_rb" / "mocap" / subject
+        d.mkdir(parents=True, exist_ok=True)
+        runner.write_sequence_npz(str(d / (name + ".npz")), seq.markers.get_points(), 30.0, seq.img_smpl.pose_body,
+                                  seq.img_smpl.root_orient, seq.img_smpl.betas)
+    (root / "cmu_kitchen_pilot_rb" / "mocap" / "s02" / "jump.c3d").write_bytes(b"")
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("name: unit\n")
+    args = runner.build_parser().parse_args(["--config", str(cfg), "--dataset", "cmu_kitchen_pilot_rb", "--input_dir",
+                                             str(root), "--subjects", "s01"])
+    assert args.print_options == ["loss", "progress"] and args.num_files is None and args.sequences is None
+    calls = []
+
+    def fake_fit(img_smpl, markers):
+        F = markers.get_points().shape[0]
+        calls.append(F)
+        eye = torch.eye(3).expand(F, 23, 3, 3).clone()
+        out = {"betas": torch.zeros(F, 10), "trans": torch.zeros(F, 3), "root_orient": torch.eye(3).expand(F, 1, 3, 3),
+               "pose_body": eye, "mocap_frame_rate": markers.get_frequency(), "mocap_markers": markers,
+               "stages": {"chamfer": {"trans": np.zeros((F, 3), np.float32), "betas": np.zeros(10, np.float32),
+                                      "root_orient": np.tile(np.eye(3, dtype=np.float32), (F, 1, 1, 1)),
+                                      "pose_body": np.tile(np.eye(3, dtype=np.float32), (F, 23, 1, 1))}}}
+        return out
+
+    assert runner.run(args, fit_fn=fake_fit) == 2 and len(calls) == 2
+    res = root / "cmu_kitchen_pilot_rb" / "results" / "unit" / "s01"
+    out = np.load(res / "run_stageii.npz")
+    assert set(out.files) == {"betas", "trans", "poses", "mocap_frame_rate", "mocap_markers", "gender"}
+    assert out["betas"].shape == (10,) and out["trans"].shape == (6, 3) and out["poses"].shape == (6, 72)
+    assert out["mocap_markers"].shape == (6, 5, 3) and str(out["gender"]) == "neutral"
+    assert (res / "run_stageii.chamfer.npz").exists()
+    assert runner.run(args, fit_fn=fake_fit) == 0 and len(calls) == 2  # skip-if-exists
+    args2 = runner.build_parser().parse_args(["--config", str(cfg), "--dataset", "cmu_kitchen_pilot_rb", "--input_dir",
+                                              str(root), "--subjects", "s02", "--sequences", "jump"])
+    with pytest.raises(NotImplementedError):
+        runner.run(args2, fit_fn=fake_fit)  # .c3d readers are outside the accelerated path

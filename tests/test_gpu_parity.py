@@ -617,3 +617,36 @@ def test_direction_coefficients_block_inverse_vs_serial(dev, k):
         assert lib.uuo_debug_small_coeffs(k, 0, seed, new.ctypes.data) == 0
         scale = max(np.abs(ref).max(), 1e-30)
         assert np.abs(ref - new).max() <= 1e-12 * scale, (k, seed, np.abs(ref - new).max() / scale)
+
+
+def test_batch_runner_end_to_end(smpl, dev, tmp_path):
+    """uuo_mocap_amd.runner (counterpart of the reference's test/test.py) on two bundled sequences: output files, keys,
+    shapes, per-stage files, and the poses written are the fitted rotations."""
+    from uuo_mocap_amd import runner
+    from uuo_mocap_amd.config import CONFIG_DIR
+    from uuo_mocap_amd.transforms import axis_angle_to_matrix
+
+    root = tmp_path / "data"
+    d = root / "moyo_val" / "mocap" / "subj"
+    d.mkdir(parents=True)
+    for i in range(2):
+        seq = make_sequence(smpl.tables, seed=30 + i, num_frames=12, num_markers=9)
+        runner.write_sequence_npz(str(d / ("seq%d.npz" % i)), seq.markers.get_points(), 30.0, seq.img_smpl.pose_body,
+                                  seq.img_smpl.root_orient, seq.img_smpl.betas)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("parent: %s\nname: unit\nstages:\n  part:\n    num_iters: 8\n  chamfer:\n    num_iters: 8\n"
+                   "  marker:\n    num_iters: 8\n" % os.path.join(CONFIG_DIR, "video_mocap.yaml"))
+    args = runner.build_parser().parse_args(["--config", str(cfg), "--dataset", "moyo_val", "--input_dir", str(root),
+                                             "--gpu", "0", "--print_options"])
+    assert runner.run(args) == 2
+    res = root / "moyo_val" / "results" / "unit" / "subj"
+    for i in range(2):
+        out = np.load(res / ("seq%d_stageii.npz" % i))
+        assert out["poses"].shape == (12, 72) and out["trans"].shape == (12, 3) and out["betas"].shape == (10,)
+        assert out["mocap_markers"].shape == (12, 9, 3) and float(out["mocap_frame_rate"]) == 30.0
+        rot = axis_angle_to_matrix(torch.from_numpy(out["poses"]).reshape(12, 24, 3))
+        eye = torch.eye(3).expand(12, 24, 3, 3)
+        torch.testing.assert_close(rot @ rot.transpose(-1, -2), eye, atol=1e-5, rtol=0)
+        stage_files = sorted(x.name for x in res.iterdir() if x.name.startswith("seq%d_stageii." % i) and x.name.count(".") == 2)
+        assert len(stage_files) >= 2, stage_files
+    assert runner.run(args) == 0  # everything exists now
