@@ -35,7 +35,7 @@ NN_FLOPS_PER_FRAME_MARKER = 6890 * 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
@@ -49,12 +49,8 @@ def parse():
 def fit_once(smpl, seq, cfg, dev):
     from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
 
-    import contextlib
-    import io
-
-    with contextlib.redirect_stdout(io.StringIO()):  # the reference prints stage banners unconditionally
-        out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
-                                     save_stages=False, smpl_inference=smpl)
+    out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                 save_stages=False, smpl_inference=smpl)
     return out, copy.deepcopy(dict(last_run_stats()))
 
 
@@ -172,13 +168,19 @@ def main():
 
     from uuo_mocap_amd.parallel import fit_many
 
-    fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
-    barrier()
-    t0 = time.perf_counter()
-    all_stats = [st for _, st in fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev),
-                                          inflight=args.inflight, device=dev)]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    import contextlib
+    import io
+
+    # the reference prints stage banners unconditionally; sys.stdout is process-wide, so it is redirected once around
+    # the fits (not per fit: with sequences in flight the per-fit redirections would restore each other's streams)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        all_stats = [st for _, st in fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev),
+                                              inflight=args.inflight, device=dev)]
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
