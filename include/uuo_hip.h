@@ -56,6 +56,16 @@ int uuo_smpl_forward(uuo_model_t* model, void* stream, int F, const float* d_pos
                      int betas_rows, const float* d_root, const float* d_trans, float* d_verts,
                      float* d_joints);
 
+/* Backward of uuo_smpl_forward for given upstream gradients (what torch autograd computes through smplx.lbs when a
+ * caller differentiates SmplInference.forward itself, e.g. a user-written closure; reference utils/smpl.py:29-50).
+ *   d_up_verts  [F,6890,3] dL/dvertices or NULL,  d_up_joints [F,45,3] dL/djoints or NULL (at least one)
+ *   d_g_poses [F,23,3,3], d_g_betas [F,10] (per frame: sum the rows if betas had one row), d_g_root [F,1,3,3],
+ *   d_g_trans [F,3];  d_scratch: F*24 floats of device scratch.  Asynchronous on `stream`. */
+int uuo_smpl_backward(uuo_model_t* model, void* stream, int F, const float* d_poses, const float* d_betas,
+                      int betas_rows, const float* d_root, const float* d_trans, const float* d_up_verts,
+                      const float* d_up_joints, float* d_g_poses, float* d_g_betas, float* d_g_root, float* d_g_trans,
+                      float* d_scratch);
+
 /* ---- K=1 nearest neighbour ------------------------------------------------------------------------
  * Replaces pytorch3d.ops.knn_points(K=1) as reached through pytorch3d.loss.chamfer_distance from
  * weighted_chamfer_distance (src/video_mocap/losses/chamfer_distance.py:5-21) and

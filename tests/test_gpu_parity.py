@@ -650,3 +650,34 @@ def test_batch_runner_end_to_end(smpl, dev, tmp_path):
         stage_files = sorted(x.name for x in res.iterdir() if x.name.startswith("seq%d_stageii." % i) and x.name.count(".") == 2)
         assert len(stage_files) >= 2, stage_files
     assert runner.run(args) == 0  # everything exists now
+
+
+@pytest.mark.parametrize("F,shared_betas,with_joints", [(5, False, True), (19, True, True), (33, False, False)])
+def test_smpl_forward_backward_matches_autograd(smpl, oracle_smpl, dev, F, shared_betas, with_joints):
+    """SmplInference.forward is differentiable as an operator (user closures): its backward (uuo_smpl_backward, the
+    fitted path's gather kernel run over all vertices) against torch autograd through the CPU restatement of
+    smplx.lbs, for random upstream gradients on vertices and on the 45 joints."""
+    g = torch.Generator().manual_seed(100 + F)
+    rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
+    betas = torch.randn(1 if shared_betas else F, 10, generator=g)
+    trans = torch.randn(F, 3, generator=g)
+    wv = torch.randn(F, 6890, 3, generator=g)
+    wj = torch.randn(F, 45, 3, generator=g)
+
+    def loss_of(out):
+        l = (out["vertices"] * wv.to(out["vertices"].device)).sum()
+        if with_joints:
+            l = l + 50.0 * (out["joints"] * wj.to(out["joints"].device)).sum()
+        return l
+
+    leaves_ref = [t.clone().requires_grad_(True) for t in (rot[:, 1:], betas, rot[:, :1], trans)]
+    ref_out = oracle_smpl(leaves_ref[0], leaves_ref[1].expand(F, 10), leaves_ref[2], leaves_ref[3])
+    loss_of(ref_out).backward()
+    leaves = [t.clone().to(dev).requires_grad_(True) for t in (rot[:, 1:], betas, rot[:, :1], trans)]
+    out = smpl(leaves[0], leaves[1].expand(F, 10), leaves[2], leaves[3])
+    loss_of(out).backward()
+    for name, a, b in zip(("poses", "betas", "root", "trans"), leaves, leaves_ref):
+        ga, gb = a.grad.cpu(), b.grad
+        assert ga.shape == gb.shape, name
+        err = (ga - gb).norm() / gb.norm().clamp_min(1e-12)
+        assert err < 2e-4, (name, float(err))

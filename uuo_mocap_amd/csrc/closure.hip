@@ -3,9 +3,12 @@
 // Only the <= M vertices a frame's markers touch carry gradient, so the backward is a gather-LBS over those
 // vertices instead of the reference's dense autograd GEMMs.
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "frame_math.h"
+
+#define UUO_STAGE_UPSTREAM 3  // internal: not a fitting stage (uuo_smpl_backward)
 
 struct BwdArgs {
   // model
@@ -40,6 +43,11 @@ struct BwdArgs {
   const float* dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
   int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat vector (-1 = absent)
   const float* frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
+  // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
+  // (+ the 21 vertex-picked joints) with dL/dv given, instead of markers with a residual
+  const float* up_verts;   // [F][V][3] or null
+  const float* up_joints;  // [F][45][3] or null
+  float* g_betas_frame;    // [F][10]
   float* frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
                       //              16 g.d, 17 sum|g|, 18 g.g, 19 max|g| over this frame's gradient entries
 };
@@ -152,7 +160,20 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
       float wgt = in ? 1.f : 0.f;
       float d2 = 0.f;
       int vi;
-      if (a.stage == UUO_STAGE_MARKER) {
+      float up0 = 0.f, up1 = 0.f, up2 = 0.f;
+      if (a.stage == UUO_STAGE_UPSTREAM) {
+        if (mm < a.V) {
+          vi = mm;
+          if (a.up_verts) {
+            const float* pu = a.up_verts + ((size_t)f * a.V + mm) * 3;
+            up0 = pu[0]; up1 = pu[1]; up2 = pu[2];
+          }
+        } else {  // joints 24..44 of SMPL.forward are vertices picked by id
+          vi = a.tree->extra_vids[mm - a.V];
+          const float* pu = a.up_joints + ((size_t)f * 45 + UUO_NUM_JOINTS + (mm - a.V)) * 3;
+          up0 = pu[0]; up1 = pu[1]; up2 = pu[2];
+        }
+      } else if (a.stage == UUO_STAGE_MARKER) {
         wgt *= a.mask[(size_t)f * M + mm];
         vi = a.assign[mm];
       } else {
@@ -167,8 +188,12 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
       if ((unsigned)vi >= (unsigned)a.V) vi = 0;  // never happens for a completed search; keeps the gather in bounds
       q.wgt = wgt;
       q.d2 = d2;
-      const float* px = a.markers + ((size_t)f * M + mm) * 3;
-      q.x0 = px[0]; q.x1 = px[1]; q.x2 = px[2];
+      if (a.stage == UUO_STAGE_UPSTREAM) {
+        q.x0 = up0; q.x1 = up1; q.x2 = up2;
+      } else {
+        const float* px = a.markers + ((size_t)f * M + mm) * 3;
+        q.x0 = px[0]; q.x1 = px[1]; q.x2 = px[2];
+      }
       const float* pt = a.PT + (size_t)vi * 3 * UUO_KB + sl;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -230,7 +255,10 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
       const float dx = cur.x0 - vx, dy = cur.x1 - vy, dz = cur.x2 - vz;
       float g[3];
       float loss_item;
-      if (a.stage == UUO_STAGE_MARKER) {
+      if (a.stage == UUO_STAGE_UPSTREAM) {
+        loss_item = 0.f;
+        g[0] = wgt * cur.x0; g[1] = wgt * cur.x1; g[2] = wgt * cur.x2;
+      } else if (a.stage == UUO_STAGE_MARKER) {
         const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float e = rr - a.d0;
         loss_item = wgt * (e * e);
@@ -454,7 +482,9 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) sdGR[j][r * 3 + c] = sdA[j * 12 + r * 4 + c] - dAt[r] * L.J[j][c];
-      sdGt[j][r] = dAt[r];
+      // joints 0..23 of SMPL.forward are the world translations G_j^t (+ transl): their upstream gradient enters here
+      const float uj = (a.stage == UUO_STAGE_UPSTREAM && a.up_joints) ? a.up_joints[((size_t)f * 45 + j) * 3 + r] : 0.f;
+      sdGt[j][r] = dAt[r] + uj;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -521,6 +551,7 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     float acc = red[4 + tid];
     for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj) acc += w_dpf[0][jj * 10 + tid];
     a.frame_part[(size_t)f * UUO_FP + 4 + tid] = acc;
+    if (a.stage == UUO_STAGE_UPSTREAM) a.g_betas_frame[(size_t)f * 10 + tid] = acc;
   }
   // body rotations
   if (j >= 1 && j < UUO_NUM_JOINTS) {
@@ -570,7 +601,11 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
     spsq[0] = 0.f;
     // d(Rz(z) root)/dz = [[-s,-c,0],[c,-s,0],[0,0,0]] root
     const float cz = L.Rz[0], sz = L.Rz[2];
-    if (a.stage == UUO_STAGE_CHAMFER) {
+    if (a.stage == UUO_STAGE_UPSTREAM) {
+      float* pg = a.g_root + (size_t)f * 9;  // the root rotation is an input as it stands: dL/dR_0
+#pragma unroll
+      for (int e = 0; e < 9; ++e) pg[e] = sdR[0][e];
+    } else if (a.stage == UUO_STAGE_CHAMFER) {
       float da[6];
       gs6d_backward(L.Mroot, sdR[0], da);
       const float* r0 = a.src.root + (size_t)f * 9;
@@ -611,7 +646,10 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   }
   if (tid >= 32 && tid < 35 && a.g_trans) {
     const int c = tid - 32;
-    const float gt = red[1 + c];
+    float gt = red[1 + c];
+    if (a.stage == UUO_STAGE_UPSTREAM && a.up_joints) {
+      for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj) gt += a.up_joints[((size_t)f * 45 + jj) * 3 + c];
+    }
     a.g_trans[(size_t)f * 3 + c] = gt;
     sstat[24 + c][0] = gt * dpre[0];
     sstat[24 + c][1] = fabsf(gt); sstat[24 + c][2] = gt * gt; sstat[24 + c][3] = fabsf(gt);
@@ -960,5 +998,49 @@ extern "C" int uuo_debug_fit_buffers(uuo_fit_t* fit, float* h_verts, float* h_bb
     UUO_HIP_CHECK(hipMemcpy(h_verts, fit->verts, (size_t)fit->F * fit->model->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (h_bbox)
     UUO_HIP_CHECK(hipMemcpy(h_bbox, fit->bbox, (size_t)fit->F * ((fit->model->V + 15) / 16) * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+
+// ----------------------------------------------------------------------------------------------------
+// C ABI: backward of SmplInference.forward (reference utils/smpl.py:29-50 is differentiated by torch autograd
+// through smplx.lbs).  Same kernel as the fitted closures, in upstream-gradient mode: every vertex is an item.
+// ----------------------------------------------------------------------------------------------------
+extern "C" int uuo_smpl_backward(uuo_model_t* m, void* stream, int F, const float* d_poses, const float* d_betas,
+                                 int betas_rows, const float* d_root, const float* d_trans, const float* d_up_verts,
+                                 const float* d_up_joints, float* d_g_poses, float* d_g_betas, float* d_g_root,
+                                 float* d_g_trans, float* d_scratch /* [F * UUO_FP] */) {
+  UUO_REQUIRE(m && d_poses && d_betas && d_root && d_g_poses && d_g_betas && d_g_root && d_g_trans && d_scratch,
+              "uuo_smpl_backward: null argument");
+  UUO_REQUIRE(d_up_verts || d_up_joints, "uuo_smpl_backward: no upstream gradient");
+  UUO_REQUIRE(F > 0, "uuo_smpl_backward: F must be positive");
+  UUO_REQUIRE(betas_rows == 1 || betas_rows == F, "uuo_smpl_backward: betas rows must be 1 or F");
+  UUO_REQUIRE(m->nnz <= 4, "uuo_smpl_backward: needs the sparse skin-weight table (<= 4 weights per vertex)");
+  hipStream_t s = (hipStream_t)stream;
+  BwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wd = m->W; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
+  a.src.body = d_poses;
+  a.src.norm_body = 0;
+  a.src.root = d_root;
+  a.src.root_mode = UUO_ROOT_RAW;
+  a.src.z = nullptr;
+  a.src.betas = d_betas;
+  a.src.betas_stride = (betas_rows == 1) ? 0 : 10;
+  a.src.trans = d_trans;
+  a.stage = UUO_STAGE_UPSTREAM;
+  a.F = F;
+  a.M = m->V + (d_up_joints ? UUO_NUM_EXTRA_JOINTS : 0);
+  a.raw_pose = d_poses;
+  a.g_pose = d_g_poses;
+  a.g_root = d_g_root;
+  a.g_trans = d_g_trans;
+  a.g_betas_frame = d_g_betas;
+  a.up_verts = d_up_verts;
+  a.up_joints = d_up_joints;
+  a.frame_part = d_scratch;
+  a.off_pose = a.off_root = a.off_z = a.off_trans = -1;
+  hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

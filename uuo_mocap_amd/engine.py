@@ -131,6 +131,30 @@ class DeviceModel:
                   "uuo_smpl_forward")
         return verts, joints
 
+    def smpl_backward(self, poses, betas, root_orient, trans, d_verts, d_joints):
+        """uuo_smpl_backward: gradients of uuo_smpl_forward's outputs' upstream (d_verts [F,V,3] / d_joints [F,45,3],
+        either may be None) with respect to poses [F,23,3,3], betas (its own shape), root_orient [F,1,3,3], trans."""
+        poses = _f32(poses, "poses")
+        betas_c = _f32(betas, "betas")
+        root = _f32(root_orient, "root_orient")
+        F = poses.shape[0]
+        tr = _f32(trans, "trans") if trans is not None else None
+        dv = _f32(d_verts, "d_verts") if d_verts is not None else None
+        dj = _f32(d_joints, "d_joints") if d_joints is not None else None
+        g_poses = torch.empty((F, 23, 3, 3), dtype=torch.float32, device=self.device)
+        g_betas = torch.empty((F, 10), dtype=torch.float32, device=self.device)
+        g_root = torch.empty((F, 1, 3, 3), dtype=torch.float32, device=self.device)
+        g_trans = torch.empty((F, 3), dtype=torch.float32, device=self.device)
+        scratch = torch.empty((F * 24,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_smpl_backward(self.handle, current_stream(self.device), F, _ptr(poses), _ptr(betas_c),
+                                             int(betas_c.shape[0]), _ptr(root), _ptr(tr), _ptr(dv), _ptr(dj),
+                                             _ptr(g_poses), _ptr(g_betas), _ptr(g_root), _ptr(g_trans), _ptr(scratch)),
+                  "uuo_smpl_backward")
+        if betas_c.shape[0] == 1:
+            g_betas = g_betas.sum(dim=0, keepdim=True)
+        return g_poses, g_betas, g_root, g_trans
+
     def nn_argmin(self, x, y, y_subset=None):
         """uuo_nn_argmin: x [N,P1,3], y [N,P2,3] -> (dist [N,P1] fp32, idx [N,P1] int32)."""
         x = _f32(x, "x")

@@ -14,19 +14,28 @@ from .engine import DeviceModel
 
 
 class _SmplForward(torch.autograd.Function):
-    """Forward on the GPU; the dense backward of the standalone operator is not built (round 1): gradients of
-    the fit flow through the fused stage closures (engine.*Problem), never through this operator."""
+    """Forward and backward on the GPU.  Gradients of the fit flow through the fused stage closures
+    (engine.*Problem), never through this operator; a caller who
+    differentiates the operator itself (own closure, own loss) gets the same sparse-gather backward kernel run over
+    all vertices (uuo_smpl_backward)."""
 
     @staticmethod
     def forward(ctx, model: DeviceModel, poses, betas, root_orient, trans):
         verts, joints = model.smpl_forward(poses, betas, root_orient, trans, want_joints=True)
+        ctx.model = model
+        ctx.has_trans = trans is not None
+        ctx.save_for_backward(poses, betas, root_orient, trans if trans is not None else poses.new_zeros(0))
         return joints, verts
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(
-            "SmplInference.forward has no standalone backward: use optim_chamfer / optim_markers / "
-            "find_best_part_fits, whose closures carry a hand-derived sparse backward on the GPU")
+    def backward(ctx, d_joints, d_verts):
+        poses, betas, root_orient, trans = ctx.saved_tensors
+        if d_joints is None and d_verts is None:
+            return None, None, None, None, None
+        g_poses, g_betas, g_root, g_trans = ctx.model.smpl_backward(
+            poses, betas, root_orient, trans if ctx.has_trans else None, d_verts, d_joints)
+        return (None, g_poses.to(poses.dtype), g_betas.to(betas.dtype), g_root.to(root_orient.dtype),
+                g_trans.to(trans.dtype) if ctx.has_trans else None)
 
 
 class SmplInference(nn.Module):
