@@ -137,14 +137,18 @@ __global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* _
 }
 
 // History layout.  S and Y are stored in column blocks of LB_CW floats: element i of slot j lives at
-//   ((i / LB_CW) * capL + j) * LB_CW + i % LB_CW            (capL = allocated slots)
+//   (i / LB_CW) * (capL * LB_CW + LB_CBPAD) + j * LB_CW + i % LB_CW            (capL = allocated slots)
 // so that all the slots of one column block are one contiguous region (capL x 2 KB).  Both passes over the history --
 // the row-wise dots below and the column-wise combination in k_lb_direction -- then stream contiguous memory:
 // a block reads capL consecutive 2-KB pieces instead of 2-KB (or 512-byte) pieces 260 KB apart, which is what
 // HBM pages and the MALL like; the first version (row-major history) reached ~2.5 TB/s however many solves ran.
 #define LB_CW 512
+#define LB_CBPAD 64  // floats of padding after each column block's slots: region stride = odd multiple of 256 B, so
+                     // that blocks working on different column blocks at the same slot do not camp on the same
+                     // memory channels (101 x 2 KB alone is 808 x 256 B)
+#define LB_CBSTRIDE(capL) ((size_t)(capL) * LB_CW + LB_CBPAD)
 __device__ __host__ __forceinline__ size_t lb_hist_off(int slot, int i, int capL) {
-  return ((size_t)(i / LB_CW) * capL + slot) * LB_CW + (i % LB_CW);
+  return (size_t)(i / LB_CW) * LB_CBSTRIDE(capL) + (size_t)slot * LB_CW + (i % LB_CW);
 }
 
 // rows of the history (and g) against {y_new, s_new, g}: skinny GEMM, fp64 accumulation.
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int h
   float4 ng[2], np_[2], nd[2], nr[LB_DRW][2];
   auto issue = [&](int cb) {
     const int ibase = cb * LB_CW;
-    const size_t cboff = (size_t)cb * capL * LB_CW;
+    const size_t cboff = (size_t)cb * LB_CBSTRIDE(capL);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int i = ibase + h * 256 + lane * 4;  // vectors are padded to a multiple of LB_CW: in-bounds loads
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int h
       }
     }
     if (special) {  // wave-uniform: the new pair's own rows and g, and the store of the pair
-      float* yn = Y + ((size_t)cb * capL + cand) * LB_CW + lane * 4;
-      float* sn = S + ((size_t)cb * capL + cand) * LB_CW + lane * 4;
+      float* yn = Y + (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + lane * 4;
+      float* sn = S + (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + lane * 4;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         *reinterpret_cast<float4*>(yn + h * 256) = vy[h];
@@ -850,18 +854,19 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
   }
 }
 
-__global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
+__global__ __launch_bounds__(128) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
                                                        const float* __restrict__ Y, const float* __restrict__ g,
                                                        LbDev* __restrict__ st, float* __restrict__ d,
                                                        const float* __restrict__ x, float t, float* __restrict__ xt) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass.
-  // One block per column block of the history (LB_CW columns, two per thread): the slots it combines are one
-  // contiguous region; 16 slots (32 loads of 8 bytes per thread) are in flight at a time.
+  // One block per column block of the history (LB_CW columns, FOUR per thread: 16-byte loads -- the vector-memory
+  // pipe costs ~16 cycles per wave instruction whatever its width, and 8-byte loads made this kernel bound by it):
+  // the slots it combines are one contiguous region; two batches of 8 slots (16 loads) are in flight per thread.
   __shared__ double scy[LB_MAXH + 16], scs[LB_MAXH + 16];
   __shared__ int sslot[LB_MAXH + 16];
   const int k = st->count, head = st->head;
-  for (int j = threadIdx.x; j < LB_MAXH + 16; j += 256) {
+  for (int j = threadIdx.x; j < LB_MAXH + 16; j += 128) {
     const bool on = j < k;
     const int sj = on ? (head + j) % cap : 0;
     sslot[j] = sj;
@@ -870,36 +875,49 @@ __global__ __launch_bounds__(256) void k_lb_direction(int n, int cap, int capL, 
   }
   __syncthreads();
   const int cb = blockIdx.x;
-  const int c = threadIdx.x * 2;       // column pair inside the block
-  const int i = cb * LB_CW + c;
+  const int c = threadIdx.x * 4;       // four columns inside the block
+  const int i = cb * LB_CW + c;        // work vectors are padded to whole column blocks: 16-byte accesses in bounds
   float mx = 0.f;
   if (i < n) {
-    const float2 gv = *reinterpret_cast<const float2*>(g + i);
-    double acc0 = st->cg * (double)gv.x, acc1 = st->cg * (double)gv.y;
-    const float* Sb = S + (size_t)cb * capL * LB_CW + c;
-    const float* Yb = Y + (size_t)cb * capL * LB_CW + c;
-    for (int j0 = 0; j0 < k; j0 += 16) {
-      float2 yv[16], sv[16];
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    const double cg = st->cg;
+    double acc[4] = {cg * (double)gv.x, cg * (double)gv.y, cg * (double)gv.z, cg * (double)gv.w};
+    const float* Sb = S + (size_t)cb * LB_CBSTRIDE(capL) + c;
+    const float* Yb = Y + (size_t)cb * LB_CBSTRIDE(capL) + c;
+    float4 yv[2][8], sv[2][8];
+    auto issue = [&](int j0, int buf) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
+      for (int u = 0; u < 8; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
         const size_t off = (size_t)sslot[j0 + u] * LB_CW;
-        yv[u] = *reinterpret_cast<const float2*>(Yb + off);
-        sv[u] = *reinterpret_cast<const float2*>(Sb + off);
+        yv[buf][u] = *reinterpret_cast<const float4*>(Yb + off);
+        sv[buf][u] = *reinterpret_cast<const float4*>(Sb + off);
       }
+    };
+    auto consume = [&](int j0, int buf) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        acc0 += scy[j0 + u] * (double)yv[u].x + scs[j0 + u] * (double)sv[u].x;
-        acc1 += scy[j0 + u] * (double)yv[u].y + scs[j0 + u] * (double)sv[u].y;
+      for (int u = 0; u < 8; ++u) {
+        const double cy = scy[j0 + u], cs = scs[j0 + u];
+        acc[0] += cy * (double)yv[buf][u].x + cs * (double)sv[buf][u].x;
+        acc[1] += cy * (double)yv[buf][u].y + cs * (double)sv[buf][u].y;
+        acc[2] += cy * (double)yv[buf][u].z + cs * (double)sv[buf][u].z;
+        acc[3] += cy * (double)yv[buf][u].w + cs * (double)sv[buf][u].w;
       }
+    };
+    if (k > 0) issue(0, 0);
+    for (int j0 = 0; j0 < k; j0 += 16) {
+      if (j0 + 8 < k) issue(j0 + 8, 1);
+      consume(j0, 0);
+      if (j0 + 16 < k) issue(j0 + 16, 0);
+      if (j0 + 8 < k) consume(j0 + 8, 1);
     }
-    const float d0 = (float)acc0, d1 = (float)acc1;
-    d[i] = d0;
-    xt[i] = x[i] + t * d0;
-    mx = fabsf(d0);
-    if (i + 1 < n) {
-      d[i + 1] = d1;
-      xt[i + 1] = x[i + 1] + t * d1;
-      mx = fmaxf(mx, fabsf(d1));
+    const float dd[4] = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i + e < n) {  // x may be the caller's tensor of exactly n floats: element-wise, guarded
+        d[i + e] = dd[e];
+        xt[i + e] = x[i + e] + t * dd[e];
+        mx = fmaxf(mx, fabsf(dd[e]));
+      }
     }
   }
 #pragma unroll
@@ -1007,8 +1025,9 @@ static int lbws_create(int n, int hist, LbWs** out) {
   auto A = [&](void** p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes);
   };
-  A((void**)&w->S, (size_t)w->cap * n * sizeof(float));
-  A((void**)&w->Y, (size_t)w->cap * n * sizeof(float));
+  const size_t hist_floats = (size_t)(n / LB_CW) * LB_CBSTRIDE(w->cap);
+  A((void**)&w->S, hist_floats * sizeof(float));
+  A((void**)&w->Y, hist_floats * sizeof(float));
   A((void**)&w->vecs, (size_t)LB_NVEC * n * sizeof(float));
   const size_t part_dots = (size_t)w->nchunks * LB_ROWS * 3;
   A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
@@ -1019,8 +1038,8 @@ static int lbws_create(int n, int hist, LbWs** out) {
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
   if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(w->S, 0, (size_t)w->cap * n * sizeof(float));
-  if (e == hipSuccess) e = hipMemset(w->Y, 0, (size_t)w->cap * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(w->S, 0, hist_floats * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(w->Y, 0, hist_floats * sizeof(float));
   if (e == hipSuccess) e = hipMemset(w->vecs, 0, (size_t)LB_NVEC * n * sizeof(float));
   // null-stream memsets are not ordered with the (non-blocking) stream the first solve runs on
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1205,7 +1224,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         else
           hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(256), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
+        hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(128), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
                            (float)t, xoth);
       }
       UUO_HIP_CHECK(hipGetLastError());
