@@ -46,7 +46,8 @@ class RecordingLBFGS(torch.optim.LBFGS):
             loss = closure()
             rec["losses"].append(float(loss))
             if rec["first_grad"] is None:
-                rec["first_grad"] = torch.cat([p.grad.reshape(-1) for p in params]).numpy().copy()
+                rec["first_grad"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                               for p in params]).numpy().copy()
             return loss
 
         return super().step(wrapped)

@@ -540,3 +540,123 @@ def multimodal_video_mocap(img_smpl, mocap_markers, smpl_inference, config, devi
     if filter_output is not None:
         output["chain"] = filter_output["chain"]
     return output
+
+
+# ----------------------------------------------------------------------------------------------
+# reprojection stage (utils/hmr_utils.py:14-124,127-167,170-425) -- disabled in every shipped config
+# ----------------------------------------------------------------------------------------------
+
+def perspective_projection(points, translation, focal_length, camera_center=None, rotation=None):
+    """hmr_utils.py:14-52, with the explicit intrinsic matrix."""
+    b = points.shape[0]
+    if rotation is None:
+        rotation = torch.eye(3, dtype=points.dtype).unsqueeze(0).expand(b, -1, -1)
+    if camera_center is None:
+        camera_center = torch.zeros(b, 2, dtype=points.dtype)
+    K = torch.zeros([b, 3, 3], dtype=points.dtype)
+    K[:, 0, 0] = focal_length[:, 0]
+    K[:, 1, 1] = focal_length[:, 1]
+    K[:, 2, 2] = 1.0
+    K[:, :-1, -1] = camera_center
+    points = torch.einsum("bij,bkj->bki", rotation, points) + translation.unsqueeze(1)
+    projected = points / points[:, :, -1].unsqueeze(-1)
+    projected = torch.einsum("bij,bkj->bki", K, projected)
+    return projected[:, :, :-1]
+
+
+def hmr_to_mocap(pos):
+    return torch.cat((pos[..., [0]], pos[..., [2]], pos[..., [1]] * -1), dim=-1)
+
+
+def mocap_to_hmr(pos):
+    return torch.cat((pos[..., [0]], pos[..., [2]] * -1, pos[..., [1]]), dim=-1)
+
+
+def compute_root_orient_y(angle: torch.Tensor) -> torch.Tensor:
+    pad = torch.zeros_like(angle)
+    return axis_angle_to_matrix(torch.cat((pad, angle, pad), dim=-1))
+
+
+def get_3d_parameters(smpl_inference, betas, body_pose, global_orient, pred_cam, center, size, scale):
+    """hmr_utils.py:57-124."""
+    focal = 5000.0
+    img = 256
+    n = pred_cam.shape[0]
+    new_size = torch.max(size, dim=-1, keepdim=True)[0]
+    top, left = (new_size - size[:, [0]]) // 2, (new_size - size[:, [1]]) // 2
+    ratio = 1.0 / torch.round(new_size) * img
+    center = (center + torch.cat((left, top), dim=-1)) * ratio
+    scale = scale * new_size * ratio
+    focal_length = focal * torch.ones(n, 2)
+    joints = smpl_inference(body_pose, betas, global_orient, torch.zeros((n, 3)))["joints"]
+    tmp = torch.stack([pred_cam[:, 1], pred_cam[:, 2], 2 * focal_length[:, 0] / (pred_cam[:, 0] * scale[:, 0] + 1e-9)], dim=1)
+    cam_t = torch.cat((tmp[:, :2] + (center - img / 2.0) * tmp[:, [2]] / focal_length, tmp[:, [2]]), dim=1)
+    kp = perspective_projection(joints, cam_t, focal_length / img, torch.zeros(n, 2),
+                                torch.eye(3).unsqueeze(0).expand(n, -1, -1))
+    kp = (kp + 0.5) * img
+    return {"camera_center": torch.zeros(n, 2), "focal_length": focal_length / img, "pred_cam_t": cam_t,
+            "pred_joints": joints, "pred_keypoints_2d_smpl": kp / img}
+
+
+def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size,
+                       cam_scale, angle, img_mask, smpl_inference, num_iters, config, trace: Optional[list] = None):
+    """hmr_utils.py:170-425 (A = 1 hypothesis axis kept).  Derived outputs are those of the last closure evaluation,
+    as the reference's nonlocal temporaries leave them."""
+    F_ = pose_body.shape[0]
+    w = config["stages"]["reprojection_part"]["losses"]
+    pose_body, root_orient, trans = pose_body.clone(), root_orient.clone(), trans.clone()
+    betas = betas.clone().detach()
+    correction = torch.tensor([[[[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]]]).repeat_interleave(F_, dim=0)
+    jo = get_3d_parameters(smpl_inference, hmr_betas, pose_body, root_orient, pred_cam.clone(), cam_center.clone(),
+                           cam_size.clone(), cam_scale.clone())
+    target = torch.nan_to_num(jo["pred_keypoints_2d_smpl"][None], 0)
+    cam_translation = jo["pred_cam_t"]
+    mask = torch.mean((cam_translation == cam_translation).float(), dim=-1).detach()
+    cam_translation = torch.nan_to_num(cam_translation, 0)
+    body_from_cam = cam_translation
+    cam_translation = trans.clone().detach()
+    offset = mocap_to_hmr(torch.median(markers.reshape(-1, 3), dim=0, keepdim=True)[0]) - \
+        torch.median(body_from_cam, dim=0, keepdim=True)[0]
+    body_t = (body_from_cam + offset)[None].clone()
+    body_t.requires_grad_(True)
+    cam_single = torch.mean(cam_translation - offset, dim=0, keepdim=True).clone()
+    cam_single.requires_grad_(True)
+    yaw = (torch.ones(1, 1, 1, 1) * angle).requires_grad_(True)
+    focal = torch.mean(jo["focal_length"], dim=0, keepdim=True)
+    opt = torch.optim.LBFGS([yaw, body_t, cam_single, betas], max_iter=num_iters,
+                            tolerance_grad=config["optimizer"]["tolerance_grad"],
+                            tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
+                            line_search_fn="strong_wolfe")
+    betas_rep = torch.repeat_interleave(betas, repeats=F_, dim=0)
+    last = {}
+
+    def closure():
+        opt.zero_grad()
+        cam_tr = torch.repeat_interleave(cam_single[:, None], dim=1, repeats=F_)
+        yaw_f = torch.repeat_interleave(yaw, repeats=F_, dim=1)
+        y_root = compute_root_orient_y(yaw_f) @ root_orient
+        off = body_t - cam_tr
+        rot = compute_root_orient_y(-yaw_f)[:, 0]
+        inv_t = (rot @ off[..., None])[..., 0] + cam_tr
+        out = smpl_inference(pose_body, betas_rep, root_orient, inv_t.flatten(0, 1))
+        kp = perspective_projection(out["joints"], cam_tr.flatten(0, 1), torch.repeat_interleave(focal, dim=0, repeats=F_),
+                                    jo["camera_center"], torch.eye(3).unsqueeze(0).expand(F_, -1, -1)).reshape(1, F_, 45, 2) + 0.5
+        loss = torch.mean((kp - target) ** 2 * mask[None, :, None, None]) * w["reprojection"]
+        verts = smpl_inference(pose_body, betas_rep, (correction @ y_root).flatten(0, 1), hmr_to_mocap(body_t).flatten(0, 1))["vertices"]
+        loss = loss + chamfer_distance(markers, verts, single_directional=True)[0] * w["chamfer"]
+        loss.backward()
+        if trace is not None:
+            trace.append(float(loss))
+        last.update(cam_tr=cam_tr.detach(), y_root=y_root.detach(), inv_t=inv_t.detach(), kp=kp.detach())
+        return loss
+
+    opt.step(closure)
+    with torch.no_grad():
+        world = smpl_inference(pose_body, betas_rep, (correction @ last["y_root"]).flatten(0, 1), last["inv_t"].flatten(0, 1))["vertices"]
+        rep_err = torch.mean((last["kp"][0] - target[0]) ** 2 * mask[None, :, None, None]).item()
+        ch_err = chamfer_distance(markers, world, single_directional=True)[0].item()
+    return {"pose_body": pose_body[None].detach(), "betas": betas_rep[None].detach(),
+            "root_orient": (correction @ last["y_root"]).detach(), "trans": hmr_to_mocap(body_t.detach()),
+            "joints_2d": last["kp"], "joints_2d_gt": target, "cam_trans": hmr_to_mocap(last["cam_tr"]),
+            "camera_center": jo["camera_center"].clone(), "focal_length": focal.clone(), "reproject_mask": mask.clone(),
+            "input_angle": float(angle), "output_angle": yaw.item(), "metrics": {"chamfer": ch_err, "reproject": rep_err}}

@@ -142,3 +142,31 @@ def test_end_to_end_matches_reference(golden, oracle_smpl, tag, cfg_name):
     np.testing.assert_allclose(out["pose_body"].numpy(), g["out_pose_body"], atol=2e-4)
     np.testing.assert_allclose(out["root_orient"].numpy(), g["out_root_orient"], atol=2e-4)
     np.testing.assert_allclose(out["betas"].numpy(), g["out_betas"], atol=2e-4)
+
+
+def test_reprojection_stage_matches_reference(oracle_smpl, golden):
+    """The oracle's restatement of optim_reprojection against the fixture captured from the reference's own
+    hmr_utils.optim_reprojection (two yaw hypotheses): first loss / gradient, the loss trajectory, final outputs."""
+    g = golden("reprojection_stage.npz")
+    cfg = packaged_config("video_mocap")
+    cfg["stages"]["reprojection_part"]["num_iters"] = 200
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).float()
+    for name, angle in (("a0", 0.0), ("a1", float(np.pi / 2))):
+        trace = []
+        out = stages_ref.optim_reprojection(
+            markers=t("markers"), pose_body=t("hmr_pose_body"), betas=t("betas"), hmr_betas=t("hmr_betas"),
+            root_orient=t("hmr_root_orient"), trans=t("trans"), pred_cam=t("pred_cam"), cam_center=t("center"),
+            cam_size=t("size"), cam_scale=t("scale"), angle=torch.tensor(angle), img_mask=t("img_mask"),
+            smpl_inference=oracle_smpl, num_iters=200, config=cfg, trace=trace)
+        ref = g[name + "_losses"]
+        n = min(len(trace), len(ref), 20)
+        np.testing.assert_allclose(trace[:n], ref[:n], rtol=2e-4)
+        assert abs(len(trace) - len(ref)) <= max(10, len(ref) // 5)
+        np.testing.assert_allclose(out["joints_2d_gt"].numpy(), g[name + "_joints_2d_gt"], atol=1e-5)
+        np.testing.assert_allclose(out["focal_length"].numpy(), g[name + "_focal_length"], rtol=1e-6)
+        np.testing.assert_allclose(out["reproject_mask"].numpy(), g[name + "_reproject_mask"])
+        assert out["input_angle"] == pytest.approx(float(g[name + "_angles"][0]))
+        assert out["output_angle"] == pytest.approx(float(g[name + "_angles"][1]), abs=5e-3)
+        np.testing.assert_allclose(out["trans"].numpy(), g[name + "_trans"], atol=5e-3)
+        np.testing.assert_allclose(out["joints_2d"].numpy(), g[name + "_joints_2d"], atol=5e-3)
+        assert trace[-1] == pytest.approx(float(ref[-1]), rel=0.05)

@@ -64,7 +64,10 @@ def multimodal_video_mocap(
     `smpl_inference` (extension) lets callers reuse one model/workspace across sequences."""
     if save_iterations or visualize_fits:
         raise NotImplementedError("save_iterations / visualize_fits are visualisation features, not built")
-    for key in ("reprojection_part", "reprojection_full", "root"):
+    for key in ("reprojection_full", "root"):
+        # both are disabled in every shipped config and cannot run in the reference as written (reprojection_full calls
+        # optim_reprojection without its img_mask argument, multimodal.py:396-413; optim_root reads an undefined
+        # o_betas and a missing 'lr' key, optimization.py:51,112)
         if config["stages"][key]["num_iters"] > 0:
             raise NotImplementedError("stage '%s' is disabled in every shipped config and is not built" % key)
     if mocap_markers.get_frequency() != img_smpl.freq:
@@ -120,6 +123,31 @@ def multimodal_video_mocap(
     filter_output = None
     smpl_part = None
     if config["find_best_part_fits"]:
+        rp = config["stages"]["reprojection_part"]
+        if rp["num_iters"] > 0:
+            # Stage [reprojection_part] (reference multimodal.py:248-331; off in every shipped config): yaw hypotheses
+            # of the camera-consistent placement, the best one by reprojection (or chamfer) error replaces the HMR
+            # root orientation / translation / shape that the part search starts from.
+            from .reprojection import optim_reprojection
+
+            trans = torch.median(markers, dim=1)[0].requires_grad_(True)
+            betas = o_betas.clone().requires_grad_(True)
+            angles = torch.arange(0, 2 * np.pi, (2 * np.pi) / rp["num_angles"])
+            hyps = [optim_reprojection(
+                markers=markers, pose_body=o_pose_body, betas=betas, hmr_betas=img_smpl.betas.clone().detach().to(device),
+                root_orient=img_smpl.hmr_root_orient.clone().detach().to(device), trans=trans,
+                pred_cam=img_smpl.camera_bbox.clone().detach().to(device),
+                cam_center=img_smpl.center.clone().detach().to(device), cam_size=img_smpl.size.clone().detach().to(device),
+                cam_scale=img_smpl.scale.clone().detach().to(device), angle=angles[k], img_mask=img_mask,
+                smpl_inference=smpl_inference, config=config, num_iters=rp["num_iters"], verbose=verbose)
+                for k in range(rp["num_angles"])]
+            key = {"reprojection": "reproject", "chamfer": "chamfer"}[rp["criterion"]]
+            best = int(np.argmin([h["metrics"][key] for h in hyps]))
+            stats["reprojection_part"] = [dict(h["metrics"], input_angle=h["input_angle"], output_angle=h["output_angle"])
+                                          for h in hyps]
+            o_betas = torch.mean(hyps[best]["betas"][0], dim=0, keepdim=True).clone().detach()
+            o_root_orient = hyps[best]["root_orient"][0].clone().detach()
+            o_trans = hyps[best]["trans"][0].clone().detach()
         filter_output = find_best_part_fits(
             markers=markers, pose_body=o_pose_body, betas=o_betas, root_orient=o_root_orient,
             marker_labels=segmented_markers, smpl_inference=smpl_inference, hierarchy=smpl_inference.smpl.parents,

@@ -202,3 +202,16 @@ def make_sequence(tables: SmplTables, seed: int = 0, num_frames: int = 300, num_
         "marker_vids": pick[perm],
     }
     return SyntheticSequence(img_smpl=img, markers=SyntheticMarkers(markers.astype(np.float32), 30.0), gt=gt)
+
+
+def synthetic_hmr_camera(num_frames: int, seed: int = 5):
+    """A plausible HMR 2.0 weak-perspective camera for the reprojection stage: `camera_bbox` (scale, shift x, shift y)
+    [F,3], bounding-box `center` [F,2] in pixels, image `size` (H, W) [F,2] and bounding-box `scale` [F,1]."""
+    from .body_model import hash_uniform
+
+    u = hash_uniform(seed, num_frames, 6)
+    pred_cam = np.stack([0.85 + 0.2 * u[:, 0], 0.1 * (u[:, 1] - 0.5), 0.1 * (u[:, 2] - 0.5)], axis=1)
+    center = np.stack([300.0 + 40 * u[:, 3], 220.0 + 30 * u[:, 4]], axis=1)
+    size = np.tile(np.array([[480.0, 640.0]]), (num_frames, 1))
+    scale = 0.35 + 0.1 * u[:, [5]]
+    return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in (pred_cam, center, size, scale)]
