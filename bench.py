@@ -205,8 +205,8 @@ def main():
         skin_flops = SKIN_FLOPS_PER_FRAME * F
         achieved = skin_flops / (skin_ms * 1e-3) / 1e12
         # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r1_pmc_summary.json):
-        # FETCH_SIZE 15 259 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 390 KB, at F=300
-        traffic = (15259 * 2 + 30390) * 1024 if (F == 300) else None
+        # FETCH_SIZE 15 084 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 400 KB, at F=300
+        traffic = (15084 * 2 + 30400) * 1024 if (F == 300) else None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                     "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
