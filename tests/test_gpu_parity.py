@@ -100,6 +100,22 @@ def test_nn_bit_exact_vs_cpu_loop(smpl, oracle_smpl, dev):
     d, i = smpl.device_model.nn_argmin(_t(a, dev), _t(b, dev), y_subset=_t(sub, dev))
     np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
     np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+    # few queries per cloud (partial marker sets take the lane = candidate kernel): P1 = 1, 9, 16, duplicates, subset
+    for p1 in (1, 9, 16):
+        q = rng.standard_normal((5, p1, 3)).astype(np.float32)
+        c = rng.standard_normal((5, 3001, 3)).astype(np.float32)
+        c[:, 2500] = c[:, 11]
+        q[:, 0] = c[:, 11]
+        d_ref, i_ref = p3d_ref.knn1_loop(q, c)
+        d, i = smpl.device_model.nn_argmin(_t(q, dev), _t(c, dev))
+        np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+        assert (i.cpu().numpy()[:, 0] == 11).all()
+        sub2 = np.sort(rng.permutation(3001)[:700]).astype(np.int32)
+        d_ref, i_ref = p3d_ref.knn1_loop(q, c[:, sub2])
+        d, i = smpl.device_model.nn_argmin(_t(q, dev), _t(c, dev), y_subset=_t(sub2, dev))
+        np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
 
 
 def test_weighted_chamfer_kat_and_backward(dev):

@@ -66,11 +66,65 @@ __global__ __launch_bounds__(64) void k_nn(const float* __restrict__ x, const fl
   if (valid && besti != 0xFFFFFFFFu) atomicMin(&out[(size_t)n * P1 + q], pack_key(best, besti));
 }
 
+// Few queries per cloud (partial marker sets: P1 <= 16): lane = query would leave most of the wave idle, so here
+// lane = candidate.  Every lane keeps the running (dist, index) key of each query over its candidates
+// (c = lane, lane + 64, ... in ascending order, strict '<' on the packed key = first index on ties), the wave merges
+// with 64-bit minima and one atomicMin per query and split.  Same packed-key order as k_nn: bit-identical results.
+#define NNQ_MAX 16
+__global__ __launch_bounds__(256) void k_nn_fewq(const float* __restrict__ x, const float* __restrict__ y,
+                                                 const int* __restrict__ ysub, int P1, int P2, int nc, int S,
+                                                 unsigned long long* __restrict__ out) {
+  __shared__ float sq[NNQ_MAX * 3];
+  const int n = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  if (tid < P1 * 3) sq[tid] = x[(size_t)n * P1 * 3 + tid];
+  __syncthreads();
+  const int per = (nc + S - 1) / S;
+  const int c0 = s * per, c1 = min(nc, c0 + per);
+  unsigned long long best[NNQ_MAX];
+#pragma unroll
+  for (int q = 0; q < NNQ_MAX; ++q) best[q] = ~0ull;
+  for (int c = c0 + tid; c < c1; c += 256) {
+    const int vi = ysub ? ysub[c] : c;
+    const float* py = y + ((size_t)n * P2 + vi) * 3;
+    const float px = py[0], pyv = py[1], pz = py[2];
+#pragma unroll
+    for (int q = 0; q < NNQ_MAX; ++q) {
+      if (q < P1) {  // block-uniform
+        const unsigned long long key = pack_key(sqdist(sq[q * 3], sq[q * 3 + 1], sq[q * 3 + 2], px, pyv, pz), (unsigned)c);
+        best[q] = key < best[q] ? key : best[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NNQ_MAX; ++q) {
+    if (q < P1) {
+      unsigned long long k = best[q];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o < k ? o : k;
+      }
+      if ((tid & 63) == 0 && k != ~0ull) atomicMin(&out[(size_t)n * P1 + q], k);
+    }
+  }
+}
+
 int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub, int P2s,
                   unsigned long long* packed) {
   const int nc = ysub ? P2s : P2;
   UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
   if (nc <= 0 || N <= 0 || P1 <= 0) return 0;
+  if (P1 <= NNQ_MAX) {
+    // splits so that N * S blocks of 256 threads cover the chip a few times, each lane seeing >= 4 candidates
+    int S = 1;
+    if (N < 1024) S = (1024 + N - 1) / N;
+    const int maxS = (nc + 1023) / 1024;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    hipLaunchKernelGGL(k_nn_fewq, dim3(N, S), dim3(256), 0, s, x, y, ysub, P1, P2, nc, S, packed);
+    UUO_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const int qgroups = (P1 + 63) / 64;
   // enough waves to fill the chip: target >= 4096 waves, at least 256 candidates per split
   int S = 1;
