@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation")
     ap.add_argument("--inflight", type=int, default=1, help="sequences fitted concurrently per GPU (parallel.fit_many)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the timing loops of the roofline section (one warm-up fit): the command profiled into "
+                         "profiles/r1_roofline_kernel_stats.csv")
     ap.add_argument("--cpu-evals", type=int, default=3, help="closure evaluations per stage type timed on the CPU")
     return ap.parse_args()
 
@@ -126,6 +129,39 @@ def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals):
     }
 
 
+def measure_roofline(smpl, seq, dev, F, iters=50):
+    from uuo_mocap_amd.config import packaged_config
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    # ---- roofline of the dominant kernel (k_skin: MFMA blend + skinning), HIP events on the launch stream
+    markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    full_cfg = packaged_config("video_mocap")
+    prob = ChamferProblem(smpl, markers, seq.img_smpl.pose_body.to(dev), o_betas, seq.img_smpl.root_orient.to(dev),
+                          full_cfg)
+    x = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas,
+                  seq.img_smpl.pose_body.to(dev))
+    skin_ms = prob.time_closure(x, iters=iters, dominant_only=True)
+    closure_ms = prob.time_closure(x, iters=iters, dominant_only=False)
+    skin_flops = SKIN_FLOPS_PER_FRAME * F
+    achieved = skin_flops / (skin_ms * 1e-3) / 1e12
+    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r1_pmc_summary.json):
+    # FETCH_SIZE 15 084 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 400 KB, at F=300
+    traffic = (15084 * 2 + 30400) * 1024 if (F == 300) else None
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
+                "kernel_ms": skin_ms, "flops_per_launch": skin_flops,
+                # SURVEY 8d asks for the HBM fraction as well: algorithmic bytes of the launch (blend basis once +
+                # vertices + unit boxes written) over its duration against the 8 TB/s spec; small by construction
+                # (the kernel is FP32-bound at ~80 FLOP/B)
+                "algorithmic_bytes": 18688848 + F * (6890 * 12 + 431 * 24),
+                "achieved_hbm_GBps": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 1e9,
+                "achieved_hbm_frac": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 8.0e12,
+                "chamfer_closure_ms": closure_ms, "closure_frame_evals_per_s": F / (closure_ms * 1e-3)}
+    return roofline
+
+
 def packaged_cfg_full():
     from uuo_mocap_amd.config import packaged_config
 
@@ -161,6 +197,13 @@ def main():
     seqs = [make_sequence(tables, seed=(rank * n_seq + i) % 8 if world > 1 else i % 8, num_frames=F,
                           num_markers=10 if limb else M, limb_only=limb) for i in range(n_seq)]
 
+    if args.roofline_only:
+        # no fit: the dominant kernel and the chamfer closure alone on an idle GPU (the command behind
+        # profiles/r1_roofline_kernel_stats.csv, whose k_skin2 average must agree with roofline.kernel_ms)
+        if rank == 0:
+            print(json.dumps({"roofline": measure_roofline(smpl, seqs[-1], dev, F, iters=500)}), flush=True)
+        return
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -191,33 +234,7 @@ def main():
         total_evals = sum(sum(eval_counts(s).values()) for s in all_stats)
         frames = world * args.steps * F
         value = frames / elapsed
-        # ---- roofline of the dominant kernel (k_skin: MFMA blend + skinning), HIP events on the launch stream
-        seq = seqs[-1]
-        markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
-        o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
-        full_cfg = packaged_config("video_mocap")
-        prob = ChamferProblem(smpl, markers, seq.img_smpl.pose_body.to(dev), o_betas, seq.img_smpl.root_orient.to(dev),
-                              full_cfg)
-        x = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas,
-                      seq.img_smpl.pose_body.to(dev))
-        skin_ms = prob.time_closure(x, iters=50, dominant_only=True)
-        closure_ms = prob.time_closure(x, iters=50, dominant_only=False)
-        skin_flops = SKIN_FLOPS_PER_FRAME * F
-        achieved = skin_flops / (skin_ms * 1e-3) / 1e12
-        # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r1_pmc_summary.json):
-        # FETCH_SIZE 15 084 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 400 KB, at F=300
-        traffic = (15084 * 2 + 30400) * 1024 if (F == 300) else None
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                    "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
-                    "kernel_ms": skin_ms, "flops_per_launch": skin_flops,
-                    # SURVEY 8d asks for the HBM fraction as well: algorithmic bytes of the launch (blend basis once +
-                    # vertices + unit boxes written) over its duration against the 8 TB/s spec; small by construction
-                    # (the kernel is FP32-bound at ~80 FLOP/B)
-                    "algorithmic_bytes": 18688848 + F * (6890 * 12 + 431 * 24),
-                    "achieved_hbm_GBps": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 1e9,
-                    "achieved_hbm_frac": (18688848 + F * (6890 * 12 + 431 * 24)) / (skin_ms * 1e-3) / 8.0e12,
-                    "chamfer_closure_ms": closure_ms, "closure_frame_evals_per_s": F / (closure_ms * 1e-3)}
+        roofline = measure_roofline(smpl, seqs[-1], dev, F)
         result = {
             "metric": "mocap frames/sec fitted (300-frame seq, 50 markers)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
