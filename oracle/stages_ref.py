@@ -294,25 +294,56 @@ def remove_approximately_redundant_hierarchies(subtrees, similarity_threshold: f
 
 
 def part_stage_loss(markers_subset, pose_body, betas, o_betas, root_orient, trans, z_angle, vertex_indices,
-                    smpl_inference, config):
-    """closure_fit_subtree (markers_utils.py:454-516) for losses {chamfer, reg_betas}."""
+                    smpl_inference, config, camera=None, foot_contacts=None, markers_subset_mean=None):
+    """closure_fit_subtree (markers_utils.py:454-533): chamfer + reg_betas (the shipped terms) and the optional
+    reproject (:477-514), foot_contact (:520-524), foot_velocity (:526-532), velocity (:534-538), ground (:540-544)
+    terms, added in the reference's order."""
     st = config["stages"]["part"]
-    unsupported = set(st["losses"]) - {"chamfer", "reg_betas"}
+    w = st["losses"]
+    unsupported = set(w) - {"chamfer", "reg_betas", "reproject", "foot_contact", "foot_velocity", "velocity", "ground"}
     if unsupported:
-        raise NotImplementedError("part-stage losses outside the shipped configs: %s" % sorted(unsupported))
+        raise NotImplementedError("part-stage losses the reference does not define: %s" % sorted(unsupported))
     num_frames = pose_body.shape[0]
     z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
     out = _smpl_repeat_betas(smpl_inference, pose_body, betas, z_root, trans)
     verts_sub = out["vertices"][:, vertex_indices]
-    loss = chamfer_distance(markers_subset, verts_sub, single_directional=True)[0] * st["losses"]["chamfer"]
-    if "reg_betas" in st["losses"]:
-        loss = loss + F.mse_loss(betas, o_betas) * st["losses"]["reg_betas"]
+    loss = chamfer_distance(markers_subset, verts_sub, single_directional=True)[0] * w["chamfer"]
+    if "reproject" in w:
+        correction = torch.tensor([[[[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]]])
+        correction = torch.repeat_interleave(correction, repeats=num_frames, dim=0)
+        hmr_cam_trans = torch.repeat_interleave(mocap_to_hmr(camera["cam_trans"]), dim=0, repeats=num_frames)
+        hmr_root_orient = torch.linalg.inv(correction) @ root_orient
+        camera_offset = mocap_to_hmr(trans) - hmr_cam_trans
+        inv_translation = (compute_root_orient_y(z_angle)[:, 0] @ camera_offset[..., None])[..., 0] + hmr_cam_trans
+        joints = _smpl_repeat_betas(smpl_inference, pose_body, betas, hmr_root_orient, inv_translation)["joints"]
+        kp = perspective_projection(joints, hmr_cam_trans,
+                                    torch.repeat_interleave(camera["focal_length"], dim=0, repeats=num_frames),
+                                    camera["camera_center"],
+                                    torch.eye(3).unsqueeze(0).expand(num_frames, -1, -1)).reshape(num_frames, 45, 2) + 0.5
+        loss = loss + torch.mean((kp - camera["joints_2d_gt"]) ** 2 * camera["reproject_mask"][:, None, None]) * w["reproject"]
+    if "reg_betas" in w:
+        loss = loss + F.mse_loss(betas, o_betas) * w["reg_betas"]
+    feet = [10, 11]  # left_foot, right_foot (utils/smpl_utils.py:11-36)
+    if "foot_contact" in w and foot_contacts is not None:
+        h = out["joints"][:, feet, 2]
+        loss = loss + torch.mean(F.mse_loss(h, torch.ones_like(h) * 0.005, reduction="none") * foot_contacts) * w["foot_contact"]
+    if "foot_velocity" in w and foot_contacts is not None:
+        vel = out["joints"][1:, feet, :2] - out["joints"][:-1, feet, :2]
+        speed = torch.norm(vel, dim=-1)
+        loss = loss + torch.mean(F.mse_loss(speed, torch.zeros_like(speed), reduction="none") * w["foot_velocity"] *
+                                 foot_contacts[1:]) * 1.0
+    if "velocity" in w:
+        loss = loss + F.mse_loss(trans[1:] - trans[:-1], markers_subset_mean[1:] - markers_subset_mean[:-1]) * w["velocity"]
+    if "ground" in w:
+        loss = loss + torch.mean(F.relu(-out["vertices"][..., 2])) * w["ground"]
     return loss, out, z_root
 
 
 def find_best_part_fits(markers, pose_body, betas, root_orient, marker_labels, smpl_inference, hierarchy, config,
-                        trace: Optional[dict] = None):
-    """markers/markers_utils.py:274-638, mode "cluster"."""
+                        trace: Optional[dict] = None, joints_2d_gt=None, focal_length=None, reproject_mask=None,
+                        camera_center=None, cam_trans=None, foot_contacts=None, subtree_limit: Optional[int] = None):
+    """markers/markers_utils.py:274-638, mode "cluster".  `subtree_limit` (tests only) stops after that many
+    candidates so a CPU test can pin the first trajectories without paying for all of them."""
     st = config["stages"]["part"]
     if st["mode"] != "cluster":
         raise NotImplementedError("part.mode 'network' needs checkpoints the reference does not ship")
@@ -337,18 +368,23 @@ def find_best_part_fits(markers, pose_body, betas, root_orient, marker_labels, s
     vertex_labels = torch.argmax(weights, dim=-1)
     best = {"distance": np.inf}
     subtree_losses = []
-    for subtree in subtrees:
+    for subtree in subtrees[:subtree_limit]:
         z_angle = torch.zeros((1, 1, 1), device=markers.device).requires_grad_(True)
         trans = torch.median(markers, dim=1)[0].clone().requires_grad_(True)
         betas_s = o_betas.clone().requires_grad_(True)
-        opt = _lbfgs([z_angle, trans, betas_s], st["num_iters"], config, lr=1.0)
+        camera = None
+        if "reproject" in st["losses"]:  # the camera translation joins the parameter list but gets no gradient (:422-424)
+            camera = {"joints_2d_gt": joints_2d_gt, "focal_length": focal_length, "reproject_mask": reproject_mask,
+                      "camera_center": camera_center, "cam_trans": cam_trans[[0]].clone()}
+        opt = _lbfgs([z_angle, trans, betas_s] + ([camera["cam_trans"]] if camera else []), st["num_iters"], config, lr=1.0)
+        extra = dict(camera=camera, foot_contacts=foot_contacts, markers_subset_mean=torch.mean(markers_subset, dim=1))
         vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
         evals = []
 
         def closure():
             opt.zero_grad()
             loss, _, _ = part_stage_loss(markers_subset, pose_body, betas_s, o_betas, root_orient, trans, z_angle,
-                                         vertex_indices, smpl_inference, config)
+                                         vertex_indices, smpl_inference, config, **extra)
             loss.backward()
             evals.append(float(loss))
             return loss
@@ -356,7 +392,7 @@ def find_best_part_fits(markers, pose_body, betas, root_orient, marker_labels, s
         opt.step(closure)
         with torch.no_grad():
             _, out, z_root = part_stage_loss(markers_subset, pose_body, betas_s, o_betas, root_orient, trans,
-                                             z_angle, vertex_indices, smpl_inference, config)
+                                             z_angle, vertex_indices, smpl_inference, config, **extra)
             verts_sub = out["vertices"][:, vertex_indices]
             distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
         subtree_losses.append([subtree, distance])

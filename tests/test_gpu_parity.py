@@ -767,3 +767,70 @@ def test_reprojection_part_stage_in_the_orchestrator(smpl, dev):
     assert len(st) == 2 and all(np.isfinite(h["reproject"]) and np.isfinite(h["chamfer"]) for h in st)
     assert st[0]["input_angle"] == 0.0 and abs(st[1]["input_angle"] - np.pi) < 1e-6
     assert out["trans"].shape == (F, 3) and out["pose_body"].shape == (F, 23, 3, 3)
+    # ... and hands the winning hypothesis' camera to the part stage when its 'reproject' term is on
+    cfg["stages"]["part"]["losses"].update(reproject=1.0, foot_contact=1.0, velocity=1.0)
+    cfg["stages"]["part"]["use_full_skeleton"] = True
+    seq.img_smpl.foot_contacts = torch.ones(F, 2)
+    out2 = multimodal_video_mocap(seq.img_smpl, seq.markers, dev, cfg, offset=0, print_options=[], save_stages=False,
+                                  smpl_inference=smpl)
+    part = last_run_stats()["part"]
+    assert len(part) == 1 and part[0]["driver"] == "torch.optim.LBFGS" and part[0]["n_eval"] >= 2
+    assert all(torch.isfinite(out2[k]).all() for k in ("trans", "pose_body", "root_orient", "betas"))
+    with pytest.raises(ValueError, match="reprojection_part"):
+        cfg["stages"]["reprojection_part"]["num_iters"] = 0
+        multimodal_video_mocap(seq.img_smpl, seq.markers, dev, cfg, offset=0, print_options=[], save_stages=False,
+                               smpl_inference=smpl)
+
+
+@pytest.mark.gpu
+def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
+    """find_best_part_fits with every optional term of the reference's part closure enabled (reproject, foot_contact,
+    foot_velocity, velocity, ground; differentiable HIP operators + torch.optim.LBFGS) against the fixture captured
+    from the reference's own find_best_part_fits fed by its own optim_reprojection camera."""
+    from uuo_mocap_amd.markers_utils import find_best_part_fits
+
+    g = golden("part_stage_losses.npz")
+    cfg = packaged_config("hmr_part")
+    cfg["stages"]["part"]["num_iters"] = int(g["num_iters"])
+    cfg["stages"]["part"]["losses"] = {str(k): float(v) for k, v in zip(g["loss_names"], g["loss_weights"])}
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
+    camera = {k[4:]: t(k).float() for k in ("cam_joints_2d_gt", "cam_focal_length", "cam_reproject_mask", "cam_cam_trans",
+                                            "cam_camera_center")}
+    runs = []
+    real = torch.optim.LBFGS
+
+    class Rec(real):
+        def step(self, closure):
+            losses = []
+            runs.append(losses)
+
+            def wrapped():
+                l = closure()
+                losses.append(float(l.detach()))
+                return l
+            return super().step(wrapped)
+
+    torch.optim.LBFGS = Rec
+    try:
+        out = find_best_part_fits(
+            markers=t("markers").float(), pose_body=t("pose_body").float(), betas=t("o_betas").float(),
+            root_orient=t("o_root_orient").float(), marker_labels=t("seg"), smpl_inference=smpl,
+            hierarchy=smpl.smpl.parents, config=cfg, foot_contacts=t("foot_contacts").float(), **camera)
+    finally:
+        torch.optim.LBFGS = real
+    assert len(runs) == int(g["n_subtrees"])
+    np.testing.assert_allclose([r[0] for r in runs], g["first_losses"], rtol=2e-4)
+    # trajectories: the first evaluations follow the reference's, the converged values agree (the evaluation count of
+    # a solve with relu / norm terms depends on the last bits of the loss, see the oracle test)
+    for k in range(2):
+        ref = g["losses%d" % k]
+        np.testing.assert_allclose(runs[k][:15], ref[:15], rtol=2e-3)
+    np.testing.assert_allclose([r[-1] for r in runs], g["final_losses"], rtol=2e-2)
+    assert np.median(np.abs(np.array([r[-1] for r in runs]) / g["final_losses"] - 1.0)) < 1e-4
+    np.testing.assert_array_equal(out["chain"], g["out_chain"])
+    np.testing.assert_array_equal(out["marker_labels"].cpu().numpy(), g["out_marker_labels"])
+    # converged parameters of the winning candidate (the objective is flat along the limb: cm-level agreement)
+    np.testing.assert_allclose(out["trans"].cpu().numpy(), g["out_trans"], atol=1e-2)
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=2e-2)
+    np.testing.assert_allclose(out["root_orient"].cpu().numpy(), g["out_root_orient"], atol=1e-2)
+    np.testing.assert_allclose(out["marker_weights"].cpu().numpy(), g["out_marker_weights"], rtol=1e-2, equal_nan=True)

@@ -170,3 +170,51 @@ def test_reprojection_stage_matches_reference(oracle_smpl, golden):
         np.testing.assert_allclose(out["trans"].numpy(), g[name + "_trans"], atol=5e-3)
         np.testing.assert_allclose(out["joints_2d"].numpy(), g[name + "_joints_2d"], atol=5e-3)
         assert trace[-1] == pytest.approx(float(ref[-1]), rel=0.05)
+
+
+def _part_losses_case(g):
+    cfg = _cfg("hmr_part", g["num_iters"], 25, 25)
+    cfg["stages"]["part"]["losses"] = {str(k): float(v) for k, v in zip(g["loss_names"], g["loss_weights"])}
+    camera = {k[4:]: _t(g[k]) for k in ("cam_joints_2d_gt", "cam_focal_length", "cam_reproject_mask", "cam_cam_trans",
+                                        "cam_camera_center")}
+    return cfg, camera
+
+
+def test_part_stage_optional_losses_match_reference(golden, oracle_smpl):
+    """Part stage with every optional term of the reference closure enabled (reproject, foot_contact, foot_velocity,
+    velocity, ground): the oracle against the fixture captured from the reference's own find_best_part_fits --
+    first loss of all 26 candidates, first gradient, and the full L-BFGS trajectories of the first two."""
+    g = golden("part_stage_losses.npz")
+    cfg, camera = _part_losses_case(g)
+    markers, pose, o_betas, root = _t(g["markers"]), _t(g["pose_body"]), _t(g["o_betas"]), _t(g["o_root_orient"])
+    seg, fc = _t(g["seg"]), _t(g["foot_contacts"])
+    subtrees = stages_ref.remove_approximately_redundant_hierarchies(
+        stages_ref.get_sub_hierarchies(oracle_smpl.smpl.parents, 3), 0.9)
+    assert len(subtrees) == int(g["n_subtrees"])
+    vlabels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    labels_mode = torch.mode(seg, axis=0)[0]
+    indices = torch.cat([torch.where(labels_mode == j)[0] for j in torch.unique(labels_mode).tolist()], dim=0)
+    sub = markers[:, indices]
+    cam = dict(camera, cam_trans=camera["cam_trans"][[0]].clone())
+    first = []
+    for k, subtree in enumerate(subtrees):
+        vidx = torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+        leaves = [torch.zeros(1, 1, 1, requires_grad=True), torch.median(markers, dim=1)[0].clone().requires_grad_(True),
+                  o_betas.clone().requires_grad_(True)]
+        loss = stages_ref.part_stage_loss(sub, pose, leaves[2], o_betas, root, leaves[1], leaves[0], vidx, oracle_smpl,
+                                          cfg, camera=cam, foot_contacts=fc, markers_subset_mean=sub.mean(1))[0]
+        first.append(float(loss))
+        if k == 0:
+            loss.backward()
+            grad = torch.cat([p.grad.reshape(-1) for p in leaves] + [torch.zeros(3)]).numpy()
+            np.testing.assert_allclose(grad, g["first_grad0"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(first, g["first_losses"], rtol=1e-5)
+    trace = {}
+    stages_ref.find_best_part_fits(markers, pose, o_betas, root, seg, oracle_smpl, oracle_smpl.smpl.parents, cfg,
+                                   trace=trace, foot_contacts=fc, subtree_limit=2, **camera)
+    # the non-smooth terms (relu, norm) make the tail of a trajectory sensitive to the last bits of the loss: pin the
+    # first 25 evaluations and the converged value, not the evaluation count
+    for k in range(2):
+        ref = g["losses%d" % k]
+        np.testing.assert_allclose(trace["evals"][k][:25], ref[:25], rtol=2e-4)
+        np.testing.assert_allclose(trace["evals"][k][-1], ref[-1], rtol=1e-4)

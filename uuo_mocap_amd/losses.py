@@ -33,9 +33,13 @@ class _Knn1(torch.autograd.Function):
         x, y, idx = ctx.saved_tensors
         gidx = idx[..., None].expand(-1, -1, 3)
         g = 2.0 * grad_dist[..., None] * (x - torch.gather(y, 1, gidx))
-        gy = torch.zeros_like(y)
-        gy.scatter_add_(1, gidx, -g)
-        return g, gy
+        # accumulate with index_put_ (sort-based on the GPU, fixed summation order) rather than scatter_add_ (float
+        # atomics): several x points may share a nearest y point, and the solves built on this operator must be
+        # reproducible run to run
+        rows = (torch.arange(y.shape[0], device=y.device)[:, None] * y.shape[1] + idx).reshape(-1)
+        gy = torch.zeros((y.shape[0] * y.shape[1], 3), dtype=y.dtype, device=y.device)
+        gy.index_put_((rows,), -g.reshape(-1, 3), accumulate=True)
+        return g, gy.view_as(y)
 
 
 def knn_points_k1(x: torch.Tensor, y: torch.Tensor):

@@ -117,6 +117,58 @@ def _retained_hierarchies_cached(subtrees, similarity_threshold):
     return tuple(kept)
 
 
+#: part-stage loss terms the device solver fuses (the only ones the shipped configs enable)
+_PART_FUSED_LOSSES = {"chamfer", "reg_betas"}
+#: further terms of the reference closure (markers_utils.py:477-533), evaluated by `part_extra_losses`
+_PART_OPTIONAL_LOSSES = {"reproject", "foot_contact", "foot_velocity", "velocity", "ground"}
+
+
+def part_extra_losses(losses: Dict, smpl_inference, smpl_output: Dict, pose_body, betas, root_orient, trans, z_angle,
+                      markers_subset_mean, camera: Dict, foot_contacts):
+    """The optional terms of the reference's part closure (markers_utils.py:477-544) as differentiable tensor
+    expressions over the HIP operators; returns {name: weighted term} for the caller to add in the reference's order.  `camera` holds the best reprojection hypothesis' joints_2d_gt [F,45,2],
+    focal_length [1,2], reproject_mask [F], camera_center [F,2] and the (fixed) camera translation [1,3]."""
+    from .reprojection import apply_matrix_33_to_vector_3, convert_mocap_pos_to_hmr_pos, perspective_projection
+    from .transforms import compute_root_orient_y
+
+    num_frames = pose_body.shape[0]
+    device = pose_body.device
+    terms = {}
+    if "reproject" in losses:
+        correction = torch.tensor([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]], device=device).expand(num_frames, 1, 3, 3)
+        hmr_cam_trans = torch.repeat_interleave(convert_mocap_pos_to_hmr_pos(camera["cam_trans"]), dim=0,
+                                                repeats=num_frames)                       # [F, 3]
+        hmr_root_orient = torch.linalg.inv(correction) @ root_orient
+        camera_offset = convert_mocap_pos_to_hmr_pos(trans) - hmr_cam_trans
+        # the yaw is applied to the body's offset from the camera, not to the body's orientation (:487-492)
+        inv_translation = apply_matrix_33_to_vector_3(compute_root_orient_y(z_angle)[:, 0], camera_offset) + hmr_cam_trans
+        joints = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas, dim=0, repeats=num_frames),
+                                root_orient=hmr_root_orient, trans=inv_translation)["joints"]
+        kp = perspective_projection(
+            points=joints, translation=hmr_cam_trans,
+            focal_length=torch.repeat_interleave(camera["focal_length"], dim=0, repeats=num_frames),
+            camera_center=camera["camera_center"],
+            rotation=torch.eye(3, device=device).unsqueeze(0).expand(num_frames, -1, -1),
+        ).reshape((num_frames, 45, 2)) + 0.5
+        terms["reproject"] = torch.mean((kp - camera["joints_2d_gt"]) ** 2 * camera["reproject_mask"][:, None, None]) * \
+            losses["reproject"]
+    feet = [get_joint_id("left_foot"), get_joint_id("right_foot")]
+    if "foot_contact" in losses and foot_contacts is not None:
+        feet_height = smpl_output["joints"][:, feet, 2]
+        terms["foot_contact"] = torch.mean((feet_height - 0.005) ** 2 * foot_contacts) * losses["foot_contact"]
+    if "foot_velocity" in losses and foot_contacts is not None:
+        vel_xy = smpl_output["joints"][1:, feet, :2] - smpl_output["joints"][:-1, feet, :2]
+        speed = torch.norm(vel_xy, dim=-1)
+        terms["foot_velocity"] = torch.mean(speed ** 2 * losses["foot_velocity"] * foot_contacts[1:]) * 1.0
+    if "velocity" in losses:
+        terms["velocity"] = torch.nn.functional.mse_loss(
+            trans[1:] - trans[:-1], markers_subset_mean[1:] - markers_subset_mean[:-1]) * losses["velocity"]
+    if "ground" in losses:
+        terms["ground"] = torch.mean(torch.relu(-smpl_output["vertices"][..., 2])) * losses["ground"]
+    return terms
+
+
+
 def find_best_part_fits(
     markers: torch.Tensor,  # [F, M, 3]
     pose_body: torch.Tensor,  # [F, J-1, 3, 3]
@@ -140,8 +192,14 @@ def find_best_part_fits(
     st = config["stages"]["part"]
     if st["mode"] != "cluster":
         raise NotImplementedError("stages.part.mode 'network' needs segmenter checkpoints the reference does not ship")
-    if "reproject" in st["losses"]:
-        raise NotImplementedError("the part-stage reprojection loss is disabled in every shipped config")
+    unknown = set(st["losses"]) - _PART_FUSED_LOSSES - _PART_OPTIONAL_LOSSES
+    if unknown:
+        raise NotImplementedError("part-stage losses the reference does not define: %s" % sorted(unknown))
+    extra = set(st["losses"]) & _PART_OPTIONAL_LOSSES
+    if "reproject" in extra and any(v is None for v in (joints_2d_gt, focal_length, reproject_mask, camera_center,
+                                                        cam_trans)):
+        raise ValueError("the part-stage 'reproject' loss needs the camera of the reprojection_part stage "
+                         "(stages.reprojection_part.num_iters > 0)")
     if iter_fn is not None or visualize_fn is not None:
         raise NotImplementedError("iter_fn / visualize_fn are visualisation hooks, not built")
     device = markers.device
@@ -197,7 +255,74 @@ def find_best_part_fits(
                 stream.synchronize()
         return out
 
+    markers_subset_mean = torch.mean(markers_subset, dim=1)
+    camera = None
+    if "reproject" in extra:
+        camera = {"joints_2d_gt": joints_2d_gt, "focal_length": focal_length, "reproject_mask": reproject_mask,
+                  "camera_center": camera_center, "cam_trans": cam_trans[[0]].clone()}
+
+    def fit_subtree_general(slot: int, subtree, stream):
+        """Same candidate fit with any of the reference's optional loss terms enabled (none is in a shipped config):
+        the closure is composed from the differentiable HIP operators and driven by torch.optim.LBFGS, exactly the
+        reference's construction (:422-434,564)."""
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+            z_angle = torch.zeros((1, 1, 1), device=device).requires_grad_(True)
+            trans = trans0.clone().requires_grad_(True)
+            betas_s = o_betas.clone().requires_grad_(True)
+            # with 'reproject' the camera translation is a (gradient-free, hence fixed) fourth parameter (:422-424)
+            params = [z_angle, trans, betas_s] + ([camera["cam_trans"]] if camera is not None else [])
+            optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"],
+                                          tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                          tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
+                                          line_search_fn="strong_wolfe")
+            n_eval = [0]
+
+            def forward():
+                z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
+                out = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
+                                     root_orient=z_root, trans=trans)
+                return z_root, out
+
+            def closure():
+                optimizer.zero_grad()
+                n_eval[0] += 1
+                _, out = forward()
+                loss = chamfer_distance(markers_subset, out["vertices"][:, vertex_indices].contiguous(),
+                                        single_directional=True)[0] * st["losses"]["chamfer"]
+                terms = part_extra_losses(st["losses"], smpl_inference, out, pose_body, betas_s, root_orient, trans,
+                                          z_angle, markers_subset_mean, camera, foot_contacts)
+                if "reg_betas" in st["losses"]:
+                    terms["reg_betas"] = torch.nn.functional.mse_loss(betas_s, o_betas) * st["losses"]["reg_betas"]
+                for name in ("reproject", "reg_betas", "foot_contact", "foot_velocity", "velocity", "ground"):
+                    if name in terms:  # the reference's order of accumulation (:477-544)
+                        loss = loss + terms[name]
+                loss.backward()
+                return loss
+
+            optimizer.step(closure)
+            with torch.no_grad():
+                z_root, out = forward()
+                verts = out["vertices"]
+                distance = chamfer_distance(markers_subset, verts[:, vertex_indices].contiguous(),
+                                            single_directional=False)[0].item()
+                near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
+                labels = vertex_labels[near].clone()
+            res = {"stats": {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)),
+                             "device_ms": 0.0, "driver": "torch.optim.LBFGS"},
+                   "distance": distance, "betas": betas_s.detach().clone(), "root_orient": z_root.clone(),
+                   "trans": trans.detach().clone(), "labels": labels}
+            if stream is not None:
+                stream.synchronize()
+        return res
+
+    if extra:
+        fit_subtree = fit_subtree_general
+
     n_threads = min(len(subtrees), int(os.environ.get("UUO_SUBTREE_THREADS", "4")))
+    if extra:
+        n_threads = 1  # autograd graphs of concurrent candidates would share the engine's forward scratch
     if n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
         streams = [torch.cuda.Stream(device=device) for _ in range(n_threads)]

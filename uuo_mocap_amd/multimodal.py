@@ -85,6 +85,9 @@ def multimodal_video_mocap(
     o_betas = torch.sum(img_smpl.betas, dim=0, keepdim=True).clone().detach().to(device)
     o_betas = o_betas / torch.sum(img_smpl.img_mask)
     img_mask = img_smpl.img_mask.to(device)
+    o_foot_contacts = getattr(img_smpl, "foot_contacts", None)
+    if o_foot_contacts is not None:
+        o_foot_contacts = o_foot_contacts.clone().detach().to(device)
 
     trans = o_trans.clone().detach().requires_grad_(True)
     root_orient = o_root_orient.clone().detach().requires_grad_(True)
@@ -95,6 +98,8 @@ def multimodal_video_mocap(
     markers = markers[:min_frames]
     o_trans, o_root_orient, o_pose_body = o_trans[:min_frames], o_root_orient[:min_frames], o_pose_body[:min_frames]
     trans, root_orient = trans[:min_frames], root_orient[:min_frames]
+    if o_foot_contacts is not None:
+        o_foot_contacts = o_foot_contacts[:min_frames]
 
     if "progress" in print_options:
         print("Stage: computing temporal alignment...")
@@ -104,6 +109,8 @@ def multimodal_video_mocap(
     o_betas = o_betas.detach()
     o_root_orient = pad(o_root_orient, offset).detach()
     o_trans = pad(o_trans, offset).detach()
+    if o_foot_contacts is not None:
+        o_foot_contacts = pad(o_foot_contacts, offset).detach()
     markers = pad(markers, -offset).detach().contiguous()
     num_frames = trans.shape[0]
 
@@ -122,6 +129,8 @@ def multimodal_video_mocap(
 
     filter_output = None
     smpl_part = None
+    camera = {"joints_2d_gt": None, "focal_length": None, "reproject_mask": None, "cam_trans": None,
+              "camera_center": None}
     if config["find_best_part_fits"]:
         rp = config["stages"]["reprojection_part"]
         if rp["num_iters"] > 0:
@@ -148,11 +157,16 @@ def multimodal_video_mocap(
             o_betas = torch.mean(hyps[best]["betas"][0], dim=0, keepdim=True).clone().detach()
             o_root_orient = hyps[best]["root_orient"][0].clone().detach()
             o_trans = hyps[best]["trans"][0].clone().detach()
+            # camera of the winning hypothesis for the part stage's optional 'reproject' loss (reference :325-335)
+            camera = {"joints_2d_gt": hyps[best]["joints_2d_gt"][0].clone().detach(),
+                      "focal_length": hyps[best]["focal_length"].clone().detach(),
+                      "reproject_mask": hyps[best]["reproject_mask"].clone().detach(),
+                      "cam_trans": hyps[best]["cam_trans"][0].clone().detach(),
+                      "camera_center": hyps[best]["camera_center"].clone().detach()}
         filter_output = find_best_part_fits(
             markers=markers, pose_body=o_pose_body, betas=o_betas, root_orient=o_root_orient,
             marker_labels=segmented_markers, smpl_inference=smpl_inference, hierarchy=smpl_inference.smpl.parents,
-            joints_2d_gt=None, focal_length=None, reproject_mask=None, cam_trans=None, camera_center=None,
-            config=config, foot_contacts=None)
+            config=config, foot_contacts=o_foot_contacts, **camera)
         stats["part"] = list(markers_utils.LAST_STATS.get("part", []))
         segmented_markers = filter_output["marker_labels"].detach().clone()
         root_orient = filter_output["root_orient"].detach().clone()
