@@ -83,6 +83,17 @@ int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d_x, const f
 int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const float* d_verts, const float* d_markers,
                            const uint8_t* d_valid, int32_t* d_idx, void* d_workspace_u64);
 
+/* ---- barycentric marker placement ------------------------------------------------------------------
+ * Replaces igl.signed_distance + trimesh.triangles.points_to_barycentric in compute_nearest_points with
+ * compute_locations.use_barycentric (src/video_mocap/optimization.py:494-500,519-523): for every query
+ * d_points[f,m] the closest point on the triangle mesh (d_verts[f] [V,3], d_faces [NF,3] int32).
+ * Outputs, all [F,M,...]: d_dist (unsigned Euclidean distance), d_face (winning face, lowest index on
+ * exact ties, -1 if no face is usable), d_closest [.,3] and d_bary [.,3] (trimesh "cramer" coordinates of
+ * the closest point with respect to the face's corners in d_faces order).  fp32 throughout. */
+int uuo_mesh_closest_points(void* stream, int F, int M, int V, int NF, const float* d_verts,
+                            const int32_t* d_faces, const float* d_points, float* d_dist, int32_t* d_face,
+                            float* d_closest, float* d_bary);
+
 /* ---- stage problems -------------------------------------------------------------------------------
  * One closure evaluation (forward + backward) of the three L-BFGS stages, on flat parameter vectors
  * packed exactly as the reference hands them to torch.optim.LBFGS:

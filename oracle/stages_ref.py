@@ -203,11 +203,15 @@ def optim_markers(markers, pose_body, o_pose_body, betas, o_betas, root_orient, 
 # ----------------------------------------------------------------------------------------------
 
 def compute_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_inference, img_mask, config,
-                           return_indices: bool = False):
-    """optimization.py:402-642 with compute_locations.use_mean True, granularity "full"."""
+                           return_indices: bool = False, marker_labels=None, granularity: str = "full",
+                           window_size: int = 1, use_velocity: bool = False):
+    """optimization.py:402-642: compute_locations.use_mean (granularity "full") or use_barycentric (any granularity)."""
     cl = config["stages"]["compute_locations"]
-    if cl["use_barycentric"] or not cl["use_mean"]:
-        raise NotImplementedError("only the shipped use_mean placement is restated")
+    if cl["use_barycentric"]:
+        return _barycentric_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_inference, img_mask,
+                                           config, marker_labels, granularity, window_size, use_velocity)
+    if not cl["use_mean"]:
+        raise NotImplementedError("the closest_point mode returns an all-zero matrix in the reference (:549-561)")
     num_frames, num_markers = markers.shape[0], markers.shape[1]
     with torch.no_grad():
         out = smpl_inference(
@@ -236,6 +240,85 @@ def compute_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_i
     if return_indices:
         return one_hot, vidx
     return one_hot
+
+
+def _barycentric_nearest_points(markers, pose_body, betas, root_orient, trans, smpl_inference, img_mask, config,
+                                marker_labels, granularity, window_size, use_velocity):
+    """The use_barycentric branch of compute_nearest_points, loop for loop (optimization.py:444-603), over
+    oracle/mesh_ref.py instead of igl / trimesh."""
+    from . import mesh_ref
+
+    num_frames, num_markers, num_joints = markers.shape[0], markers.shape[1], pose_body.shape[1]
+    with torch.no_grad():
+        out = smpl_inference(
+            poses=normalize_rot(pose_body),
+            betas=torch.repeat_interleave(torch.mean(betas, dim=0, keepdim=True), dim=0, repeats=betas.shape[0]),
+            root_orient=normalize_rot(root_orient), trans=trans)
+    vertices = out["vertices"].detach().cpu().numpy()
+    o_vertices = vertices  # the reference recomputes it from the same inputs (:434-442)
+    faces = np.asarray(smpl_inference.smpl.faces)
+    torch_faces = torch.from_numpy(faces.astype(np.int64))
+    num_windows = int(np.ceil(num_frames / window_size))
+    size = {"part": num_joints, "marker": num_markers, "full": 1}[granularity]
+    min_distance = np.full((num_windows, size), np.inf)
+    final = torch.zeros((num_markers, vertices.shape[1]))
+    stride = window_size
+    n_str = int(np.ceil(num_frames / stride))
+    distance = np.zeros((n_str, num_markers))
+    face_indices = np.zeros((n_str, num_markers), dtype=np.int32)
+    points_3d = np.zeros((n_str, num_markers, 3))
+    valid_frames = torch.where(img_mask == 1)[0].tolist()
+    markers_np = markers.detach().cpu().numpy()
+    window_index = 0
+    for w_start in range(0, num_frames, window_size):
+        for f_index in range(w_start, min(w_start + window_size, num_frames), stride):
+            fs = f_index // stride
+            if fs not in valid_frames:
+                continue
+            distance[fs], face_indices[fs], points_3d[fs] = mesh_ref.signed_distance(
+                markers_np[f_index], vertices[f_index], faces.astype(np.int32))
+            distance[fs] = np.abs(distance[fs])
+            tri = vertices[f_index][faces.astype(np.int64)][face_indices[fs]]
+            bc_np = mesh_ref.points_to_barycentric(tri, points_3d[fs])
+            bc = torch.from_numpy(bc_np).float()
+            i0, i1, i2 = (torch_faces[face_indices[fs]][:, k] for k in range(3))
+            one_hot = torch.zeros((num_markers, vertices.shape[1]))
+            one_hot.scatter_(1, i0.unsqueeze(1), bc[:, [0]])
+            one_hot.scatter_(1, i1.unsqueeze(1), bc[:, [1]])
+            one_hot.scatter_(1, i2.unsqueeze(1), bc[:, [2]])
+            vel_factor = np.ones((num_frames, num_markers))
+            if use_velocity:
+                pts = sum(o_vertices[:, i.numpy()] * np.repeat(np.reshape(bc_np[..., k], (1, -1, 1)), num_frames, axis=0)
+                          for k, i in enumerate((i0, i1, i2)))
+                pv = pts[1:] - pts[:-1]
+                pv = np.concatenate((pv[[0]] * 0, pv), axis=0)
+                mv = markers_np[1:] - markers_np[:-1]
+                mv = np.concatenate((mv[[0]] * 0, mv), axis=0)
+                vel_factor = np.sum(mv * pv, axis=-1)
+            if granularity == "part":
+                for m in range(num_joints):
+                    sel = marker_labels[f_index] == m
+                    part_distance = (sel.astype(np.float32) * distance[fs])[sel]
+                    if part_distance.size > 0 and np.median(part_distance) < min_distance[window_index, m]:
+                        final[sel] = one_hot[sel]
+                        min_distance[window_index, m] = np.median(part_distance)
+            elif granularity == "marker":
+                for m in range(num_markers):
+                    if distance[fs, m] < min_distance[window_index, m]:
+                        final[m] = one_hot[m]
+                        min_distance[window_index, m] = distance[fs, m]
+            else:
+                if np.mean(distance[fs]) * np.mean(vel_factor[fs]) < min_distance[window_index]:
+                    final = one_hot
+                    min_distance[window_index] = np.mean(distance[fs])
+        window_index += 1
+    if cl_use_mean(config):
+        raise NotImplementedError("use_mean together with use_barycentric is not restated")
+    return final
+
+
+def cl_use_mean(config) -> bool:
+    return bool(config["stages"]["compute_locations"]["use_mean"])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -218,3 +218,61 @@ def test_part_stage_optional_losses_match_reference(golden, oracle_smpl):
         ref = g["losses%d" % k]
         np.testing.assert_allclose(trace["evals"][k][:25], ref[:25], rtol=2e-4)
         np.testing.assert_allclose(trace["evals"][k][-1], ref[-1], rtol=1e-4)
+
+
+def _dense(g, tag, M, V=6890):
+    mat = torch.zeros(M, V)
+    nz = torch.from_numpy(g[tag + "_nz"].astype(np.int64))
+    mat[nz[:, 0], nz[:, 1]] = torch.from_numpy(g[tag + "_val"]).float()
+    return mat
+
+
+def test_point_triangle_known_answers():
+    """oracle/mesh_ref.py against hand-computed closest points in all seven regions of a triangle, and the
+    reconstruction property of the barycentric coordinates."""
+    from oracle import mesh_ref
+
+    tri = np.array([[[0.0, 0, 0], [1, 0, 0], [0, 1, 0]]])
+    cases = [((-1, -1, 0.5), (0, 0, 0)), ((2, -0.5, 0), (1, 0, 0)), ((-0.5, 2, 0), (0, 1, 0)),
+             ((0.5, -1, 1), (0.5, 0, 0)), ((-1, 0.5, 1), (0, 0.5, 0)), ((1, 1, 3), (0.5, 0.5, 0)),
+             ((0.25, 0.25, -2), (0.25, 0.25, 0))]
+    for p, q in cases:
+        got, d2 = mesh_ref.closest_on_triangles(np.array(p, float), tri)
+        np.testing.assert_allclose(got[0], q, atol=1e-12)
+        np.testing.assert_allclose(d2[0], np.sum((np.array(p) - np.array(q)) ** 2), atol=1e-12)
+        bc = mesh_ref.points_to_barycentric(tri, got)
+        np.testing.assert_allclose(bc.sum(), 1.0, atol=1e-12)
+        np.testing.assert_allclose((bc[0][:, None] * tri[0]).sum(0), q, atol=1e-12)
+    rng = np.random.default_rng(0)
+    V = rng.normal(size=(40, 3))
+    F = rng.integers(0, 40, size=(60, 3))
+    P = rng.normal(size=(25, 3))
+    S, I, C = mesh_ref.signed_distance(P, V, F)
+    nearest_vertex = np.min(np.linalg.norm(P[:, None] - V[None, np.unique(F)], axis=-1), axis=1)
+    assert np.all(S <= nearest_vertex + 1e-12) and np.all(S >= 0)
+    np.testing.assert_allclose(np.linalg.norm(P - C, axis=-1), S, atol=1e-12)
+
+
+def test_barycentric_placement_matches_reference(golden, oracle_smpl):
+    """compute_nearest_points with use_barycentric: the oracle's restatement of the reference's window / granularity /
+    scatter logic against the fixture captured from the reference's own function (over the same mesh primitives),
+    and the marker stage on the three-corner placement."""
+    g = golden("placement_barycentric.npz")
+    cfg = _cfg("video_mocap", 25, 25, int(g["num_iters"]))
+    cfg["stages"]["compute_locations"].update(use_barycentric=True, use_mean=False)
+    markers, pose, betas = _t(g["markers"]), _t(g["in_pose_body"]), _t(g["in_betas"])
+    root, trans = _t(g["in_root_orient"]), _t(g["in_trans"])
+    M = markers.shape[1]
+    for tag, vel in (("full", True), ("marker", False), ("part", False)):
+        mat = stages_ref.compute_nearest_points(markers, pose, betas, root, trans, oracle_smpl, _t(g[tag + "_mask"]), cfg,
+                                                marker_labels=g["labels"], granularity=tag, use_velocity=vel)
+        np.testing.assert_allclose(mat.numpy(), _dense(g, tag, M).numpy(), atol=1e-6)
+    o_pose, o_betas = _t(g["o_pose_body"]), _t(g["o_betas"])
+    leaves = [x.clone().requires_grad_(True) for x in (pose, betas, root, trans)]
+    trace = []
+    stages_ref.optim_markers(markers, leaves[0], o_pose, leaves[1], o_betas, leaves[2], leaves[3], _dense(g, "full", M),
+                             oracle_smpl, cfg, trace=trace)
+    assert len(trace) == len(g["losses"])
+    np.testing.assert_allclose(trace, g["losses"], rtol=1e-4)
+    np.testing.assert_allclose(leaves[0].detach().numpy(), g["out_pose_body"], atol=1e-4)
+    np.testing.assert_allclose(leaves[3].detach().numpy(), g["out_trans"], atol=1e-4)

@@ -53,6 +53,8 @@ _SIGNATURES = {
                               c_void_p, c_void_p]),
     "uuo_assign_mean_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "uuo_mesh_closest_points": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "uuo_fit_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "uuo_fit_destroy": (c_int, [c_void_p]),
     "uuo_problem_num_params": (c_int, [POINTER(UuoProblem)]),

@@ -393,6 +393,150 @@ extern "C" int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const f
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Closest point on the body surface (the reference's barycentric placement: igl.signed_distance followed by
+// trimesh.triangles.points_to_barycentric, optimization.py:494-500,519-523).  Brute force over the faces with the
+// closest-point-on-triangle region test of Ericson, Real-Time Collision Detection 5.1.5 (what libigl's
+// point_simplex_squared_distance implements).  Thread = face (its three corners stay in registers), the block's
+// markers are broadcast from LDS; faces are merged with a 64-bit min on (d^2 bits << 32 | face), so ties go to the
+// lowest face index independent of the schedule.
+// ----------------------------------------------------------------------------------------------------
+struct TriHit {
+  float cx, cy, cz, d2;
+};
+__device__ __forceinline__ TriHit closest_on_triangle(float px, float py, float pz, float ax, float ay, float az,
+                                                      float bx, float by, float bz, float cx, float cy, float cz) {
+  const float abx = bx - ax, aby = by - ay, abz = bz - az;
+  const float acx = cx - ax, acy = cy - ay, acz = cz - az;
+  const float apx = px - ax, apy = py - ay, apz = pz - az;
+  const float d1 = abx * apx + aby * apy + abz * apz, d2 = acx * apx + acy * apy + acz * apz;
+  const float bpx = px - bx, bpy = py - by, bpz = pz - bz;
+  const float d3 = abx * bpx + aby * bpy + abz * bpz, d4 = acx * bpx + acy * bpy + acz * bpz;
+  const float cpx = px - cx, cpy = py - cy, cpz = pz - cz;
+  const float d5 = abx * cpx + aby * cpy + abz * cpz, d6 = acx * cpx + acy * cpy + acz * cpz;
+  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  float v, w;  // closest point = a + v*ab + w*ac
+  if (d1 <= 0.f && d2 <= 0.f) {  // vertex region a
+    v = 0.f; w = 0.f;
+  } else if (d3 >= 0.f && d4 <= d3) {  // vertex region b
+    v = 1.f; w = 0.f;
+  } else if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {  // edge ab
+    v = d1 / (d1 - d3); w = 0.f;
+  } else if (d6 >= 0.f && d5 <= d6) {  // vertex region c
+    v = 0.f; w = 1.f;
+  } else if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {  // edge ac
+    v = 0.f; w = d2 / (d2 - d6);
+  } else if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {  // edge bc
+    w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1.f - w;
+  } else {  // interior
+    const float denom = 1.f / (va + vb + vc);
+    v = vb * denom; w = vc * denom;
+  }
+  TriHit h;
+  h.cx = ax + abx * v + acx * w;
+  h.cy = ay + aby * v + acy * w;
+  h.cz = az + abz * v + acz * w;
+  const float ex = px - h.cx, ey = py - h.cy, ez = pz - h.cz;
+  h.d2 = ex * ex + ey * ey + ez * ez;
+  if (!(h.d2 == h.d2)) h.d2 = UUO_INF;  // degenerate triangle (0/0): never the winner
+  return h;
+}
+
+#define MESH_MB 16  // query points per block
+__global__ __launch_bounds__(256) void k_mesh_closest(int M, int V, int NF, const float* __restrict__ verts,
+                                                       const int32_t* __restrict__ faces,
+                                                       const float* __restrict__ points, float* __restrict__ dist,
+                                                       int32_t* __restrict__ face_out, float* __restrict__ closest,
+                                                       float* __restrict__ bary) {
+  __shared__ float sp[MESH_MB * 3];
+  __shared__ unsigned long long skey[MESH_MB];
+  const int f = blockIdx.x, m0 = blockIdx.y * MESH_MB, tid = threadIdx.x;
+  const int mg = min(MESH_MB, M - m0);
+  const float* vf = verts + (size_t)f * V * 3;
+  if (tid < MESH_MB * 3) sp[tid] = (tid < mg * 3) ? points[((size_t)f * M + m0) * 3 + tid] : 0.f;
+  if (tid < MESH_MB) skey[tid] = ~0ull;
+  __syncthreads();
+  float best[MESH_MB];
+  int bestf[MESH_MB];
+#pragma unroll
+  for (int q = 0; q < MESH_MB; ++q) {
+    best[q] = UUO_INF;
+    bestf[q] = -1;
+  }
+  for (int t = tid; t < NF; t += 256) {
+    const int i0 = faces[(size_t)t * 3], i1 = faces[(size_t)t * 3 + 1], i2 = faces[(size_t)t * 3 + 2];
+    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) continue;
+    const float ax = vf[i0 * 3], ay = vf[i0 * 3 + 1], az = vf[i0 * 3 + 2];
+    const float bx = vf[i1 * 3], by = vf[i1 * 3 + 1], bz = vf[i1 * 3 + 2];
+    const float cx = vf[i2 * 3], cy = vf[i2 * 3 + 1], cz = vf[i2 * 3 + 2];
+#pragma unroll
+    for (int q = 0; q < MESH_MB; ++q) {
+      const TriHit h = closest_on_triangle(sp[q * 3], sp[q * 3 + 1], sp[q * 3 + 2], ax, ay, az, bx, by, bz, cx, cy, cz);
+      if (h.d2 < best[q]) {  // ascending faces per thread + strict '<': the thread's first minimum
+        best[q] = h.d2;
+        bestf[q] = t;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MESH_MB; ++q) {
+    unsigned long long key = (bestf[q] >= 0) ? pack_key(best[q], (unsigned)bestf[q]) : ~0ull;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(key, off, 64);
+      key = o < key ? o : key;
+    }
+    if ((tid & 63) == 0 && key != ~0ull) atomicMin(&skey[q], key);
+  }
+  __syncthreads();
+  if (tid < mg) {
+    const unsigned long long key = skey[tid];
+    const size_t o = (size_t)f * M + m0 + tid;
+    if (key == ~0ull) {  // no usable face
+      dist[o] = UUO_INF;
+      face_out[o] = -1;
+      for (int c = 0; c < 3; ++c) closest[o * 3 + c] = bary[o * 3 + c] = 0.f;
+      return;
+    }
+    const int t = (int)(unsigned)(key & 0xFFFFFFFFull);
+    const int i0 = faces[(size_t)t * 3], i1 = faces[(size_t)t * 3 + 1], i2 = faces[(size_t)t * 3 + 2];
+    const float ax = vf[i0 * 3], ay = vf[i0 * 3 + 1], az = vf[i0 * 3 + 2];
+    const float bx = vf[i1 * 3], by = vf[i1 * 3 + 1], bz = vf[i1 * 3 + 2];
+    const float cx = vf[i2 * 3], cy = vf[i2 * 3 + 1], cz = vf[i2 * 3 + 2];
+    const TriHit h = closest_on_triangle(sp[tid * 3], sp[tid * 3 + 1], sp[tid * 3 + 2], ax, ay, az, bx, by, bz, cx, cy, cz);
+    dist[o] = sqrtf(h.d2);
+    face_out[o] = t;
+    closest[o * 3] = h.cx;
+    closest[o * 3 + 1] = h.cy;
+    closest[o * 3 + 2] = h.cz;
+    // trimesh.triangles.points_to_barycentric(method="cramer") of the closest point
+    const float e0x = bx - ax, e0y = by - ay, e0z = bz - az, e1x = cx - ax, e1y = cy - ay, e1z = cz - az;
+    const float wx = h.cx - ax, wy = h.cy - ay, wz = h.cz - az;
+    const float dot00 = e0x * e0x + e0y * e0y + e0z * e0z, dot01 = e0x * e1x + e0y * e1y + e0z * e1z;
+    const float dot02 = e0x * wx + e0y * wy + e0z * wz, dot11 = e1x * e1x + e1y * e1y + e1z * e1z;
+    const float dot12 = e1x * wx + e1y * wy + e1z * wz;
+    const float inv = 1.f / (dot00 * dot11 - dot01 * dot01);
+    const float b2 = (dot00 * dot12 - dot01 * dot02) * inv, b1 = (dot11 * dot02 - dot01 * dot12) * inv;
+    bary[o * 3] = 1.f - b1 - b2;
+    bary[o * 3 + 1] = b1;
+    bary[o * 3 + 2] = b2;
+  }
+}
+
+extern "C" int uuo_mesh_closest_points(void* stream, int F, int M, int V, int NF, const float* d_verts,
+                                       const int32_t* d_faces, const float* d_points, float* d_dist,
+                                       int32_t* d_face, float* d_closest, float* d_bary) {
+  UUO_REQUIRE(d_verts && d_faces && d_points && d_dist && d_face && d_closest && d_bary,
+              "uuo_mesh_closest_points: null argument");
+  UUO_REQUIRE(F >= 0 && M >= 0 && V > 0 && NF > 0, "uuo_mesh_closest_points: sizes must be positive");
+  if (F == 0 || M == 0) return 0;
+  UUO_REQUIRE((long)F <= 2147483647L && (M + MESH_MB - 1) / MESH_MB <= 65535, "uuo_mesh_closest_points: grid too large");
+  hipLaunchKernelGGL(k_mesh_closest, dim3(F, (M + MESH_MB - 1) / MESH_MB), dim3(256), 0, (hipStream_t)stream, M, V, NF,
+                     d_verts, d_faces, d_points, d_dist, d_face, d_closest, d_bary);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
 // get_marker_mask (reference optimization.py:703-715): sum(|xyz|) != 0, plus the count of set entries
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mask(int count, const float* __restrict__ markers, float* __restrict__ mask,

@@ -107,8 +107,11 @@ def optim_markers(
     one_hot = barycentric_coords_one_hot
     if one_hot.dim() != 2 or one_hot.shape[1] != smpl_inference.device_model.V:
         raise ValueError("barycentric_coords_one_hot must be [M, %d]" % smpl_inference.device_model.V)
-    if not bool(((one_hot != 0).sum(dim=1) == 1).all()):
-        raise NotImplementedError("only one-hot vertex placements (compute_locations.use_mean) are supported")
+    rows_nz = (one_hot != 0).sum(dim=1)
+    if not bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all()):
+        # barycentric placement (compute_locations.use_barycentric): up to three weighted vertices per marker
+        return _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
+                                      smpl_inference, config, verbose)
     assign = torch.argmax(one_hot, dim=-1)
     prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config)
     x = prob.pack(pose_body, betas, root_orient, trans)
@@ -122,6 +125,61 @@ def optim_markers(
         betas.copy_(new_betas)
         root_orient.copy_(new_root)
         trans.copy_(new_trans)
+    LAST_STATS["marker"] = stats
+    _tls_stats.marker = stats
+    return None
+
+
+def _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, coords, smpl_inference,
+                           config, verbose):
+    """Marker stage for a general placement matrix [M, V] (reference optimization.py:288-399 as written: virtual
+    markers = coords @ vertices).  The fused device solver covers the one-hot placements of the shipped configs; this
+    path composes the same closure from the differentiable HIP operators (SmplInference forward / uuo_smpl_backward)
+    and drives it with torch.optim.LBFGS like the reference.  Mutates the four leaves in place."""
+    st = config["stages"]["marker"]
+    unsupported = set(st["losses"]) - {"marker", "reg_pose_body", "reg_betas"}
+    if unsupported:
+        raise NotImplementedError("marker-stage losses outside the shipped configs: %s" % sorted(unsupported))
+    if st.get("use_sdf"):
+        raise NotImplementedError("stages.marker.use_sdf is off in every shipped config")
+    num_frames = pose_body.shape[0]
+    leaves = [pose_body, betas, root_orient, trans]
+    params = [p.detach().clone().requires_grad_(True) for p in leaves]
+    p_pose, p_betas, p_root, p_trans = params
+    optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                  tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
+                                  line_search_fn="strong_wolfe")
+    weights = get_marker_mask(markers)
+    coords = coords.to(torch.float32)
+    n_eval = [0]
+    trace = []
+
+    def closure():
+        optimizer.zero_grad()
+        out = smpl_inference(poses=normalize_rot(p_pose), betas=torch.repeat_interleave(p_betas, dim=0, repeats=num_frames),
+                             root_orient=normalize_rot(p_root), trans=p_trans)
+        virtual = torch.einsum("mv,fvc->fmc", coords, out["vertices"])
+        loss = 0
+        if "marker" in st["losses"]:
+            loss = loss + torch.mean(MarkerLoss(markers=markers, virtual_markers=virtual, marker_weights=weights,
+                                                marker_distance=MARKER_DISTANCE)) * st["losses"]["marker"]
+        if "reg_pose_body" in st["losses"]:
+            loss = loss + F.mse_loss(p_pose, o_pose_body) * st["losses"]["reg_pose_body"]
+        if "reg_betas" in st["losses"]:
+            loss = loss + F.mse_loss(p_betas, o_betas) * st["losses"]["reg_betas"]
+        loss.backward()
+        if verbose:
+            print("Marker", n_eval[0], float(loss))
+        n_eval[0] += 1
+        trace.append(loss.detach())
+        return loss
+
+    optimizer.step(closure)
+    with torch.no_grad():
+        for leaf, p in zip(leaves, params):
+            leaf.copy_(p)
+    stats = {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)), "device_ms": 0.0,
+             "driver": "torch.optim.LBFGS", "loss_first": float(trace[0]), "loss_final": float(min(trace))}
     LAST_STATS["marker"] = stats
     _tls_stats.marker = stats
     return None
@@ -143,10 +201,23 @@ def compute_nearest_points(
     window_size: int = 1,
     use_velocity: bool = True,
 ):
-    """Marker placement: one-hot [M, 6890] of argmin_v mean_f |v_fv - x_fm| over the frames with img_mask == 1."""
+    """Marker placement [M, 6890] (reference optimization.py:402-642).
+
+    `compute_locations.use_mean` (every shipped config): one-hot of argmin_v mean_f |v_fv - x_fm| over the frames with
+    img_mask == 1 (one fused kernel).  `use_barycentric`: the closest point on the body surface (HIP brute force over
+    the 13 776 faces) expressed in the winning face's three corners, chosen per `granularity` ("full" | "marker" |
+    "part") exactly as the reference's window loop chooses it.  The third mode (neither flag) is not runnable in the
+    reference: its three scatter_ calls write (1, 0, 0) to the SAME entry, so it returns an all-zero matrix
+    (:549-561)."""
     cl = config["stages"]["compute_locations"]
-    if cl["use_barycentric"] or not cl["use_mean"] or granularity != "full" or window_size != 1:
-        raise NotImplementedError("only the shipped placement (use_mean, granularity 'full', window 1) is built")
+    if not cl["use_barycentric"] and not cl["use_mean"]:
+        raise NotImplementedError("compute_locations without use_mean / use_barycentric returns an all-zero placement "
+                                  "in the reference (scatter_ overwrite, optimization.py:549-561): not reproduced")
+    if granularity not in ("full", "marker", "part"):
+        raise ValueError("granularity must be 'full', 'marker' or 'part'")
+    if cl["use_mean"] and window_size != 1:
+        raise NotImplementedError("use_mean with window_size != 1 (the reference's only callers pass 1; its distance "
+                                  "table is then indexed inconsistently, optimization.py:457-484,597)")
     with torch.no_grad():
         verts = smpl_inference(
             poses=normalize_rot(pose_body.detach()),
@@ -155,11 +226,92 @@ def compute_nearest_points(
             root_orient=normalize_rot(root_orient.detach()),
             trans=trans.detach(),
         )["vertices"]
-        valid = (img_mask == 1)
-        idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, valid)
-        one_hot = torch.zeros((markers.shape[1], verts.shape[1]), dtype=torch.float32, device=verts.device)
-        one_hot.scatter_(1, idx.long()[:, None], 1.0)
-    return one_hot.to(device)
+        if cl["use_mean"] and not cl["use_barycentric"]:
+            # the window loop only fills the distance matrix in this mode; the result is the argmin below (:595-603)
+            valid = (img_mask == 1)
+            idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, valid)
+            one_hot = torch.zeros((markers.shape[1], verts.shape[1]), dtype=torch.float32, device=verts.device)
+            one_hot.scatter_(1, idx.long()[:, None], 1.0)
+            return one_hot.to(device)
+        coords = _barycentric_placement(markers, verts, smpl_inference, marker_labels, granularity, img_mask,
+                                        pose_body.shape[1], window_size, use_velocity and o_pose_body is not None)
+        if cl["use_mean"]:
+            # both flags: the mean-distance argmin overwrites the window loop's result (:595-603)
+            idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, img_mask == 1)
+            coords = torch.zeros_like(coords)
+            coords.scatter_(1, idx.long()[:, None], 1.0)
+    return coords.to(device)
+
+
+#: diagnostics of the last barycentric placement (selected frame per marker, distances, velocity factors)
+LAST_PLACEMENT: Dict = {}
+
+
+def _barycentric_placement(markers, verts, smpl_inference, marker_labels, granularity, img_mask, num_joints,
+                           window_size, use_velocity):
+    """The reference's window loop (optimization.py:464-591) for `use_barycentric`.  One frame per window is examined
+    (the loop's stride equals the window size, :455,468), each window owns its running minimum (:449), so every
+    examined frame passes the `< min_distance[window]` test against +inf and the rows it selects overwrite the
+    previous ones: the result is a per-marker "last examined frame that selects the marker" rule.  The closest points
+    of ALL examined frames are computed in one launch; the selection itself is O(F M) host logic."""
+    F, M = markers.shape[0], markers.shape[1]
+    V = verts.shape[1]
+    dm = smpl_inference.device_model
+    faces = torch.from_numpy(np.asarray(smpl_inference.smpl.faces).astype(np.int64)).to(verts.device)
+    valid_frames = set(torch.where(img_mask == 1)[0].tolist())
+    # window w examines frame w * window_size and files it under index w; the validity test is on the window index
+    # (:472-474), as in the reference
+    frames = [(w, f) for w, f in enumerate(range(0, F, window_size)) if w in valid_frames]
+    final_vid = torch.zeros((M, 3), dtype=torch.long, device=verts.device)
+    final_w = torch.zeros((M, 3), dtype=torch.float32, device=verts.device)
+    chosen = np.full((M,), -1, dtype=np.int64)
+    info = {"frames": [f for _, f in frames], "chosen_frame": chosen}
+    if frames:
+        fsel = torch.tensor([f for _, f in frames], device=verts.device)
+        dist, face, closest, bary = dm.mesh_closest_points(verts[fsel], faces, markers[fsel])
+        dist_np = dist.double().cpu().numpy()              # [K, M]
+        vids = faces[face.long()]                          # [K, M, 3]
+        vel = np.ones((len(frames), M))
+        if use_velocity:
+            # vel_factor[w, m] of the placement found in examined frame k (:563-580): velocity of the placed point
+            # (between trajectory frames w-1 and w) dotted with the marker's velocity; row w of the [F, M] table
+            widx = torch.tensor([w for w, _ in frames], device=verts.device)
+            prev = torch.clamp(widx - 1, min=0)
+            gi = vids.reshape(len(frames), -1)                                             # [K, 3M]
+            p_now = torch.gather(verts[widx].double(), 1, gi[..., None].expand(-1, -1, 3)).view(len(frames), M, 3, 3)
+            p_prev = torch.gather(verts[prev].double(), 1, gi[..., None].expand(-1, -1, 3)).view(len(frames), M, 3, 3)
+            wts = bary.double()[..., None]
+            pv = ((p_now * wts).sum(2) - (p_prev * wts).sum(2)) * (widx > 0).double()[:, None, None]
+            mv = (markers[widx].double() - markers[prev].double()) * (widx > 0).double()[:, None, None]
+            vel = (pv * mv).sum(-1).cpu().numpy()
+        info.update(distance=dist_np, vel_factor=vel)
+        labels = np.asarray(marker_labels)
+        for k, (w, f) in enumerate(frames):  # ascending, so later frames overwrite earlier ones
+            if granularity == "full":
+                if np.mean(dist_np[k]) * np.mean(vel[k]) < np.inf:
+                    chosen[:] = k
+            elif granularity == "marker":
+                chosen[dist_np[k] < np.inf] = k
+            else:  # "part": markers whose label this frame is one of the first `num_joints` joints (:583-589)
+                lab = labels[f]
+                for j in range(num_joints):
+                    sel = lab == j
+                    if sel.any() and np.median(dist_np[k][sel]) < np.inf:
+                        if j >= M:  # the reference files the part's point under column j of an [windows, M] table (:578)
+                            raise IndexError("granularity 'part': populated joint id %d >= number of markers %d" % (j, M))
+                        chosen[sel] = k
+        has = torch.from_numpy(chosen >= 0).to(verts.device)
+        kk = torch.from_numpy(np.maximum(chosen, 0)).to(verts.device)
+        ar = torch.arange(M, device=verts.device)
+        final_vid = vids[kk, ar]
+        final_w = bary[kk, ar] * has[:, None].float()
+    coords = torch.zeros((M, V), dtype=torch.float32, device=verts.device)
+    # three scatter_ calls in corner order (:533-535): assignment, so a repeated corner keeps the last weight
+    for c in range(3):
+        coords.scatter_(1, final_vid[:, [c]], final_w[:, [c]])
+    LAST_PLACEMENT.clear()
+    LAST_PLACEMENT.update(info)
+    return coords
 
 
 def compute_marker_labels_from_coords(smpl_inference: SmplInference, barycentric_coords_one_hot: torch.Tensor,
