@@ -511,14 +511,62 @@ def find_best_part_fits(markers, pose_body, betas, root_orient, marker_labels, s
 
 
 # ----------------------------------------------------------------------------------------------
+# frame-rate resampling (multimodal.py:145-182)
+# ----------------------------------------------------------------------------------------------
+
+def unitquat_slerp(q0: torch.Tensor, q1: torch.Tensor, steps: torch.Tensor, shortest_arc: bool = True) -> torch.Tensor:
+    """roma.utils.unitquat_slerp (roma is not installed here: restated from the package's published source; the
+    result is also checked against scipy's Slerp in tests/test_oracle_stages.py).  q0, q1 [..., 4], steps [S] ->
+    [S, ..., 4].  sin((1-t)w) q0 + sin(t w) q1, linear weights where cos w > 1 - 1e-3, normalised."""
+    batch = q0.shape[:-1]
+    q0, q1 = q0.reshape(-1, 4), q1.reshape(-1, 4)
+    cos_omega = torch.sum(q0 * q1, dim=-1)
+    if shortest_arc:
+        q1 = q1.clone()
+        q1[cos_omega < 0, :] *= -1
+        cos_omega = torch.abs(cos_omega)
+    nearby = cos_omega > (1.0 - 1e-3)
+    omega = torch.acos(cos_omega)
+    alpha = torch.sin((1 - steps.unsqueeze(-1)) * omega)
+    beta = torch.sin(steps.unsqueeze(-1) * omega)
+    alpha[..., nearby] = (1 - steps.unsqueeze(-1)).expand_as(alpha)[..., nearby]
+    beta[..., nearby] = steps.unsqueeze(-1).expand_as(beta)[..., nearby]
+    q = alpha.unsqueeze(-1) * q0 + beta.unsqueeze(-1) * q1
+    q = q / torch.norm(q, dim=-1, keepdim=True)
+    return q.reshape(steps.shape + batch + (4,))
+
+
+def resample_hmr(o_trans, o_root_orient, o_pose_body, img_freq, mocap_freq):
+    """The resampling loop of multimodal.py:145-182, frame by frame (foot contacts are carried by the product only)."""
+    from .p3d_ref import matrix_to_quaternion, quaternion_to_matrix
+
+    tl, rl, pl = [], [], []
+    new_num_frames = round(o_trans.shape[0] * (mocap_freq / img_freq))
+    for i in range(new_num_frames):
+        frame = int(i * (img_freq / mocap_freq))
+        alpha = i * (img_freq / mocap_freq) - frame
+        inv_alpha = 1.0 - alpha
+        if frame + 1 < o_trans.shape[0]:
+            tl.append((o_trans[frame + 1] * alpha) + (o_trans[frame] * inv_alpha))
+            steps = torch.tensor([alpha]).to(o_trans.device)
+            rl.append(quaternion_to_matrix(unitquat_slerp(matrix_to_quaternion(o_root_orient[frame]),
+                                                          matrix_to_quaternion(o_root_orient[frame + 1]), steps))[0])
+            pl.append(quaternion_to_matrix(unitquat_slerp(matrix_to_quaternion(o_pose_body[frame]),
+                                                          matrix_to_quaternion(o_pose_body[frame + 1]), steps))[0])
+        else:
+            tl.append(o_trans[frame])
+            rl.append(o_root_orient[frame])
+            pl.append(o_pose_body[frame])
+    return torch.stack(tl, dim=0), torch.stack(rl, dim=0), torch.stack(pl, dim=0)
+
+
+# ----------------------------------------------------------------------------------------------
 # orchestrator
 # ----------------------------------------------------------------------------------------------
 
 def multimodal_video_mocap(img_smpl, mocap_markers, smpl_inference, config, device=torch.device("cpu"),
                            stats: Optional[dict] = None) -> Dict:
-    """multimodal.py:38-710 for equal mocap/video frame rates, offset 0, reprojection and root stages off."""
-    if mocap_markers.get_frequency() != img_smpl.freq:
-        raise NotImplementedError("frame-rate resampling (multimodal.py:145-182) is outside the restated path")
+    """multimodal.py:38-710 for offset 0, reprojection and root stages off."""
     for key in ("reprojection_part", "reprojection_full", "root"):
         if config["stages"][key]["num_iters"] > 0:
             raise NotImplementedError("stage %s is disabled in every shipped config" % key)
@@ -529,6 +577,9 @@ def multimodal_video_mocap(img_smpl, mocap_markers, smpl_inference, config, devi
     o_betas = torch.sum(img_smpl.betas, dim=0, keepdim=True).clone().detach().to(device)
     o_betas = o_betas / torch.sum(img_smpl.img_mask)
     img_mask = img_smpl.img_mask.to(device)
+    if mocap_markers.get_frequency() != img_smpl.freq:
+        o_trans, o_root_orient, o_pose_body = resample_hmr(o_trans, o_root_orient, o_pose_body, img_smpl.freq,
+                                                           mocap_markers.get_frequency())
 
     trans = o_trans.clone().detach().requires_grad_(True)
     root_orient = o_root_orient.clone().detach().requires_grad_(True)

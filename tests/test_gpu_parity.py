@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import p3d_ref, stages_ref  # noqa: E402
 from uuo_mocap_amd.config import packaged_config  # noqa: E402
-from uuo_mocap_amd.synthetic import make_sequence  # noqa: E402
+from uuo_mocap_amd.synthetic import SyntheticImgSmpl, SyntheticMarkers, make_sequence  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -975,3 +975,37 @@ def test_orchestrator_with_barycentric_placement(smpl, dev):
     # span the body, and a surface point placed on one of them on the last frame does not track the marker on the
     # others -- a property of the stand-in mesh, see scratch notes in DESIGN.md; the stage itself must make progress)
     assert all(s["loss_final"] < s["loss_first"] for s in last_run_stats()["marker"])
+
+
+@pytest.mark.gpu
+def test_frame_rate_resampling_matches_reference(smpl, golden, dev):
+    """multimodal_video_mocap with a 15 Hz HMR track under 30 Hz markers against the fixture captured from the
+    reference's own orchestrator: the output pose is the normalised resampled HMR pose (pins the resampling to fp32
+    rounding), translation / orientation / shape come from the part stage on the resampled track."""
+    from uuo_mocap_amd.multimodal import multimodal_video_mocap
+    from uuo_mocap_amd.resample import resample_hmr
+
+    g = golden("e2e_resample.npz")
+    cfg = packaged_config("hmr_full")
+    cfg["stages"]["part"]["num_iters"] = int(g["part_iters"])
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).float()
+    F_img = g["hmr_trans"].shape[0]
+    img = SyntheticImgSmpl(
+        trans=t("hmr_trans"), root_orient=t("hmr_root_orient"), hmr_root_orient=t("hmr_root_orient"),
+        pose_body=t("hmr_pose_body"), betas=t("hmr_betas"), foot_contacts=torch.zeros(F_img, 2),
+        camera_bbox=torch.zeros(F_img, 3), center=torch.zeros(F_img, 2), scale=torch.zeros(F_img, 1),
+        size=torch.zeros(F_img, 2), img_mask=t("img_mask"), freq=float(g["video_freq"]))
+    out = multimodal_video_mocap(img, SyntheticMarkers(g["markers"].copy(), float(g["mocap_freq"])), dev, cfg, offset=0,
+                                 print_options=[], save_stages=False, smpl_inference=smpl)
+    assert out["trans"].shape[0] == 9
+    np.testing.assert_allclose(out["pose_body"].cpu().numpy(), g["out_pose_body"], atol=2e-6)
+    np.testing.assert_allclose(out["trans"].cpu().numpy(), g["out_trans"], atol=2e-3)
+    np.testing.assert_allclose(out["root_orient"].cpu().numpy(), g["out_root_orient"], atol=2e-3)
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=5e-3)
+    # up-sampling by a non-integer ratio and the tail rule (frames past the last video frame repeat it)
+    tr, ro, po, fc = resample_hmr(t("hmr_trans").to(dev), t("hmr_root_orient").to(dev), t("hmr_pose_body").to(dev),
+                                  torch.rand(F_img, 2, device=dev), 25.0, 60.0)
+    assert tr.shape[0] == round(F_img * 60.0 / 25.0) and fc.shape == (tr.shape[0], 2)
+    np.testing.assert_array_equal(tr[-1].cpu().numpy(), g["hmr_trans"][-1])
+    det = torch.linalg.det(po)
+    assert float((det - 1).abs().max()) < 1e-5

@@ -276,3 +276,38 @@ def test_barycentric_placement_matches_reference(golden, oracle_smpl):
     np.testing.assert_allclose(trace, g["losses"], rtol=1e-4)
     np.testing.assert_allclose(leaves[0].detach().numpy(), g["out_pose_body"], atol=1e-4)
     np.testing.assert_allclose(leaves[3].detach().numpy(), g["out_trans"], atol=1e-4)
+
+
+def _resample_case(g):
+    F_img = g["hmr_trans"].shape[0]
+    img = SyntheticImgSmpl(
+        trans=_t(g["hmr_trans"]), root_orient=_t(g["hmr_root_orient"]), hmr_root_orient=_t(g["hmr_root_orient"]),
+        pose_body=_t(g["hmr_pose_body"]), betas=_t(g["hmr_betas"]), foot_contacts=torch.zeros(F_img, 2),
+        camera_bbox=torch.zeros(F_img, 3), center=torch.zeros(F_img, 2), scale=torch.zeros(F_img, 1),
+        size=torch.zeros(F_img, 2), img_mask=_t(g["img_mask"]), freq=float(g["video_freq"]))
+    return img, SyntheticMarkers(g["markers"].copy(), float(g["mocap_freq"]))
+
+
+def test_frame_rate_resampling_matches_reference(golden, oracle_smpl):
+    """Video (15 Hz) -> mocap (30 Hz) resampling of the HMR track: the oracle's slerp against scipy's, and the
+    oracle's orchestrator against the fixture captured from the reference's own multimodal_video_mocap."""
+    from scipy.spatial.transform import Rotation, Slerp
+
+    rot = Rotation.random(6, random_state=2)
+    q = torch.from_numpy(rot.as_quat()).float()  # component order is irrelevant to slerp
+    for t in (0.0, 0.25, 0.5, 0.9):
+        got = stages_ref.unitquat_slerp(q[:-1], q[1:], torch.tensor([t]))[0].numpy()
+        for k in range(5):
+            ref = Slerp([0, 1], rot[k:k + 2])([t]).as_quat()[0]
+            assert min(np.abs(got[k] - ref).max(), np.abs(got[k] + ref).max()) < 1e-6
+    g = golden("e2e_resample.npz")
+    cfg = _cfg("hmr_full", g["part_iters"], 25, 25)
+    img, markers = _resample_case(g)
+    stats = {}
+    out = stages_ref.multimodal_video_mocap(img, markers, oracle_smpl, cfg, stats=stats)
+    assert out["trans"].shape[0] == g["out_trans"].shape[0] == 9
+    np.testing.assert_allclose(out["pose_body"].numpy(), g["out_pose_body"], atol=1e-6)
+    np.testing.assert_allclose(out["trans"].numpy(), g["out_trans"], atol=2e-4)
+    np.testing.assert_allclose(out["root_orient"].numpy(), g["out_root_orient"], atol=2e-4)
+    np.testing.assert_allclose(out["betas"].numpy(), g["out_betas"], atol=2e-4)
+    np.testing.assert_array_equal([len(e) for e in stats["part"]["evals"]], g["n_evals"])

@@ -70,9 +70,6 @@ def multimodal_video_mocap(
         # o_betas and a missing 'lr' key, optimization.py:51,112)
         if config["stages"][key]["num_iters"] > 0:
             raise NotImplementedError("stage '%s' is disabled in every shipped config and is not built" % key)
-    if mocap_markers.get_frequency() != img_smpl.freq:
-        raise NotImplementedError("mocap/video frame-rate resampling (reference multimodal.py:145-182) is not built: "
-                                  "resample the HMR track to the mocap rate first")
     device = torch.device(device)
     if smpl_inference is None:
         smpl_inference = SmplInference(device)
@@ -88,6 +85,17 @@ def multimodal_video_mocap(
     o_foot_contacts = getattr(img_smpl, "foot_contacts", None)
     if o_foot_contacts is not None:
         o_foot_contacts = o_foot_contacts.clone().detach().to(device)
+    if mocap_markers.get_frequency() != img_smpl.freq:
+        # bring the HMR track to the mocap frame rate (reference :145-182); img_mask and the camera stay in video
+        # frames there, so the reprojection stage (which pairs them with the resampled track) cannot follow
+        if config["find_best_part_fits"] and config["stages"]["reprojection_part"]["num_iters"] > 0:
+            raise NotImplementedError("stages.reprojection_part with different mocap / video frame rates: the reference "
+                                      "pairs the resampled HMR track with the un-resampled camera (multimodal.py:270-284)")
+        from .resample import resample_hmr
+
+        o_trans, o_root_orient, o_pose_body, o_foot_contacts = resample_hmr(
+            o_trans, o_root_orient, o_pose_body, o_foot_contacts, float(img_smpl.freq),
+            float(mocap_markers.get_frequency()))
 
     trans = o_trans.clone().detach().requires_grad_(True)
     root_orient = o_root_orient.clone().detach().requires_grad_(True)

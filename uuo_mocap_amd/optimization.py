@@ -228,7 +228,7 @@ def compute_nearest_points(
         )["vertices"]
         if cl["use_mean"] and not cl["use_barycentric"]:
             # the window loop only fills the distance matrix in this mode; the result is the argmin below (:595-603)
-            valid = (img_mask == 1)
+            valid = _valid_frames(img_mask, markers.shape[0])
             idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, valid)
             one_hot = torch.zeros((markers.shape[1], verts.shape[1]), dtype=torch.float32, device=verts.device)
             one_hot.scatter_(1, idx.long()[:, None], 1.0)
@@ -237,10 +237,22 @@ def compute_nearest_points(
                                         pose_body.shape[1], window_size, use_velocity and o_pose_body is not None)
         if cl["use_mean"]:
             # both flags: the mean-distance argmin overwrites the window loop's result (:595-603)
-            idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, img_mask == 1)
+            idx = smpl_inference.device_model.assign_mean_argmin(verts, markers, _valid_frames(img_mask, markers.shape[0]))
             coords = torch.zeros_like(coords)
             coords.scatter_(1, idx.long()[:, None], 1.0)
     return coords.to(device)
+
+
+def _valid_frames(img_mask: torch.Tensor, num_frames: int) -> torch.Tensor:
+    """[num_frames] bool.  The reference indexes its per-frame tables with np.where(img_mask == 1) (:466,597): the mask
+    is in VIDEO frames, the tables in mocap frames, so after frame-rate resampling only the leading len(img_mask)
+    frames can be valid, and a set index beyond the sequence is an IndexError there."""
+    idx = torch.where(img_mask == 1)[0]
+    if idx.numel() and int(idx.max()) >= num_frames:
+        raise IndexError("img_mask marks frame %d but the sequence has %d frames" % (int(idx.max()), num_frames))
+    valid = torch.zeros(num_frames, dtype=torch.bool, device=img_mask.device)
+    valid[idx] = True
+    return valid
 
 
 #: diagnostics of the last barycentric placement (selected frame per marker, distances, velocity factors)
