@@ -129,7 +129,7 @@ def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals):
     }
 
 
-def measure_roofline(smpl, seq, dev, F, iters=50):
+def measure_roofline(smpl, seq, dev, F, iters=200):
     from uuo_mocap_amd.config import packaged_config
     from uuo_mocap_amd.engine import ChamferProblem
 
