@@ -81,24 +81,33 @@ def get_sub_hierachies(parents, num_bones: int) -> List[List[int]]:
     return [list(st) for st in _sub_hierarchies_cached(key)]
 
 
-@functools.lru_cache(maxsize=64)
-def _sub_hierarchies_cached(key):
-    parents_t, num_bones = key
+@functools.lru_cache(maxsize=8)
+def _rooted_subtrees(parents_t):
+    """Every connected sub-tree of the kinematic tree, grouped by its root, in the reference's enumeration order.  It
+    does not depend on the requested size, so it is built once per tree (15 ms for SMPL) and only filtered per call:
+    the number of rigid marker clusters, hence the size, changes from sequence to sequence."""
     n = len(parents_t)
-    num_bones = min(num_bones, n)
     kids: Dict[int, List[int]] = {i: [] for i in range(n)}
     for i in range(1, n):
         kids[int(parents_t[i])].append(i)
     rooted: Dict[int, List[List[int]]] = {}
     for node in reversed(range(n)):  # children carry larger ids, so they are finished first
         options = [[]]
+        seen = {()}
         for pick in itertools.product(*[rooted[c] for c in kids[node]]):
-            merged = sorted(j for part in pick for j in part)
-            cand = [node] + merged
-            if cand not in options:
-                options.append(cand)
+            cand = tuple([node] + sorted(j for part in pick for j in part))
+            if cand not in seen:
+                seen.add(cand)
+                options.append(list(cand))
         rooted[node] = options
-    return tuple(tuple(st) for node in reversed(range(n)) for st in rooted[node] if len(st) == num_bones)
+    return tuple(tuple(tuple(st) for st in rooted[node]) for node in reversed(range(n)))
+
+
+@functools.lru_cache(maxsize=64)
+def _sub_hierarchies_cached(key):
+    parents_t, num_bones = key
+    num_bones = min(num_bones, len(parents_t))
+    return tuple(st for per_root in _rooted_subtrees(parents_t) for st in per_root if len(st) == num_bones)
 
 
 def remove_approximately_redundant_hierarchies(subtrees_list: List[List[int]], similarity_threshold: float = 0.9):
