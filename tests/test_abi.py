@@ -1,5 +1,6 @@
 """CPU-side checks of the C-ABI library and the host mirror (no kernels are launched)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -165,3 +166,26 @@ def test_runner_conventions(tmp_path, tables):
                                               str(root), "--subjects", "s02", "--sequences", "jump"])
     with pytest.raises(NotImplementedError):
         runner.run(args2, fit_fn=fake_fit)  # .c3d readers are outside the accelerated path
+
+
+def test_evaluation_metrics_match_reference():
+    """uuo_mocap_amd.metrics against the fixture captured from the reference's own evaluation/metrics.py (the pure
+    tensor metrics run anywhere; the marker-to-surface distance needs the GPU and is in tests/test_gpu_parity.py)."""
+    import numpy as np
+    import torch
+    from uuo_mocap_amd import metrics as m
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    pred, gt = torch.from_numpy(g["pred"]), torch.from_numpy(g["gt"])
+    ids, freq = g["joint_ids"].tolist(), float(g["freq"])
+    got = {
+        "mpjpe": m.compute_MPJPE(pred, gt), "mpjpe_joints": m.compute_MPJPE_joints(pred, gt, ids),
+        "mpjve": m.compute_MPJVE(pred, gt, freq), "mpjve_joints": m.compute_MPJVE_joints(pred, gt, freq, ids),
+        "pa_mpjpe": m.compute_PA_MPJPE(pred, gt), "pa_mpjpe_joints": m.compute_PA_MPJPE_joints(pred, gt, ids),
+        "pa_mpjve": m.compute_PA_MPJVE(pred, gt, freq),
+        "pa_mpjve_joints": m.compute_PA_MPJVE_joints(pred, gt, freq, ids),
+        "v2v": m.compute_V2V(torch.from_numpy(g["pred_verts"]), torch.from_numpy(g["gt_verts"])),
+        "aligned": m.compute_similarity_transform(pred, gt),
+    }
+    for k, v in got.items():
+        np.testing.assert_allclose(v.numpy(), g["out_" + k], rtol=2e-5, atol=2e-6, err_msg=k)

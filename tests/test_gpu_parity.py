@@ -1009,3 +1009,18 @@ def test_frame_rate_resampling_matches_reference(smpl, golden, dev):
     np.testing.assert_array_equal(tr[-1].cpu().numpy(), g["hmr_trans"][-1])
     det = torch.linalg.det(po)
     assert float((det - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_marker_to_surface_metric_matches_reference(golden, dev):
+    """compute_marker_to_surface_distance (HIP closest point on the mesh for every marker and frame) against the value
+    the reference's own metric produced for the same inputs (its igl call routed to the float64 oracle)."""
+    from uuo_mocap_amd import metrics as m
+
+    g = golden("metrics.npz")
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
+    F = g["gt_verts"].shape[0]
+    got = m.compute_marker_to_surface_distance(t("gt_verts"), t("faces")[None].repeat(F, 1, 1), t("markers"))
+    assert got.device.type == "cpu" and float(got) == pytest.approx(float(g["out_m2s"]), rel=1e-5)
+    assert float(m.compute_marker_to_surface_distance(t("gt_verts"), t("faces"), t("markers"))) == float(got)
+    assert float(m.compute_PA_MPJPE(t("pred"), t("gt"))) == pytest.approx(float(g["out_pa_mpjpe"]), rel=1e-4)

@@ -62,7 +62,7 @@ struct BwdArgs {
 #define BWD_SLOTS 16  // (wave, 16-lane group) pairs: items in flight per block
 #define BWD_NW 4  // waves per frame block (8 waves needs <= 128 VGPRs for 2 blocks/CU and spills: 43 -> 73 us)
 template <bool SPARSE>
-__global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
+__device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   __builtin_amdgcn_s_setprio(2);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
@@ -217,10 +217,9 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
       return v;
     };
     const int rounds = (M + BWD_SLOTS - 1) / BWD_SLOTS;
-    Item16 cur, nxt;
-    fetch16(slot, cur);
+    Item16 cur;
     for (int r = 0; r < rounds; ++r) {
-      if (r + 1 < rounds) fetch16(slot + BWD_SLOTS * (r + 1), nxt);  // block-uniform
+      fetch16(slot + BWD_SLOTS * r, cur);
       const float wgt = cur.wgt, d2 = cur.d2;
       float vp[3];
       {
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
       }
       acc_dt16 += (sl == 0) ? g[0] : ((sl == 1) ? g[1] : g[2]);  // sub-lanes 0..2
       acc_loss16 += loss_item;                                     // sub-lane 0 is the one that is stored
-      cur = nxt;
     }
 #pragma unroll
     for (int t = 0; t < 13; ++t) w_dpf[slot][sl + 16 * t] = acc_pf[t];
@@ -673,6 +671,15 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd(BwdArgs a) {
   }
 }
 
+// Two entry points so that each gets its own register budget.  The sparse one (<= 4 skin weights per vertex: SMPL) is
+// held to 168 VGPRs = 3 waves per SIMD: k_skin2 keeps 2 x 168 of the 512 registers of every SIMD for the whole of its
+// run, and a backward block of another yaw hypothesis / sequence can only start beside it if it fits in the remaining
+// 176 (at 238 registers it waited for the skinning kernel to drain: +1.7 % fit throughput, same single-stream time).
+__global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bwd_sparse(BwdArgs a) {
+  bwd_body<true>(a);
+}
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_dense(BwdArgs a) { bwd_body<false>(a); }
+
 // ----------------------------------------------------------------------------------------------------
 // K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
 // prior, writes the loss and the shared-parameter gradients (betas; z for the part stage).
@@ -915,9 +922,9 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.dir = d_dir;
   a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
   if (m->nnz <= 4)
-    hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   else
-    hipLaunchKernelGGL(k_bwd<false>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    hipLaunchKernelGGL(k_bwd_dense, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
 
   FinArgs fa;
@@ -1057,7 +1064,7 @@ extern "C" int uuo_smpl_backward(uuo_model_t* m, void* stream, int F, const floa
   a.up_joints = d_up_joints;
   a.frame_part = d_scratch;
   a.off_pose = a.off_root = a.off_z = a.off_trans = -1;
-  hipLaunchKernelGGL(k_bwd<true>, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -157,7 +157,7 @@ __device__ __host__ __forceinline__ size_t lb_hist_off(int slot, int i, int capL
 // the candidate slot by split 0) and the 512-column pieces of its rows (row r belongs to wave r mod 4*LB_DRS), all
 // loads of a column block in flight together.  Per-lane fp64 accumulators, one wave reduction per row at the end.
 #define LB_DRS 16                        // row splits
-#define LB_DRW ((LB_ROWS + 4 * LB_DRS - 1) / (4 * LB_DRS))  // rows per wave (7)
+#define LB_DRW ((LB_ROWS + 4 * LB_DRS - 1) / (4 * LB_DRS))  // rows per wave (4)
 __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int head, int count, int cand,
                                                   float* __restrict__ S, float* __restrict__ Y,
                                                   const float* __restrict__ g, const float* __restrict__ gp,
@@ -192,80 +192,61 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int h
   for (int a_ = 0; a_ < 3; ++a_) sp[a_][0] = sp[a_][1] = sp[a_][2] = 0.0;
 
   const int cb0 = grp * gcb, cb1 = min(ncb, cb0 + gcb);
-  // software pipeline over the group's column blocks: the loads of block cb + 1 are issued before block cb is
-  // consumed (6 + 2 * LB_DRW float4 per lane in flight per stage)
-  float4 ng[2], np_[2], nd[2], nr[LB_DRW][2];
-  auto issue = [&](int cb) {
-    const int ibase = cb * LB_CW;
-    const size_t cboff = (size_t)cb * LB_CBSTRIDE(capL);
+  // software pipeline over the group's column blocks, one 256-column half per stage: the loads of half hb + 1 are
+  // issued before half hb is consumed (3 + LB_DRW float4 per lane in flight per stage).  Half a column block per
+  // stage rather than a whole one keeps the kernel at 168 registers = 3 waves per SIMD, which is also what lets its
+  // blocks start beside a running k_skin2 (2 x 168 of the 512 registers of every SIMD) instead of waiting for it.
+  float4 ng, np_, nd, nr[LB_DRW];
+  auto issue = [&](int hb) {
+    const int cb = hb >> 1, h = hb & 1;
+    const int i = cb * LB_CW + h * 256 + lane * 4;  // vectors are padded to a multiple of LB_CW: in-bounds loads
+    const size_t cboff = (size_t)cb * LB_CBSTRIDE(capL) + (size_t)h * 256;
+    ng = *reinterpret_cast<const float4*>(g + i);
+    np_ = *reinterpret_cast<const float4*>(gp + i);
+    nd = *reinterpret_cast<const float4*>(d + i);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = ibase + h * 256 + lane * 4;  // vectors are padded to a multiple of LB_CW: in-bounds loads
-      ng[h] = *reinterpret_cast<const float4*>(g + i);
-      np_[h] = *reinterpret_cast<const float4*>(gp + i);
-      nd[h] = *reinterpret_cast<const float4*>(d + i);
-    }
-#pragma unroll
-    for (int q = 0; q < LB_DRW; ++q) {
-      nr[q][0] = *reinterpret_cast<const float4*>(rptr[q] + cboff);
-      nr[q][1] = *reinterpret_cast<const float4*>(rptr[q] + cboff + 256);
-    }
+    for (int q = 0; q < LB_DRW; ++q) nr[q] = *reinterpret_cast<const float4*>(rptr[q] + cboff);
   };
-  if (cb0 < cb1) issue(cb0);
-  for (int cb = cb0; cb < cb1; ++cb) {
-    const int ibase = cb * LB_CW;
-    float4 vg[2], vy[2], vs[2], rv[LB_DRW][2];
+  const int hb0 = cb0 * 2, hb1 = cb1 * 2;
+  if (hb0 < hb1) issue(hb0);
+  for (int hb = hb0; hb < hb1; ++hb) {
+    const int cb = hb >> 1, h = hb & 1;
+    const int i = cb * LB_CW + h * 256 + lane * 4;
+    float4 vg = ng;
+    float4 vy = make_float4(ng.x - np_.x, ng.y - np_.y, ng.z - np_.z, ng.w - np_.w);
+    float4 vs = make_float4(nd.x * t, nd.y * t, nd.z * t, nd.w * t);
+    float4 rv[LB_DRW];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      vg[h] = ng[h];
-      vy[h] = make_float4(ng[h].x - np_[h].x, ng[h].y - np_[h].y, ng[h].z - np_[h].z, ng[h].w - np_[h].w);
-      vs[h] = make_float4(nd[h].x * t, nd[h].y * t, nd[h].z * t, nd[h].w * t);
-    }
-#pragma unroll
-    for (int q = 0; q < LB_DRW; ++q) {
-      rv[q][0] = nr[q][0];
-      rv[q][1] = nr[q][1];
-    }
-    if (cb + 1 < cb1) issue(cb + 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = ibase + h * 256 + lane * 4;
-      // Entries past n belong to whatever problem used the work vectors before (a larger one leaves its gradient
-      // there) and must reach neither the dot products nor the stored pair.
-#define LB_MASK(c, k_) { const bool in_ = i + k_ < n; vg[h].c = in_ ? vg[h].c : 0.f; vy[h].c = in_ ? vy[h].c : 0.f; vs[h].c = in_ ? vs[h].c : 0.f; }
-      LB_MASK(x, 0) LB_MASK(y, 1) LB_MASK(z, 2) LB_MASK(w, 3)
+    for (int q = 0; q < LB_DRW; ++q) rv[q] = nr[q];
+    if (hb + 1 < hb1) issue(hb + 1);
+    // Entries past n belong to whatever problem used the work vectors before (a larger one leaves its gradient
+    // there) and must reach neither the dot products nor the stored pair.
+#define LB_MASK(c, k_) { const bool in_ = i + k_ < n; vg.c = in_ ? vg.c : 0.f; vy.c = in_ ? vy.c : 0.f; vs.c = in_ ? vs.c : 0.f; }
+    LB_MASK(x, 0) LB_MASK(y, 1) LB_MASK(z, 2) LB_MASK(w, 3)
 #undef LB_MASK
-    }
 #pragma unroll
     for (int q = 0; q < LB_DRW; ++q) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 r = rv[q][h];
-#define LB_ACC(c)                                         \
-        acc[q][0] += (double)r.c * (double)vy[h].c;       \
-        acc[q][1] += (double)r.c * (double)vs[h].c;       \
-        acc[q][2] += (double)r.c * (double)vg[h].c;
-        LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
+      const float4 r = rv[q];
+#define LB_ACC(c)                                      \
+      acc[q][0] += (double)r.c * (double)vy.c;         \
+      acc[q][1] += (double)r.c * (double)vs.c;         \
+      acc[q][2] += (double)r.c * (double)vg.c;
+      LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
 #undef LB_ACC
-      }
     }
     if (special) {  // wave-uniform: the new pair's own rows and g, and the store of the pair
-      float* yn = Y + (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + lane * 4;
-      float* sn = S + (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + lane * 4;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        *reinterpret_cast<float4*>(yn + h * 256) = vy[h];
-        *reinterpret_cast<float4*>(sn + h * 256) = vs[h];
-#define LB_SP(c)                                                                                           \
-        {                                                                                                  \
-          const double y_ = (double)vy[h].c, s_ = (double)vs[h].c, g_ = (double)vg[h].c;                   \
-          sp[0][0] += s_ * y_; sp[0][1] += s_ * s_; sp[0][2] += s_ * g_;                                   \
-          sp[1][0] += y_ * y_; sp[1][1] += y_ * s_; sp[1][2] += y_ * g_;                                   \
-          sp[2][0] += g_ * y_; sp[2][1] += g_ * s_; sp[2][2] += g_ * g_;                                   \
-        }
-        LB_SP(x) LB_SP(y) LB_SP(z) LB_SP(w)
-#undef LB_SP
+      const size_t o = (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + h * 256 + lane * 4;
+      *reinterpret_cast<float4*>(Y + o) = vy;
+      *reinterpret_cast<float4*>(S + o) = vs;
+#define LB_SP(c)                                                                                         \
+      {                                                                                                  \
+        const double y_ = (double)vy.c, s_ = (double)vs.c, g_ = (double)vg.c;                            \
+        sp[0][0] += s_ * y_; sp[0][1] += s_ * s_; sp[0][2] += s_ * g_;                                   \
+        sp[1][0] += y_ * y_; sp[1][1] += y_ * s_; sp[1][2] += y_ * g_;                                   \
+        sp[2][0] += g_ * y_; sp[2][1] += g_ * s_; sp[2][2] += g_ * g_;                                   \
       }
+      LB_SP(x) LB_SP(y) LB_SP(z) LB_SP(w)
+#undef LB_SP
     }
   }
 #pragma unroll

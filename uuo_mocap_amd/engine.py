@@ -185,23 +185,31 @@ class DeviceModel:
 
 
     def mesh_closest_points(self, verts, faces, points):
-        """uuo_mesh_closest_points: closest point of points[f,m] on the mesh (verts[f], faces) ->
-        (dist [F,M], face [F,M] int32, closest [F,M,3], barycentric [F,M,3])."""
-        verts = _f32(verts, "verts")
-        points = _f32(points, "points")
-        faces = faces.to(device=self.device, dtype=torch.int32).contiguous()
-        F, V, M, NF = verts.shape[0], verts.shape[1], points.shape[1], faces.shape[0]
-        if points.shape[0] != F or faces.dim() != 2 or faces.shape[1] != 3:
-            raise ValueError("mesh_closest_points: verts [F,V,3], faces [NF,3], points [F,M,3] expected")
-        dist = torch.empty((F, M), dtype=torch.float32, device=self.device)
-        face = torch.empty((F, M), dtype=torch.int32, device=self.device)
-        closest = torch.empty((F, M, 3), dtype=torch.float32, device=self.device)
-        bary = torch.empty((F, M, 3), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            check(self.lib.uuo_mesh_closest_points(current_stream(self.device), F, M, V, NF, _ptr(verts), _ptr(faces),
-                                                   _ptr(points), _ptr(dist), _ptr(face), _ptr(closest), _ptr(bary)),
-                  "uuo_mesh_closest_points")
-        return dist, face, closest, bary
+        """uuo_mesh_closest_points (see the module-level function; it needs no model tables)."""
+        return mesh_closest_points(verts, faces, points)
+
+
+def mesh_closest_points(verts, faces, points):
+    """uuo_mesh_closest_points: closest point of points[f,m] on the mesh (verts[f], faces) ->
+    (dist [F,M], face [F,M] int32, closest [F,M,3], barycentric [F,M,3])."""
+    lib = _lib.load()
+    verts = _f32(verts, "verts")
+    points = _f32(points, "points")
+    device = verts.device
+    if device.type != "cuda":
+        raise RuntimeError("mesh_closest_points needs a CUDA/HIP device (got %s); there is no CPU path" % device)
+    faces = faces.to(device=device, dtype=torch.int32).contiguous()
+    if verts.dim() != 3 or points.dim() != 3 or points.shape[0] != verts.shape[0] or faces.dim() != 2 or faces.shape[1] != 3:
+        raise ValueError("mesh_closest_points: verts [F,V,3], faces [NF,3], points [F,M,3] expected")
+    F, V, M, NF = verts.shape[0], verts.shape[1], points.shape[1], faces.shape[0]
+    dist = torch.empty((F, M), dtype=torch.float32, device=device)
+    face = torch.empty((F, M), dtype=torch.int32, device=device)
+    closest = torch.empty((F, M, 3), dtype=torch.float32, device=device)
+    bary = torch.empty((F, M, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(lib.uuo_mesh_closest_points(current_stream(device), F, M, V, NF, _ptr(verts), _ptr(faces), _ptr(points),
+                                          _ptr(dist), _ptr(face), _ptr(closest), _ptr(bary)), "uuo_mesh_closest_points")
+    return dist, face, closest, bary
 
 
 class _StageProblem:

@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict
 
@@ -73,7 +74,12 @@ def multimodal_video_mocap(
     device = torch.device(device)
     if smpl_inference is None:
         smpl_inference = SmplInference(device)
-    stats: Dict = {"part": [], "chamfer": [], "marker": [], "marker_final": []}
+    stats: Dict = {"part": [], "chamfer": [], "marker": [], "marker_final": [], "timeline": []}
+    t_start = time.perf_counter()
+
+    def mark(label: str):  # host-side stage boundaries of this call, seconds since entry (bench.py reports them)
+        stats["timeline"].append((label, time.perf_counter() - t_start))
+
     verbose = "loss" in print_options
 
     o_trans = img_smpl.trans.clone().detach().to(device)
@@ -122,6 +128,7 @@ def multimodal_video_mocap(
     markers = pad(markers, -offset).detach().contiguous()
     num_frames = trans.shape[0]
 
+    mark("inputs")
     # ---- marker segmentation
     print("Stage: computing marker segmentation...")
     with torch.no_grad():
@@ -135,6 +142,7 @@ def multimodal_video_mocap(
         aabb_volume_ratio = torch.median(get_aabb_volume(get_aabb(markers)) /
                                          get_aabb_volume(get_aabb(mean_out["vertices"])))
 
+    mark("segmentation")
     filter_output = None
     smpl_part = None
     camera = {"joints_2d_gt": None, "focal_length": None, "reproject_mask": None, "cam_trans": None,
@@ -183,6 +191,7 @@ def multimodal_video_mocap(
         smpl_part = {"trans": _np(trans), "root_orient": _np(normalize_rot(root_orient)), "betas": _np(betas[0]),
                      "pose_body": _np(normalize_rot(o_pose_body))}
     marker_labels = segmented_markers.detach().cpu().numpy()
+    mark("part")
 
     if not config["find_best_part_fits"] or aabb_volume_ratio > 0.4:
         trans = torch.median(markers, dim=1)[0].requires_grad_(True)
@@ -270,6 +279,7 @@ def multimodal_video_mocap(
     else:
         results = [fit_hypothesis(0, a, None) for a in root_orient_angles]
     set_workspace_slot(0)
+    mark("hypotheses")
     for root_orient_angle, local in zip(root_orient_angles, results):
         smpl_chamfer_rotations[root_orient_angle] = local["chamfer"]
         smpl_marker_rotations[root_orient_angle] = local["marker"]
@@ -297,6 +307,7 @@ def multimodal_video_mocap(
             best_angle_chamfer, best_angle = score, root_orient_angle
     stats["yaw_scores"] = yaw_scores
     stats["best_angle"] = best_angle
+    mark("selection")
 
     smpl_chamfer = smpl_chamfer_rotations[best_angle]
     smpl_marker = smpl_marker_rotations[best_angle]
@@ -335,6 +346,7 @@ def multimodal_video_mocap(
         smpl_marker_final = {"trans": _np(trans), "root_orient": _np(root_orient), "betas": _np(betas[0]),
                              "pose_body": _np(pose_body)}
 
+    mark("final_marker")
     output = {
         "trans": trans.detach().cpu(),
         "root_orient": normalize_rot(root_orient).detach().cpu(),
@@ -358,6 +370,7 @@ def multimodal_video_mocap(
             output["stages"]["marker_final"] = smpl_marker_final
     if filter_output is not None:
         output["chain"] = filter_output["chain"]
+    mark("outputs")
     LAST_RUN_STATS.clear()
     LAST_RUN_STATS.update(stats)
     _tls_stats.last = stats
