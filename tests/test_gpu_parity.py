@@ -634,6 +634,12 @@ def test_direction_coefficients_block_inverse_vs_serial(dev, k):
         assert lib.uuo_debug_small_coeffs(k, 0, seed, new.ctypes.data) == 0
         scale = max(np.abs(ref).max(), 1e-30)
         assert np.abs(ref - new).max() <= 1e-12 * scale, (k, seed, np.abs(ref - new).max() / scale)
+        # k_lb_small_inv (the default): the window's inverse is carried between iterations and the accepted pair
+        # appends one column to it, so both recurrences are mat-vecs; its state is prepared on the host here, with
+        # NaN everywhere the kernel has no business reading
+        inv = np.zeros(209)
+        assert lib.uuo_debug_small_coeffs(k, 2, seed, inv.ctypes.data) == 0
+        assert np.abs(ref - inv).max() <= 1e-11 * scale, (k, seed, np.abs(ref - inv).max() / scale)
 
 
 def test_batch_runner_end_to_end(smpl, dev, tmp_path):

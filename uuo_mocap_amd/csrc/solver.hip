@@ -31,6 +31,7 @@ struct LbDev {                       // device-resident optimiser state
   unsigned dmax_bits;
   int pad;
   double out[16];                    // read-back block (see LbOut)
+  double W[LB_MAXH * LB_MAXH];       // inverse of U = upper triangle of S.Y^T over the window, by slot (k_lb_small_inv)
 };
 
 struct LbOut {  // layout of LbDev::out
@@ -835,6 +836,219 @@ __global__ __launch_bounds__(512) void k_lb_small(int nchunks, int cap, int hist
   }
 }
 
+// Third formulation of the same step: no triangular SOLVE at all.  The inverse W of U (upper triangle of S.Y^T over
+// the history window, logical order oldest first) is kept on the device from one iteration to the next:
+//   * accepting the pair (s, y) appends the column u = S_old.y and the diagonal rho = s.y to U; the inverse gains the
+//     column -W u / rho and the diagonal 1 / rho (column-by-column inversion of a triangular matrix, Higham,
+//     "Accuracy and Stability of Numerical Algorithms", method 2: |W U - I| <= c eps |W| |U|) -- one mat-vec;
+//   * dropping the oldest pair removes the first row and column of U, and the inverse of a trailing block of a
+//     triangular matrix is the trailing block of its inverse -- nothing to compute, the slot simply leaves the window.
+// Both loops of the recursion are then mat-vecs, al = W (-S.g) and cs = W^T (D al - cg Y.g - YY cy): the 2 * 7
+// dependent block steps of k_lb_small (~19 us at a full history) become three 104-term mat-vecs spread over 512 lanes
+// (4 lanes per row, fixed summation order).  W is indexed by SLOT like S.Y^T; rows are zeroed when a slot is
+// (re)inserted, so entries below the logical diagonal are exact zeros and the mat-vecs need no masks.
+__device__ __forceinline__ double quad_sum_d(double v) {  // sum over the 4 lanes of a quad, same order on every lane
+  const double a = v + __shfl_xor(v, 1, 64);
+  return a + __shfl_xor(a, 2, 64);
+}
+__global__ __launch_bounds__(512) void k_lb_small_inv(int nchunks, int cap, int hist, int cand,
+                                                       const double* __restrict__ part, LbDev* __restrict__ st,
+                                                       int stop) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  __shared__ double Ws[LB_MAXH * LB_US];  // W by slot
+  __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH], vv[LB_MAXH];
+  __shared__ double ucol[LB_MAXH], udiag[LB_MAXH];
+  __shared__ double rd[LB_ROWS * 3];
+  __shared__ int slot_of[LB_MAXH + 24];
+  __shared__ double wpart[3][LB_MAXH + 24];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int head = st->head, count = st->count;
+  const int nact = count + 1;
+  // ---- W as it stands before this iteration's pair, and the diagonal of U: issued first, consumed after the sums
+  constexpr int NSY = LB_MAXH * LB_MAXH / 2;               // double2 elements
+  constexpr int PSY = (NSY + 511) / 512;                   // per thread (11)
+  double2 wcopy[PSY];
+  {
+    const double2* src = reinterpret_cast<const double2*>(st->W);
+#pragma unroll
+    for (int r = 0; r < PSY; ++r) {
+      const int e = tid + 512 * r;
+      wcopy[r] = (e < NSY) ? src[e] : make_double2(0.0, 0.0);
+    }
+  }
+  const double dg = (tid < LB_MAXH) ? st->SY[tid * (LB_MAXH + 1)] : 0.0;
+  // ---- reduce the partial dots of the active rows (fixed chunk order -> deterministic)
+  for (int e = tid; e < LB_ROWS * 3; e += 512) {
+    const int row = e / 3;
+    const int slot = (row < LB_MAXH) ? row : row - LB_MAXH;
+    bool active = (row == 2 * LB_MAXH);
+    if (!active && slot < cap) {
+      const int rel = (slot - head + cap) % cap;
+      active = (rel < count) || (slot == cand);
+    }
+    double acc = 0.0;
+    if (active) {
+      double v[LB_MAXCHUNK];
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) v[c] = (c < nchunks) ? part[(size_t)c * LB_ROWS * 3 + e] : 0.0;
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) acc += v[c];
+    }
+    rd[e] = acc;
+  }
+#pragma unroll
+  for (int r = 0; r < PSY; ++r) {
+    const int e = tid + 512 * r;
+    if (e < NSY) {
+      const int row = (2 * e) / LB_MAXH, col = (2 * e) - row * LB_MAXH;  // LB_MAXH is even: pairs never straddle rows
+      Ws[row * LB_US + col] = wcopy[r].x;
+      Ws[row * LB_US + col + 1] = wcopy[r].y;
+    }
+  }
+  if (tid < LB_MAXH) udiag[tid] = dg;
+  __syncthreads();
+  // ---- candidate row / column of the Gram matrices (device copies for the next iterations)
+  const double ys = rd[cand * 3 + 0];              // s_new . y_new
+  const double yy = rd[(LB_MAXH + cand) * 3 + 0];  // y_new . y_new
+  for (int r = tid; r < nact; r += 512) {
+    const int slot = (r < count) ? (head + r) % cap : cand;
+    const double sy_col = rd[slot * 3 + 0];              // s_slot . y_new
+    const double sy_row = rd[(LB_MAXH + slot) * 3 + 1];  // s_new . y_slot
+    st->SY[slot * LB_MAXH + cand] = sy_col;
+    st->SY[cand * LB_MAXH + slot] = sy_row;
+    ucol[slot] = sy_col;
+    st->YY[slot * LB_MAXH + cand] = rd[(LB_MAXH + slot) * 3 + 0];
+    st->YY[cand * LB_MAXH + slot] = rd[(LB_MAXH + slot) * 3 + 0];
+    Sg[slot] = rd[slot * 3 + 2];
+    Yg[slot] = rd[(LB_MAXH + slot) * 3 + 2];
+  }
+  __threadfence_block();
+  const bool accept = ys > 1e-10;
+  double Hdiag = st->Hdiag;
+  if (accept) {
+    if (count == hist)
+      head = (head + 1) % cap;  // drop the oldest; the candidate slot becomes the newest
+    else
+      count += 1;
+    Hdiag = ys / yy;
+  }
+  const int k = count;
+  auto slotf = [&](int i) { const int v = head + i; return (v >= cap) ? v - cap : v; };
+  for (int j = tid; j < LB_MAXH + 24; j += 512) slot_of[j] = (j < k) ? slotf(j) : 0;
+  __syncthreads();
+  if (stop == 1) return;
+  // ---- waves 3..5 fetch their rows of Y.Y^T into registers for the mat-vec between the two products
+  const int j0 = lane, j1 = lane + 64;
+  const int sl0 = (j0 < k) ? slotf(j0) : 0, sl1 = (j1 < k) ? slotf(j1) : 0;
+  double yv0[LB_YR], yv1[LB_YR];  // waves 3..5: rows i = (wave-3) + 3 r of YY, columns j0 / j1
+  if (wave >= 3 && wave <= 5) {
+#pragma unroll
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 3) + 3 * r;
+      const int si = (i < k) ? slot_of[i] : 0;
+      yv0[r] = (i < k && j0 < k) ? st->YY[si * LB_MAXH + sl0] : 0.0;
+      yv1[r] = (i < k && j1 < k) ? st->YY[si * LB_MAXH + sl1] : 0.0;
+    }
+  }
+  if (stop == 2) return;
+  // quad (4 lanes) per row: row i = tid / 4 (128 >= LB_MAXH rows), lane p of the quad takes columns p, p + 4, ...
+  const int qi = tid >> 2, qp = tid & 3;
+  const bool qrow = qi < k;
+  const int qs = qrow ? slot_of[qi] : 0;
+  // ---- the accepted pair's column of W: -W_old u / rho over the rows that stay in the window, 1 / rho on the diagonal
+  if (accept) {
+    double t = 0.0;
+    for (int j = qp; j < k - 1; j += 4) {
+      const int sj = slot_of[j];
+      t = fma(Ws[qs * LB_US + sj], ucol[sj], t);
+    }
+    t = quad_sum_d(t);
+    __syncthreads();  // every read of the old W is done before the candidate's row and column are rewritten
+    const double rinv = 1.0 / ys;
+    if (qp == 0 && qi < k - 1) {
+      const double wcol = -t * rinv;
+      Ws[qs * LB_US + cand] = wcol;
+      st->W[qs * LB_MAXH + cand] = wcol;
+    }
+    for (int c = tid; c < LB_MAXH; c += 512) {  // the candidate's row: zeros below the logical diagonal
+      const double wrow = (c == cand) ? rinv : 0.0;
+      Ws[cand * LB_US + c] = wrow;
+      st->W[cand * LB_MAXH + c] = wrow;
+    }
+    if (tid == 0) udiag[cand] = ys;
+  }
+  __syncthreads();
+  if (stop == 3) return;
+  // ---- loop 1 of the recursion:  al = W (-S.g)
+  {
+    double t = 0.0;
+    for (int j = qp; j < k; j += 4) {
+      const int sj = slot_of[j];
+      t = fma(Ws[qs * LB_US + sj], -Sg[sj], t);
+    }
+    t = quad_sum_d(t);
+    if (qp == 0 && qrow) al[qi] = t;
+  }
+  __syncthreads();
+  if (stop == 4) return;
+  const double cg = -Hdiag;
+  for (int j = tid; j < k; j += 512) cy_s[j] = -Hdiag * al[j];
+  __syncthreads();
+  // ---- w = YY cy: YY is symmetric, so lane j accumulates sum_i YY[i][j] cy_i over the rows its wave fetched
+  if (wave >= 3 && wave <= 5) {
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < LB_YR; ++r) {
+      const int i = (wave - 3) + 3 * r;
+      const double c = (i < k) ? cy_s[i] : 0.0;
+      acc0 = fma(yv0[r], c, acc0);
+      acc1 = fma(yv1[r], c, acc1);
+    }
+    wpart[wave - 3][j0] = acc0;
+    if (j1 < LB_MAXH) wpart[wave - 3][j1] = acc1;
+  }
+  __syncthreads();
+  for (int j = tid; j < k; j += 512) {
+    const int sj = slot_of[j];
+    vv[j] = al[j] * udiag[sj] - (cg * Yg[sj] + ((wpart[0][j] + wpart[1][j]) + wpart[2][j]));
+  }
+  __syncthreads();
+  if (stop == 5) return;
+  // ---- loop 2:  cs = W^T (D al - (cg Y.g + YY cy))
+  {
+    double t = 0.0;
+    for (int j = qp; j < k; j += 4) t = fma(Ws[slot_of[j] * LB_US + qs], vv[j], t);
+    t = quad_sum_d(t);
+    if (qp == 0 && qrow) cs_s[qi] = t;
+  }
+  __syncthreads();
+  // ---- publish: coefficients by slot, g.d from the Gram data
+  double gpart = 0.0;
+  for (int j = tid; j < k; j += 512) {
+    const int sj = slot_of[j];
+    gpart += cy_s[j] * Yg[sj] + cs_s[j] * Sg[sj];
+    st->cy[sj] = cy_s[j];
+    st->cs[sj] = cs_s[j];
+  }
+  gpart = wave_sum_d(gpart);
+  if (lane == 0) wpart[0][LB_MAXH + wave] = gpart;  // free tail of the scratch rows
+  __syncthreads();
+  if (tid == 0) {
+    double gsum = 0.0;
+    for (int w_ = 0; w_ < 8; ++w_) gsum += wpart[0][LB_MAXH + w_];
+    const double gg = rd[(2 * LB_MAXH) * 3 + 2];
+    st->cg = cg;
+    st->Hdiag = Hdiag;
+    st->head = head;
+    st->count = count;
+    st->dmax_bits = 0u;
+    LbOut* o = reinterpret_cast<LbOut*>(st->out);
+    o->gtd_dir = cg * gg + gsum;
+    o->accepted = accept ? 1.0 : 0.0;
+    o->ys = ys;
+  }
+}
+
 __global__ __launch_bounds__(128) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
                                                        const float* __restrict__ Y, const float* __restrict__ g,
                                                        LbDev* __restrict__ st, float* __restrict__ d,
@@ -1201,10 +1415,13 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
                            w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part);
         static const int small_stop = getenv("UUO_SMALL_STOP") ? atoi(getenv("UUO_SMALL_STOP")) : 0;  // ablation only
         static const int small_ref = getenv("UUO_SMALL_REF") ? atoi(getenv("UUO_SMALL_REF")) : 0;  // comparison only
+        static const int small_block = getenv("UUO_SMALL_BLOCK") ? atoi(getenv("UUO_SMALL_BLOCK")) : 0;  // comparison only
         if (small_ref)
           hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        else
+        else if (small_block)
           hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
+        else
+          hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(128), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
                            (float)t, xoth);
       }
@@ -1550,6 +1767,11 @@ extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
   UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, YY), YY.data(), YY.size() * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double> part((size_t)LB_MAXCHUNK * LB_ROWS * 3, 1e-3);
   UUO_HIP_CHECK(hipMemcpy(w->part, part.data(), part.size() * sizeof(double), hipMemcpyHostToDevice));
+  {
+    std::vector<double> W((size_t)LB_MAXH * LB_MAXH, 0.0);
+    for (int i = 0; i < LB_MAXH; ++i) W[(size_t)i * LB_MAXH + i] = 0.5;
+    UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, W), W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   const int cap = LB_MAXH - 3, hist = LB_MAXH - 4;
   float total = 0.f;
   for (int it = 0; it < iters + 1; ++it) {
@@ -1559,7 +1781,9 @@ extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
     const double one = 1.0;
     UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
     UUO_HIP_CHECK(hipEventRecord(w->ev0, nullptr));
-    if (stop >= 100)
+    if (stop >= 200)
+      hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 200);
+    else if (stop >= 100)
       hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 100);
     else
       hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop);
@@ -1623,6 +1847,7 @@ extern "C" int uuo_debug_small_coeffs(int k, int use_ref, int seed, double* out)
   for (int r = 0; r < LB_ROWS; ++r)
     for (int c = 0; c < 3; ++c) part[(size_t)r * 3 + c] = (r == k - 1 && c == 0) ? 1.3 : 0.7 * rnd(r + 2000, c);  // chunk 0 only
   part[(size_t)(LB_MAXH + k - 1) * 3 + 0] = 2.9;  // y_new . y_new
+  part[(size_t)(LB_MAXH + k - 1) * 3 + 1] = 1.3;  // y_new . s_new: the same number as s_new . y_new, as in a real run
   UUO_HIP_CHECK(hipMemcpy(w->part, part.data(), part.size() * sizeof(double), hipMemcpyHostToDevice));
   const int cap = LB_MAXH - 3, hist = LB_MAXH - 4;
   const int head = 0, count = k - 1;
@@ -1630,7 +1855,23 @@ extern "C" int uuo_debug_small_coeffs(int k, int use_ref, int seed, double* out)
   UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, count), &count, sizeof(int), hipMemcpyHostToDevice));
   const double one = 1.0;
   UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
-  if (use_ref)
+  if (use_ref == 2) {
+    // the state k_lb_small_inv expects: W = inverse of the upper triangle of S.Y^T over the k - 1 pairs already in the
+    // window (slots 0..k-2), by back-substitution on the host; everything else in W is poisoned to catch stray reads
+    const int m = k - 1;
+    std::vector<double> W((size_t)LB_MAXH * LB_MAXH, std::nan(""));
+    for (int c = 0; c < m; ++c) {
+      std::vector<double> x(m, 0.0);
+      for (int r = c; r >= 0; --r) {
+        double acc = (r == c) ? 1.0 : 0.0;
+        for (int q = r + 1; q <= c; ++q) acc -= SY[(size_t)r * LB_MAXH + q] * x[q];
+        x[r] = acc / SY[(size_t)r * LB_MAXH + r];
+      }
+      for (int r = 0; r < m; ++r) W[(size_t)r * LB_MAXH + c] = x[r];
+    }
+    UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, W), W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
+  } else if (use_ref)
     hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
   else
     hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
