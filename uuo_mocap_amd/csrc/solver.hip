@@ -1049,19 +1049,24 @@ __global__ __launch_bounds__(512) void k_lb_small_inv(int nchunks, int cap, int 
   }
 }
 
-__global__ __launch_bounds__(128) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
-                                                       const float* __restrict__ Y, const float* __restrict__ g,
-                                                       LbDev* __restrict__ st, float* __restrict__ d,
-                                                       const float* __restrict__ x, float t, float* __restrict__ xt) {
+#define LB_DQ 4  // slot ranges per 256-column strip of k_lb_direction (one wave each)
+__global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
+                                                             const float* __restrict__ Y, const float* __restrict__ g,
+                                                             LbDev* __restrict__ st, float* __restrict__ d,
+                                                             const float* __restrict__ x, float t, float* __restrict__ xt) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass.
-  // One block per column block of the history (LB_CW columns, FOUR per thread: 16-byte loads -- the vector-memory
-  // pipe costs ~16 cycles per wave instruction whatever its width, and 8-byte loads made this kernel bound by it):
-  // the slots it combines are one contiguous region; two batches of 8 slots (16 loads) are in flight per thread.
+  // One block per 256-column strip of the history (FOUR columns per lane: 16-byte loads -- the vector-memory pipe costs
+  // ~16 cycles per wave instruction whatever its width, and 8-byte loads made this kernel bound by it).  The strip's
+  // slots are one contiguous region per column block; they are split into LB_DQ consecutive ranges, one wave each, two
+  // batches of 8 slots (16 loads) in flight per lane -- with one wave per strip the kernel had 8 MB of loads in flight
+  // on the whole chip and streamed the 53 MB of history at 3.6 TB/s; four waves per strip quadruple that.  The ranges'
+  // fp64 partial sums are added in range order by wave 0 (fixed order: deterministic).
   __shared__ double scy[LB_MAXH + 16], scs[LB_MAXH + 16];
   __shared__ int sslot[LB_MAXH + 16];
+  __shared__ double spart[LB_DQ][256];
   const int k = st->count, head = st->head;
-  for (int j = threadIdx.x; j < LB_MAXH + 16; j += 128) {
+  for (int j = threadIdx.x; j < LB_MAXH + 16; j += 64 * LB_DQ) {
     const bool on = j < k;
     const int sj = on ? (head + j) % cap : 0;
     sslot[j] = sj;
@@ -1069,14 +1074,15 @@ __global__ __launch_bounds__(128) void k_lb_direction(int n, int cap, int capL, 
     scs[j] = on ? st->cs[sj] : 0.0;
   }
   __syncthreads();
-  const int cb = blockIdx.x;
-  const int c = threadIdx.x * 4;       // four columns inside the block
-  const int i = cb * LB_CW + c;        // work vectors are padded to whole column blocks: 16-byte accesses in bounds
-  float mx = 0.f;
-  if (i < n) {
-    const float4 gv = *reinterpret_cast<const float4*>(g + i);
-    const double cg = st->cg;
-    double acc[4] = {cg * (double)gv.x, cg * (double)gv.y, cg * (double)gv.z, cg * (double)gv.w};
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int cb = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int c = half * 256 + lane * 4;   // four columns inside the column block
+  const int i = cb * LB_CW + c;          // work vectors are padded to whole column blocks: 16-byte accesses in bounds
+  // this wave's slots: batches of 8, nbq batches per range
+  const int nb = (k + 7) >> 3, nbq = (nb + LB_DQ - 1) / LB_DQ;
+  const int jlo = wave * nbq * 8, jhi = min(k, jlo + nbq * 8);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  {
     const float* Sb = S + (size_t)cb * LB_CBSTRIDE(capL) + c;
     const float* Yb = Y + (size_t)cb * LB_CBSTRIDE(capL) + c;
     float4 yv[2][8], sv[2][8];
@@ -1098,26 +1104,40 @@ __global__ __launch_bounds__(128) void k_lb_direction(int n, int cap, int capL, 
         acc[3] += cy * (double)yv[buf][u].w + cs * (double)sv[buf][u].w;
       }
     };
-    if (k > 0) issue(0, 0);
-    for (int j0 = 0; j0 < k; j0 += 16) {
-      if (j0 + 8 < k) issue(j0 + 8, 1);
+    if (jlo < jhi) issue(jlo, 0);
+    for (int j0 = jlo; j0 < jhi; j0 += 16) {
+      if (j0 + 8 < jhi) issue(j0 + 8, 1);
       consume(j0, 0);
-      if (j0 + 16 < k) issue(j0 + 16, 0);
-      if (j0 + 8 < k) consume(j0 + 8, 1);
-    }
-    const float dd[4] = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (i + e < n) {  // x may be the caller's tensor of exactly n floats: element-wise, guarded
-        d[i + e] = dd[e];
-        xt[i + e] = x[i + e] + t * dd[e];
-        mx = fmaxf(mx, fabsf(dd[e]));
-      }
+      if (j0 + 16 < jhi) issue(j0 + 16, 0);
+      if (j0 + 8 < jhi) consume(j0 + 8, 1);
     }
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(&st->dmax_bits, __float_as_uint(mx));
+  for (int e = 0; e < 4; ++e) spart[wave][lane * 4 + e] = acc[e];
+  __syncthreads();
+  float mx = 0.f;
+  if (wave == 0 && i < n) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    const double cg = st->cg;
+    const double g4[4] = {(double)gv.x, (double)gv.y, (double)gv.z, (double)gv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double v = cg * g4[e];
+#pragma unroll
+      for (int q = 0; q < LB_DQ; ++q) v += spart[q][lane * 4 + e];
+      const float dd = (float)v;
+      if (i + e < n) {  // x may be the caller's tensor of exactly n floats: element-wise, guarded
+        d[i + e] = dd;
+        xt[i + e] = x[i + e] + t * dd;
+        mx = fmaxf(mx, fabsf(dd));
+      }
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) atomicMax(&st->dmax_bits, __float_as_uint(mx));
+  }
 }
 
 // -------------------------------------------------------------------------------------------------- objectives
@@ -1422,7 +1442,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         else
           hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        hipLaunchKernelGGL(k_lb_direction, dim3(ncb), dim3(128), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
+        hipLaunchKernelGGL(k_lb_direction, dim3(2 * ncb), dim3(64 * LB_DQ), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
                            (float)t, xoth);
       }
       UUO_HIP_CHECK(hipGetLastError());
