@@ -155,13 +155,19 @@ typedef struct {
   float device_ms;          /* HIP-event time of the whole solve */
 } uuo_lbfgs_stats_t;
 
-/* optional per-closure callback (mirrors iter_fn / verbose prints): called on the host after each
- * closure evaluation with (user, evaluation index, loss). */
-typedef void (*uuo_eval_callback_t)(void* user, int eval_index, float loss);
+/* optional per-closure callback (mirrors iter_fn / verbose prints, optimization.py:259-272,378-391): called on
+ * the host, from the thread that called uuo_lbfgs_solve, after each closure evaluation with (user, evaluation
+ * index, loss, device pointer of the parameter vector that was evaluated -- valid, and ordered after the
+ * evaluation on the solve's stream, until the callback returns). */
+typedef void (*uuo_eval_callback_t)(void* user, int eval_index, float loss, const float* d_x_eval);
 
 int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
                     const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
                     void* cb_user);
+
+/* device -> host copy of n floats, ordered on `stream`, complete on return (for uuo_eval_callback_t users that only
+ * hold the raw pointer, e.g. the iter_fn adapter). */
+int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n);
 
 /* ---- benchmarking helpers (used by bench.py for the roofline object) -------------------------------
  * average device milliseconds per closure evaluation over `iters` back-to-back evaluations, measured with

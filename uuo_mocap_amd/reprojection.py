@@ -82,8 +82,6 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
     about the camera's vertical axis [1], the per-frame body translation [F,3] (HMR axes), one camera translation
     [3] and the shape [10] on  mean((kp - kp_hmr)^2 * mask) * w_reprojection + chamfer(markers -> vertices) * w_chamfer.
     Returns the reference's dictionary (leading hypothesis axis of size 1 kept)."""
-    if iter_fn is not None:
-        raise NotImplementedError("iter_fn is a visualisation hook, not built")
     device = markers.device
     F = pose_body.shape[0]
     w = config["stages"]["reprojection_part"]["losses"]
@@ -115,6 +113,7 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
                                   line_search_fn="strong_wolfe")
     eye = torch.eye(3, device=device).unsqueeze(0).expand(F, -1, -1)
     state = {}
+    n_eval = [0]
 
     def forward_terms():
         cam_tr = cam_single[:, None].expand(1, F, 3)
@@ -137,6 +136,12 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
         loss.backward()
         if verbose:
             print("Reprojection", float(loss))
+        if iter_fn is not None:  # hmr_utils.py:350-362
+            iter_fn(stage="reprojection", iteration=n_eval[0], pose_body=pose_body.detach().cpu().numpy(),
+                    betas=betas.detach().cpu().numpy(), trans=convert_hmr_pos_to_mocap_pos(body_t)[0].detach().cpu().numpy(),
+                    root_orient=(correction @ y_root)[0].detach().cpu().numpy(), pred_angle=yaw.item(), initial_angle=angle,
+                    pred_2d_joints=kp[0].detach().cpu().numpy(), gt_2d_joints=kp_target[0].detach().cpu().numpy())
+        n_eval[0] += 1
         return loss
 
     optimizer.step(closure)
