@@ -1076,3 +1076,43 @@ def test_save_iterations_records_every_closure_evaluation(smpl, dev):
     # the marker stage's accepted result is one of its recorded iterates
     final = rec["stages"]["marker_final"]["trans"]
     assert min(np.abs(v["trans"] - final).max() for v in it["marker_1"][0].values()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_recompute_marker_labels(smpl, dev):
+    """config.recompute_marker_labels (reference multimodal.py:529-539,632-642; False in the shipped configs): the
+    returned marker labels are the dominant joints of the vertices the final placement chose (smoothed over the rigid
+    clusters with segment.rigid_filter); with the 'full' granularity the fit itself does not depend on them."""
+    from uuo_mocap_amd.markers_utils import filter_rigid
+    from uuo_mocap_amd.multimodal import multimodal_video_mocap
+    from uuo_mocap_amd.optimization import compute_marker_labels_from_coords, compute_nearest_points
+
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = 10
+    cfg["num_root_orient_angles"] = 2
+    F, M = 9, 12
+    seq = make_sequence(smpl.tables, seed=9, num_frames=F, num_markers=M)
+    run = lambda c: multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, c, offset=0, print_options=[],
+                                           save_stages=True, smpl_inference=smpl)
+    base = run(cfg)
+    cfg_r = copy.deepcopy(cfg)
+    cfg_r["recompute_marker_labels"] = True
+    rec = run(cfg_r)
+    for k in ("trans", "pose_body", "root_orient", "betas"):
+        np.testing.assert_array_equal(base[k].numpy(), rec[k].numpy())
+    # labels = dominant joint of the vertex the final placement (computed from the pre-final-stage parameters) chose
+    pre = rec["stages"]["marker"]
+    t = lambda a: torch.from_numpy(np.asarray(a)).float().to(dev)
+    markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+    coords = compute_nearest_points(markers=markers, pose_body=t(pre["pose_body"]), betas=t(pre["betas"])[None],
+                                    root_orient=t(pre["root_orient"]), trans=t(pre["trans"]), smpl_inference=smpl,
+                                    marker_labels=None, granularity="full", img_mask=seq.img_smpl.img_mask.to(dev),
+                                    device=dev, config=cfg_r)
+    expect = compute_marker_labels_from_coords(smpl, coords, F).cpu().numpy()
+    np.testing.assert_array_equal(rec["markers_labels"], expect)
+    assert rec["markers_labels"].shape == (F, M) and not np.array_equal(rec["markers_labels"], base["markers_labels"])
+    cfg_f = copy.deepcopy(cfg_r)
+    cfg_f["stages"]["segment"]["rigid_filter"] = True
+    filt = run(cfg_f)
+    np.testing.assert_array_equal(filt["markers_labels"], filter_rigid(seq.markers.get_points(), expect))

@@ -72,6 +72,14 @@ def segment_rigid(points: np.ndarray) -> List[List[int]]:
     return [np.where(labels == v)[0].tolist() for v in np.unique(labels).tolist()]
 
 
+def filter_rigid(points: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    """Every rigid cluster of markers takes the median of its members' labels (reference markers_utils.py:220-241)."""
+    output = np.array(labels)
+    for group in segment_rigid(points):
+        output[:, group] = np.median(labels[:, group])
+    return output
+
+
 def get_sub_hierachies(parents, num_bones: int) -> List[List[int]]:
     """All connected sub-trees of the kinematic tree with exactly `num_bones` joints, enumerated in the reference's
     order (it decides which candidate wins ties).  Name keeps the reference's spelling.  The enumeration depends on

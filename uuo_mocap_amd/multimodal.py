@@ -231,12 +231,19 @@ def multimodal_video_mocap(
     run_chamfer = config["stages"]["chamfer"]["num_iters"] > 0
     run_marker = config["stages"]["marker"]["num_iters"] > 0
     root_orient_angles = torch.arange(0, 2 * np.pi, (2 * np.pi) / config["num_root_orient_angles"]).tolist()
-    if config["recompute_marker_labels"] and run_marker:
-        raise NotImplementedError("recompute_marker_labels is False in every shipped config")
+    recompute_labels = bool(config["recompute_marker_labels"]) and run_marker
+
+    def labels_from_placement(coords):
+        """config.recompute_marker_labels (reference :529-539,632-642): the markers' part labels become the dominant
+        joint of the vertex they were placed on, optionally smoothed over the rigid clusters."""
+        labels = compute_marker_labels_from_coords(smpl_inference, coords, num_frames).detach().cpu().numpy()
+        if config["stages"]["segment"]["rigid_filter"]:
+            labels = markers_utils.filter_rigid(markers.detach().cpu().numpy(), labels)
+        return labels
 
     group = workspace_group()  # worker threads do not inherit thread-locals
 
-    def fit_hypothesis(index: int, root_orient_angle: float, stream):
+    def fit_hypothesis(index: int, root_orient_angle: float, stream, marker_labels=marker_labels):
         """One yaw hypothesis (reference multimodal.py:463-574): chamfer L-BFGS -> placement -> marker L-BFGS.
         Hypotheses are independent, so each runs on its own host thread, HIP stream and solver workspace."""
         set_workspace_group(group)
@@ -271,6 +278,8 @@ def multimodal_video_mocap(
                     granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
                     config=config, o_pose_body=o_pose_body, window_size=1,
                     use_velocity=config["stages"]["compute_locations"]["use_velocity"])
+                if recompute_labels:
+                    local["marker_labels"] = labels_from_placement(one_hot)
                 if "progress" in print_options:
                     print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(1, config["stage_repeats"]))
                 z_root = z_root.clone().detach().requires_grad_(True)
@@ -291,6 +300,10 @@ def multimodal_video_mocap(
         return local
 
     n_threads = min(len(root_orient_angles), int(os.environ.get("UUO_HYPOTHESIS_THREADS", "4")))
+    if recompute_labels and config["stages"]["segment"]["granularity"] == "part":
+        # the reference's hypotheses run one after the other and each placement reads the labels the previous one
+        # recomputed (only the "part" granularity looks at them): keep that order
+        n_threads = 1
     if n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
         streams = [torch.cuda.Stream(device=device) for _ in root_orient_angles]
@@ -302,7 +315,12 @@ def multimodal_video_mocap(
         for st_ in streams:
             main_stream.wait_stream(st_)
     else:
-        results = [fit_hypothesis(0, a, None) for a in root_orient_angles]
+        results = []
+        for a in root_orient_angles:
+            results.append(fit_hypothesis(0, a, None, marker_labels))
+            marker_labels = results[-1].get("marker_labels", marker_labels)
+    if recompute_labels and results:
+        marker_labels = results[-1].get("marker_labels", marker_labels)  # the last hypothesis' labels survive the loop
     set_workspace_slot(0)
     mark("hypotheses")
     for root_orient_angle, local in zip(root_orient_angles, results):
@@ -354,8 +372,8 @@ def multimodal_video_mocap(
                 granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
                 config=config, o_pose_body=pose_body_stage, window_size=1,
                 use_velocity=config["stages"]["compute_locations"]["use_velocity"])
-            if config["recompute_marker_labels"]:
-                marker_labels = compute_marker_labels_from_coords(smpl_inference, one_hot, num_frames).cpu().numpy()
+            if recompute_labels:
+                marker_labels = labels_from_placement(one_hot)
             if "progress" in print_options:
                 print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(stage_i + 1,
                                                                                       config["stage_repeats"]))
