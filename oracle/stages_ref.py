@@ -97,33 +97,57 @@ def _smpl_repeat_betas(smpl_inference, poses, betas, root_orient, trans):
 # chamfer stage
 # ----------------------------------------------------------------------------------------------
 
+def chamfer_distance_by_part(markers, vertices, marker_labels, vertex_weights, single_directional: bool = False):
+    """optimization.py:682-700."""
+    vertex_mask = torch.argmax(vertex_weights, dim=-1)
+    labels_mode = torch.mode(marker_labels, dim=0)[0]
+    loss = 0
+    for i in torch.unique(labels_mode).tolist():
+        part = chamfer_distance(vertices[:, vertex_mask == i], markers[:, labels_mode == i],
+                                single_directional=single_directional)[0]
+        loss = loss + (part - MARKER_DISTANCE) ** 2
+    return loss
+
+
 def chamfer_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, z_angle,
-                       smpl_inference, config):
-    """One forward of closure_stage_chamfer (optimization.py:187-256) for the shipped loss keys."""
+                       smpl_inference, config, marker_labels=None):
+    """One forward of closure_stage_chamfer (optimization.py:187-256): the shipped terms and the optional
+    part_chamfer (:227-235), trans_vel (:245-249), ground (:250-253) ones, yaw_lock True or False (:190-193)."""
     st = config["stages"]["chamfer"]
-    if not st["yaw_lock"]:
-        raise NotImplementedError("yaw_lock False is not a shipped configuration")
-    z_root = compute_root_orient_z(z_angle) @ root_orient
+    w = st["losses"]
+    z_root = compute_root_orient_z(z_angle) @ root_orient if st["yaw_lock"] else normalize_rot(z_angle)
     out = _smpl_repeat_betas(smpl_inference, normalize_rot(pose_body), betas, normalize_rot(z_root), trans)
     loss = 0
-    unsupported = set(st["losses"]) - {"full_chamfer", "reg_pose_body", "reg_betas"}
+    unsupported = set(w) - {"full_chamfer", "reg_pose_body", "reg_betas", "part_chamfer", "trans_vel", "ground"}
     if unsupported:
-        raise NotImplementedError("chamfer-stage losses outside the shipped configs: %s" % sorted(unsupported))
-    if "full_chamfer" in st["losses"]:
+        raise NotImplementedError("chamfer-stage losses that cannot run in the reference: %s" % sorted(unsupported))
+    if "part_chamfer" in w:
+        loss = loss + chamfer_distance_by_part(markers, out["vertices"], marker_labels, smpl_inference.smpl.lbs_weights,
+                                               single_directional=st["single_directional"]) * w["part_chamfer"]
+    if "full_chamfer" in w:
         c = weighted_chamfer_distance(markers, out["vertices"], get_marker_mask(markers),
                                       single_directional=st["single_directional"])[0]
-        loss = loss + c * st["losses"]["full_chamfer"]
-    if "reg_pose_body" in st["losses"]:
-        loss = loss + F.mse_loss(pose_body, o_pose_body) * st["losses"]["reg_pose_body"]
-    if "reg_betas" in st["losses"]:
-        loss = loss + F.mse_loss(betas, o_betas) * st["losses"]["reg_betas"]
+        loss = loss + c * w["full_chamfer"]
+    if "reg_pose_body" in w:
+        loss = loss + F.mse_loss(pose_body, o_pose_body) * w["reg_pose_body"]
+    if "trans_vel" in w:
+        markers_mean = torch.mean(markers, dim=1)
+        loss = loss + F.mse_loss(trans[1:] - trans[:-1], markers_mean[1:] - markers_mean[:-1]) * w["trans_vel"]
+    if "ground" in w:
+        loss = loss + torch.mean(F.relu(-out["joints"][..., 2])) * w["ground"]
+    if "reg_betas" in w:
+        loss = loss + F.mse_loss(betas, o_betas) * w["reg_betas"]
     return loss, out
 
 
 def optim_chamfer(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, smpl_inference, config,
-                  trace: Optional[list] = None):
+                  trace: Optional[list] = None, marker_labels=None):
     """optimization.py:147-285. Mutates trans/betas/pose_body (L-BFGS) and root_orient (in place)."""
-    z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
+    if config["stages"]["chamfer"]["yaw_lock"]:
+        z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
+    else:
+        z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 3, 3), device=root_orient.device)
+        z_angle[..., 0, 0] = z_angle[..., 1, 1] = z_angle[..., 2, 2] = 1.0
     z_angle.requires_grad_(True)
     params = [trans, z_angle, betas, pose_body]
     opt = _lbfgs(params, config["stages"]["chamfer"]["num_iters"], config, lr=0.1)
@@ -132,7 +156,7 @@ def optim_chamfer(markers, pose_body, o_pose_body, betas, o_betas, root_orient, 
     def closure():
         opt.zero_grad()
         loss, _ = chamfer_stage_loss(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
-                                     z_angle, smpl_inference, config)
+                                     z_angle, smpl_inference, config, marker_labels=marker_labels)
         loss.backward()
         if trace is not None:
             trace.append(float(loss))
@@ -140,7 +164,10 @@ def optim_chamfer(markers, pose_body, o_pose_body, betas, o_betas, root_orient, 
 
     opt.step(closure)
     with torch.no_grad():
-        root_orient[:] = compute_root_orient_z(z_angle) @ root_orient
+        if config["stages"]["chamfer"]["yaw_lock"]:
+            root_orient[:] = compute_root_orient_z(z_angle) @ root_orient
+        else:
+            root_orient[:] = normalize_rot(z_angle) @ root_orient
     root_orient.requires_grad_(True)
     return z_angle.detach()
 

@@ -311,3 +311,30 @@ def test_frame_rate_resampling_matches_reference(golden, oracle_smpl):
     np.testing.assert_allclose(out["root_orient"].numpy(), g["out_root_orient"], atol=2e-4)
     np.testing.assert_allclose(out["betas"].numpy(), g["out_betas"], atol=2e-4)
     np.testing.assert_array_equal([len(e) for e in stats["part"]["evals"]], g["n_evals"])
+
+
+def _chamfer_options_cfg(g, tag):
+    cfg = _cfg("video_mocap", 25, int(g["num_iters"]), 25)
+    if tag == "terms":
+        cfg["stages"]["chamfer"]["losses"].update({str(k): float(v) for k, v in zip(g["extra_names"], g["extra_weights"])})
+    else:
+        cfg["stages"]["chamfer"]["yaw_lock"] = False
+    return cfg
+
+
+@pytest.mark.parametrize("tag", ["terms", "free"])
+def test_chamfer_stage_options_match_reference(golden, oracle_smpl, tag):
+    """Chamfer stage with part_chamfer + trans_vel + ground ("terms") and with yaw_lock False ("free"): the oracle
+    against the fixture captured from the reference's own optim_chamfer (first gradient, the first 40 evaluations of
+    the loss trajectory, the converged loss)."""
+    g = golden("chamfer_stage_options.npz")
+    cfg = _chamfer_options_cfg(g, tag)
+    cfg["stages"]["chamfer"]["num_iters"] = 30  # enough for 40 evaluations; the full solves take minutes on the CPU
+    leaves = [_t(g[k]).clone().requires_grad_(True) for k in ("o_pose_body", "o_betas", "o_root_orient", "trans0")]
+    pose, betas, root, trans = leaves
+    trace = []
+    stages_ref.optim_chamfer(_t(g["markers"]), pose, _t(g["o_pose_body"]), betas, _t(g["o_betas"]), root, trans,
+                             oracle_smpl, cfg, trace=trace, marker_labels=torch.from_numpy(g["labels"]))
+    ref = g[tag + "_losses"]
+    n = min(len(trace), 30)
+    np.testing.assert_allclose(trace[:n], ref[:n], rtol=2e-4)

@@ -262,7 +262,8 @@ def multimodal_video_mocap(
                 print("Stage [pose]: optimizing poses and shapes...")
             if run_chamfer:
                 optim_chamfer(markers, pose_body=pose_angle, o_pose_body=o_pose_body, betas=betas_angle,
-                              o_betas=o_betas, root_orient=z_root, trans=trans_angle, marker_labels=None,
+                              o_betas=o_betas, root_orient=z_root, trans=trans_angle,
+                              marker_labels=torch.from_numpy(np.asarray(marker_labels)).to(device),
                               img_mask=img_mask, smpl_inference=smpl_inference, initial_angle=root_orient_angle,
                               repeat=0, config=config, verbose=verbose, iter_fn=save_iter_fn)
                 local["chamfer_stats"] = optimization.last_stats("chamfer")

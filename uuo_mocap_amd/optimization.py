@@ -56,6 +56,10 @@ def optim_chamfer(
 ):
     """Chamfer (pose fitting) stage: L-BFGS over [trans, z_angle, betas, pose_body], lr 0.1.  Mutates
     trans / betas / pose_body in place and applies the optimised yaw to root_orient in place."""
+    st = config["stages"]["chamfer"]
+    if (set(st["losses"]) - _CHAMFER_FUSED_LOSSES) or not st["yaw_lock"]:
+        return _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, marker_labels,
+                                      smpl_inference, config, initial_angle, repeat, verbose, iter_fn)
     prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, root_orient, config)
     z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
     x = prob.pack(trans, z_angle, betas, pose_body)
@@ -81,6 +85,88 @@ def optim_chamfer(
         root_orient.requires_grad_(False)
         root_orient[:] = compute_root_orient_z(new_z) @ root_orient
     root_orient.requires_grad_(True)
+    LAST_STATS["chamfer"] = stats
+    _tls_stats.chamfer = stats
+    return None
+
+
+#: chamfer-stage loss terms the device solver fuses (the only ones the shipped configs enable)
+_CHAMFER_FUSED_LOSSES = {"full_chamfer", "reg_pose_body", "reg_betas"}
+
+
+def _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, marker_labels,
+                           smpl_inference, config, initial_angle, repeat, verbose, iter_fn):
+    """Chamfer stage with the reference's optional terms (`part_chamfer`, `trans_vel`, `ground`) and / or
+    `yaw_lock: False` (reference optimization.py:164-285; none is in a shipped config): the closure is composed from the
+    differentiable HIP operators and driven by torch.optim.LBFGS with the reference's parameter list
+    [trans, z_angle, betas, pose_body], lr 0.1.  `root_orient_vel` stops in a debugger in the reference (:241) and is
+    refused.  Same in-place semantics as the fused path."""
+    st = config["stages"]["chamfer"]
+    w = st["losses"]
+    unknown = set(w) - _CHAMFER_FUSED_LOSSES - {"part_chamfer", "trans_vel", "ground"}
+    if unknown:
+        raise NotImplementedError("chamfer-stage losses that cannot run in the reference: %s" % sorted(unknown))
+    device = root_orient.device
+    num_frames = pose_body.shape[0]
+    root_fixed = root_orient.detach().clone()
+    if st["yaw_lock"]:
+        z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=device).requires_grad_(True)
+    else:  # a free rotation that REPLACES the root orientation inside the closure and multiplies it afterwards (:167-172,196,282)
+        z_angle = torch.eye(3, device=device).expand(root_orient.shape[0], root_orient.shape[1], 3, 3).clone().requires_grad_(True)
+    p_trans, p_betas, p_pose = (t.detach().clone().requires_grad_(True) for t in (trans, betas, pose_body))
+    params = [p_trans, z_angle, p_betas, p_pose]
+    optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                  tolerance_change=config["optimizer"]["tolerance_change"], lr=0.1,
+                                  line_search_fn="strong_wolfe")
+    mask = get_marker_mask(markers)
+    lbs_weights = smpl_inference.get_lbs_weights()
+    n_eval = [0]
+    trace = []
+
+    def z_root():
+        return compute_root_orient_z(z_angle) @ root_fixed if st["yaw_lock"] else normalize_rot(z_angle)
+
+    def closure():
+        optimizer.zero_grad()
+        out = smpl_inference(poses=normalize_rot(p_pose), betas=torch.repeat_interleave(p_betas, dim=0, repeats=num_frames),
+                             root_orient=normalize_rot(z_root()), trans=p_trans)
+        loss = 0
+        if "part_chamfer" in w:
+            loss = loss + chamfer_distance_by_part(markers, out["vertices"], marker_labels, lbs_weights,
+                                                   single_directional=st["single_directional"]) * w["part_chamfer"]
+        if "full_chamfer" in w:
+            loss = loss + weighted_chamfer_distance(x=markers, y=out["vertices"], x_weights=mask,
+                                                    single_directional=st["single_directional"])[0] * w["full_chamfer"]
+        if "reg_pose_body" in w:
+            loss = loss + F.mse_loss(p_pose, o_pose_body) * w["reg_pose_body"]
+        if "trans_vel" in w:
+            markers_mean = torch.mean(markers, dim=1)
+            loss = loss + F.mse_loss(p_trans[1:] - p_trans[:-1], markers_mean[1:] - markers_mean[:-1]) * w["trans_vel"]
+        if "ground" in w:
+            loss = loss + torch.mean(F.relu(-out["joints"][..., 2])) * w["ground"]
+        if "reg_betas" in w:
+            loss = loss + F.mse_loss(p_betas, o_betas) * w["reg_betas"]
+        loss.backward()
+        if verbose:
+            print("Chamfer", n_eval[0], float(loss))
+        if iter_fn is not None:
+            iter_fn(stage="chamfer_" + str(repeat), iteration=n_eval[0], initial_angle=np.array([initial_angle]),
+                    pose_body=normalize_rot(p_pose).detach().cpu().numpy(), betas=p_betas.detach().cpu().numpy(),
+                    trans=p_trans.detach().cpu().numpy(), root_orient=normalize_rot(root_fixed).cpu().numpy())
+        n_eval[0] += 1
+        trace.append(loss.detach())
+        return loss
+
+    optimizer.step(closure)
+    with torch.no_grad():
+        trans.copy_(p_trans)
+        betas.copy_(p_betas)
+        pose_body.copy_(p_pose)
+        root_orient.requires_grad_(False)
+        root_orient[:] = (compute_root_orient_z(z_angle) if st["yaw_lock"] else normalize_rot(z_angle)) @ root_fixed
+    root_orient.requires_grad_(True)
+    stats = {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)), "device_ms": 0.0,
+             "driver": "torch.optim.LBFGS", "loss_first": float(trace[0]), "loss_final": float(min(trace))}
     LAST_STATS["chamfer"] = stats
     _tls_stats.chamfer = stats
     return None
