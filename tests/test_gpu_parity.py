@@ -1167,3 +1167,36 @@ def test_chamfer_stage_options_match_reference(smpl, golden, dev, tag):
     assert np.median(np.abs(trans.detach().cpu().numpy() - g[tag + "_out_trans"])) < 2e-2
     det = torch.linalg.det(root.detach())
     assert float((det - 1).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_mesh_closest_points_full_size_properties(smpl, dev):
+    """uuo_mesh_closest_points at the BASELINE size (F=300, M=50, 13 776 faces), where the float64 oracle would take
+    minutes: the result must (a) be no farther than the nearest mesh vertex and no nearer than zero, (b) lie on the
+    reported face (barycentric coordinates in [0,1] summing to 1 and reconstructing the point), (c) be exactly the
+    distance between marker and reported point, (d) not change when the faces are presented in reverse order
+    (distance only: ties may pick another face), (e) be identical run to run."""
+    F, M = 300, 50
+    seq = make_sequence(smpl.tables, seed=2, num_frames=F, num_markers=M)
+    gt = seq.gt
+    verts = torch.from_numpy(np.asarray(gt["verts"])).float().to(dev)
+    markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+    faces = torch.from_numpy(np.asarray(smpl.smpl.faces).astype(np.int64)).to(dev)
+    used = torch.unique(faces)
+    dist, face, closest, bary = smpl.device_model.mesh_closest_points(verts, faces, markers)
+    d_vertex = torch.cat([(markers[a:a + 20, :, None] - verts[a:a + 20, None][:, :, used]).norm(dim=-1).min(-1)[0]
+                          for a in range(0, F, 20)])
+    assert bool((dist <= d_vertex * (1 + 1e-5) + 1e-6).all()) and bool((dist >= 0).all())
+    assert bool((face >= 0).all()) and bool((face < faces.shape[0]).all())
+    tri = verts[torch.arange(F, device=dev)[:, None, None], faces[face.long()]]          # [F, M, 3, 3]
+    np.testing.assert_allclose((bary[..., None] * tri).sum(2).cpu().numpy(), closest.cpu().numpy(), atol=2e-5)
+    assert float(bary.min()) > -1e-3 and float((bary.sum(-1) - 1).abs().max()) < 1e-4
+    np.testing.assert_allclose((markers - closest).norm(dim=-1).cpu().numpy(), dist.cpu().numpy(), atol=1e-6)
+    dist_r = smpl.device_model.mesh_closest_points(verts, faces.flip(0), markers)[0]
+    np.testing.assert_allclose(dist_r.cpu().numpy(), dist.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    again = smpl.device_model.mesh_closest_points(verts, faces, markers)
+    for a, b in zip((dist, face, closest, bary), again):
+        assert torch.equal(a, b)
+    # markers sit 9.5 mm off their vertex: the surface cannot be farther than that (plus the 1 mm noise)
+    present = markers.abs().sum(-1) != 0
+    assert float(dist[present].max()) < 0.0095 + 0.006
