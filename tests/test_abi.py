@@ -189,3 +189,37 @@ def test_evaluation_metrics_match_reference():
     }
     for k, v in got.items():
         np.testing.assert_allclose(v.numpy(), g["out_" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_dropin_package_exposes_the_reference_module_paths():
+    """uuo_mocap_amd/dropin on PYTHONPATH presents the reference's module paths -- import only, no GPU."""
+    import importlib
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uuo_mocap_amd", "dropin")
+    saved = {k: v for k, v in sys.modules.items() if k == "video_mocap" or k.startswith("video_mocap.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, root)
+    try:
+        expect = {
+            "video_mocap.utils.smpl": ["SmplInference"],
+            "video_mocap.losses.chamfer_distance": ["weighted_chamfer_distance"],
+            "video_mocap.losses.losses": ["MarkerLoss"],
+            "video_mocap.optimization": ["optim_chamfer", "optim_markers", "compute_nearest_points",
+                                         "compute_marker_labels_from_coords", "compute_root_orient_z",
+                                         "chamfer_distance_by_part", "get_marker_mask", "weighted_mse_loss"],
+            "video_mocap.markers.markers_utils": ["find_best_part_fits", "segment_rigid", "filter_rigid"],
+            "video_mocap.multimodal": ["multimodal_video_mocap", "pad"],
+            "video_mocap.utils.hmr_utils": ["optim_reprojection", "perspective_projection", "get_3d_parameters"],
+            "video_mocap.evaluation.metrics": ["compute_marker_to_surface_distance", "compute_PA_MPJPE", "compute_V2V"],
+        }
+        for mod, names in expect.items():
+            m = importlib.import_module(mod)
+            for n in names:
+                assert hasattr(m, n), (mod, n)
+    finally:
+        sys.path.remove(root)
+        for k in [k for k in sys.modules if k == "video_mocap" or k.startswith("video_mocap.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
