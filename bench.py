@@ -177,7 +177,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal on a box with fewer GPUs than ranks (UUO_BENCH_SHARE_GPU=1): ranks share the devices and rendezvous
+        # over gloo -- RCCL refuses two ranks on one device; the timed path is the same
+        share = os.environ.get("UUO_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the fitted path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -225,7 +232,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
