@@ -155,7 +155,10 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
 #define CULL_MAXU 512
 #define CULL_UB 4
 #define CULL_MAXG 8
-__global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int mper, const float* __restrict__ x,
+#ifndef CULL_T
+#define CULL_T 256  // threads per block (128: 7 us slower alone and 2 % slower fits; 512: no faster)
+#endif
+__global__ __launch_bounds__(CULL_T) void k_nn_cull(int M, int V, int nunits, int mper, const float* __restrict__ x,
                                                   const float* __restrict__ verts, const float* __restrict__ bbox,
                                                   unsigned long long* __restrict__ packed, int* __restrict__ stats) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int m
   const float* vf = verts + (size_t)f * V * 3;
   {  // unit bounding boxes of this frame (written by k_skin's epilogue) -> LDS
     const float* bf = bbox + (size_t)f * nunits * 6;
-    for (int i = tid; i < nunits * 6; i += 256) sbox[i] = bf[i];
+    for (int i = tid; i < nunits * 6; i += CULL_T) sbox[i] = bf[i];
   }
   if (tid < mg) {
     const float* px = x + ((size_t)f * M + m0 + tid) * 3;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int m
   __syncthreads();
   // ---- phase A: thread = unit (box in registers); the marker loop only sets bits of a survivor mask (no branch,
   // no atomic on the loop path), then one LDS atomicAdd per thread reserves the list slots
-  for (int u = tid; u < nunits; u += 256) {
+  for (int u = tid; u < nunits; u += CULL_T) {
     const float* b = sbox + u * 6;
     const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
     unsigned long long mask = 0ull;
@@ -221,14 +224,14 @@ __global__ __launch_bounds__(256) void k_nn_cull(int M, int V, int nunits, int m
   const int nent = overflow ? nunits * mg : found;
   // ---- phase B: 16 lanes per (marker, unit) pair, 4 pairs per wave pass, CULL_UB passes in flight
   // (the vertex gathers are L2 round trips: issue them for several passes before the first is consumed)
-  for (int e0 = wave * 4; e0 < nent; e0 += 16 * CULL_UB) {
+  for (int e0 = wave * 4 * CULL_UB; e0 < nent; e0 += (CULL_T / 64) * 4 * CULL_UB) {
     unsigned long long key[CULL_UB];
     int mm[CULL_UB];
     float vx[CULL_UB], vy[CULL_UB], vz[CULL_UB];
     int vid[CULL_UB];
 #pragma unroll
     for (int r = 0; r < CULL_UB; ++r) {
-      const int e = e0 + 16 * r + (lane >> 4);
+      const int e = e0 + 4 * r + (lane >> 4);
       mm[r] = 0;
       vid[r] = -1;
       vx[r] = vy[r] = vz[r] = 0.f;
@@ -280,7 +283,7 @@ int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const flo
   while (G < CULL_MAXG && (long)F * G < 1024 && (M + G) / (G + 1) >= 8) ++G;
   const int mper = (M + G - 1) / G;
   UUO_REQUIRE(mper <= CULL_MG && G <= CULL_MAXG, "uuo_launch_nn_cull: too many markers per frame for the pruned search");
-  hipLaunchKernelGGL(k_nn_cull, dim3(F, G), dim3(256), 0, s, M, V, nunits, mper, markers, verts, bbox, packed, stats);
+  hipLaunchKernelGGL(k_nn_cull, dim3(F, G), dim3(CULL_T), 0, s, M, V, nunits, mper, markers, verts, bbox, packed, stats);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
