@@ -255,6 +255,21 @@ def main():
             "frame_evals_per_s": world * total_evals * F / elapsed if world == 1 else None,
             "roofline": roofline,
         }
+        if world == 1 and args.config == "video_mocap" and not args.roofline_only:
+            # BASELINE configs[1] (hmr_full.yaml) on the same sequences, reported beside the headline: it disables the
+            # chamfer and marker stages, so it times the part stage only and is not the metric's workload
+            cfg_hf = packaged_config("hmr_full")
+            with contextlib.redirect_stdout(io.StringIO()):
+                fit_once(smpl, seqs[0], cfg_hf, dev)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                hf_stats = [fit_once(smpl, sq, cfg_hf, dev)[1] for sq in seqs[args.warmup:n_seq]]
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t1
+            result["other_configs"] = {"hmr_full": {
+                "value": args.steps * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps,
+                "closure_evals_per_step": sum(sum(eval_counts(s_).values()) for s_ in hf_stats) / max(args.steps, 1),
+                "note": "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"}}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals)
             if result["cpu_baseline"]["value"]:
