@@ -1200,3 +1200,36 @@ def test_mesh_closest_points_full_size_properties(smpl, dev):
     # markers sit 9.5 mm off their vertex: the surface cannot be farther than that (plus the 1 mm noise)
     present = markers.abs().sum(-1) != 0
     assert float(dist[present].max()) < 0.0095 + 0.006
+
+
+@pytest.mark.gpu
+def test_adam_driver_extension(smpl, golden, dev):
+    """EXTENSION (not in the reference): `optimizer.type: adam` drives the fused HIP closures with torch.optim.Adam on
+    the flat parameter vector.  The update must equal a hand-rolled Adam on the closure's own gradients, reduce the
+    loss, and leave the default (L-BFGS) path untouched when the key is absent."""
+    from uuo_mocap_amd.engine import ChamferProblem
+    from uuo_mocap_amd.optimization import last_stats, optim_chamfer
+
+    g = golden("chamfer_stage.npz")
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).float().to(dev)
+    cfg = packaged_config("video_mocap")
+    prob = ChamferProblem(smpl, t("markers"), t("hmr_pose_body"), t("o_betas"), t("hmr_root_orient"), cfg)
+    x0 = prob.pack(t("trans0"), torch.zeros(8, 1, 1, device=dev), t("o_betas"), t("hmr_pose_body"))
+    x = x0.clone()
+    st = prob.solve_adam(x, num_steps=5, lr=1e-3)
+    # hand-rolled Adam (Kingma & Ba, bias-corrected) on the same closure
+    y, m, v = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
+    for i in range(1, 6):
+        _, grad, _ = prob.evaluate(y, want_nn=False)
+        m = 0.9 * m + 0.1 * grad
+        v = 0.999 * v + 0.001 * grad * grad
+        y = y - 1e-3 * (m / (1 - 0.9 ** i)) / ((v / (1 - 0.999 ** i)).sqrt() + 1e-8)
+    np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert st["driver"] == "adam" and st["final_loss"] < st["first_loss"]
+    cfg["optimizer"].update(type="adam", adam_steps=40, adam_lr=2e-3)
+    leaves = [t(k).clone().requires_grad_(True) for k in ("hmr_pose_body", "o_betas", "hmr_root_orient", "trans0")]
+    optim_chamfer(t("markers"), pose_body=leaves[0], o_pose_body=t("hmr_pose_body"), betas=leaves[1], o_betas=t("o_betas"),
+                  root_orient=leaves[2], trans=leaves[3], img_mask=t("img_mask"), marker_labels=None, smpl_inference=smpl,
+                  config=cfg)
+    s2 = last_stats("chamfer")
+    assert s2["driver"] == "adam" and s2["n_eval"] == 40 and s2["final_loss"] < float(g["losses"][0])

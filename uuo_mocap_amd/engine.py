@@ -287,6 +287,33 @@ class _StageProblem:
                 "final_loss": stats.final_loss, "stop_reason": STOP_REASONS[stats.stop_reason],
                 "device_ms": stats.device_ms}
 
+    def solve_adam(self, x: torch.Tensor, num_steps: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                   callback: Optional[Callable[[int, float], None]] = None) -> Dict:
+        """EXTENSION, not reference behaviour (the reference only drives its closures with L-BFGS; BASELINE's north star
+        also names Adam): `num_steps` steps of torch.optim.Adam on the flat parameter vector, every gradient from the
+        fused HIP closure (uuo_closure_eval), the update itself a handful of element-wise device ops; x updated in place.
+        No host synchronisation inside the loop unless a callback asks for the loss."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        p = x.detach().requires_grad_(True)
+        opt = torch.optim.Adam([p], lr=lr, betas=betas, eps=eps)
+        loss = torch.empty((1,), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.n,), dtype=torch.float32, device=self.device)
+        first = last = None
+        stream = current_stream(self.device)
+        for i in range(int(num_steps)):
+            with torch.cuda.device(self.device):
+                check(self.lib.uuo_closure_eval(self.fit, stream, byref(self.problem), _ptr(p), _ptr(loss), _ptr(grad),
+                                                None), "uuo_closure_eval")
+            if callback is not None or i == 0 or i == num_steps - 1:
+                last = float(loss.item())
+                first = last if first is None else first
+                if callback is not None:
+                    callback(i, last)
+            p.grad = grad
+            opt.step()
+        return {"n_iter": int(num_steps), "n_eval": int(num_steps), "first_loss": first, "final_loss": last,
+                "stop_reason": "num_steps", "device_ms": 0.0, "driver": "adam"}
+
     def time_closure(self, x: torch.Tensor, iters: int = 20, dominant_only: bool = False) -> float:
         ms = c_float(0.0)
         with torch.cuda.device(self.device):

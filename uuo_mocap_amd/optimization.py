@@ -73,10 +73,7 @@ def optim_chamfer(
                     pose_body=normalize_rot(e_pose).numpy(), betas=e_betas.numpy().copy(), trans=e_trans.numpy().copy(),
                     root_orient=root_np)
 
-    stats = prob.solve(
-        x, max_iter=config["stages"]["chamfer"]["num_iters"], lr=0.1,
-        tolerance_grad=config["optimizer"]["tolerance_grad"], tolerance_change=config["optimizer"]["tolerance_change"],
-        callback=_printer("Chamfer", verbose), point_callback=point_cb)
+    stats = _solve(prob, x, config, "chamfer", 0.1, "Chamfer", verbose, point_cb)
     new_trans, new_z, new_betas, new_pose = prob.unpack(x)
     with torch.no_grad():
         trans.copy_(new_trans)
@@ -88,6 +85,24 @@ def optim_chamfer(
     LAST_STATS["chamfer"] = stats
     _tls_stats.chamfer = stats
     return None
+
+
+def _solve(prob, x, config, stage: str, lr: float, verbose_tag: str, verbose: bool, point_cb):
+    """L-BFGS (the reference's only driver) unless the config carries the EXTENSION key `optimizer.type: adam`
+    (BASELINE's north star names Adam; the reference has no such option): then `optimizer.adam_steps` (default: the
+    stage's num_iters) Adam steps of `optimizer.adam_lr` (default: the stage's L-BFGS lr / 100) on the same fused closure."""
+    opt = config["optimizer"]
+    kind = str(opt.get("type", "lbfgs")).lower()
+    if kind == "lbfgs":
+        return prob.solve(x, max_iter=config["stages"][stage]["num_iters"], lr=lr, tolerance_grad=opt["tolerance_grad"],
+                          tolerance_change=opt["tolerance_change"], callback=_printer(verbose_tag, verbose),
+                          point_callback=point_cb)
+    if kind != "adam":
+        raise ValueError("optimizer.type must be 'lbfgs' or 'adam' (got %r)" % kind)
+    if point_cb is not None:
+        raise NotImplementedError("iter_fn is reported by the L-BFGS driver only")
+    return prob.solve_adam(x, num_steps=int(opt.get("adam_steps", config["stages"][stage]["num_iters"])),
+                           lr=float(opt.get("adam_lr", lr / 100.0)), callback=_printer(verbose_tag, verbose))
 
 
 #: chamfer-stage loss terms the device solver fuses (the only ones the shipped configs enable)
@@ -210,10 +225,7 @@ def optim_markers(
                     pose_body=normalize_rot(e_pose).numpy(), betas=e_betas.numpy().copy(), trans=e_trans.numpy().copy(),
                     root_orient=normalize_rot(e_root).numpy())
 
-    stats = prob.solve(
-        x, max_iter=config["stages"]["marker"]["num_iters"], lr=1.0,
-        tolerance_grad=config["optimizer"]["tolerance_grad"], tolerance_change=config["optimizer"]["tolerance_change"],
-        callback=_printer("Marker", verbose), point_callback=point_cb)
+    stats = _solve(prob, x, config, "marker", 1.0, "Marker", verbose, point_cb)
     new_pose, new_betas, new_root, new_trans = prob.unpack(x)
     with torch.no_grad():
         pose_body.copy_(new_pose)
