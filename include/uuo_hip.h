@@ -83,6 +83,18 @@ int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d_x, const f
 int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const float* d_verts, const float* d_markers,
                            const uint8_t* d_valid, int32_t* d_idx, void* d_workspace_u64);
 
+/* ---- EXTENSION: soft-assignment (soft-min) nearest neighbour ----------------------------------------
+ * Not reference behaviour (the reference's chamfer term is the hard K=1 minimum above; BASELINE's north star names a
+ * soft assignment).  softmin[n,i] = -tau log sum_j exp(-|x[n,i]-y[n,j]|^2 / tau); d_dmin / d_sumexp ([N,P1]) are the
+ * exact minimum and the normaliser sum_j exp((dmin - d2)/tau), kept for the backward.  Backward: gradients of
+ * sum_i grad_softmin[n,i] softmin[n,i] with respect to x (d_gx [N,P1,3]) and y (d_gy [N,P2,3]); either may be NULL.
+ * d_ws: N*P1 uint64. */
+int uuo_soft_nn_forward(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y, float tau,
+                        float* d_softmin, float* d_dmin, float* d_sumexp, void* d_ws);
+int uuo_soft_nn_backward(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y, float tau,
+                         const float* d_dmin, const float* d_sumexp, const float* d_grad_softmin, float* d_gx,
+                         float* d_gy);
+
 /* ---- barycentric marker placement ------------------------------------------------------------------
  * Replaces igl.signed_distance + trimesh.triangles.points_to_barycentric in compute_nearest_points with
  * compute_locations.use_barycentric (src/video_mocap/optimization.py:494-500,519-523): for every query

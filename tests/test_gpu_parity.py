@@ -1233,3 +1233,44 @@ def test_adam_driver_extension(smpl, golden, dev):
                   config=cfg)
     s2 = last_stats("chamfer")
     assert s2["driver"] == "adam" and s2["n_eval"] == 40 and s2["final_loss"] < float(g["losses"][0])
+
+
+@pytest.mark.gpu
+def test_soft_assignment_chamfer_extension(smpl, golden, dev):
+    """EXTENSION (not in the reference): soft-min nearest neighbour kernels against the torch formula
+    -tau logsumexp(-d2 / tau) and its autograd gradients; convergence to the hard chamfer term as tau -> 0; usable as the
+    chamfer stage's data term (`losses.soft_chamfer`)."""
+    from uuo_mocap_amd.losses import soft_weighted_chamfer_distance, weighted_chamfer_distance
+    from uuo_mocap_amd.optimization import last_stats, optim_chamfer
+
+    gen = torch.Generator().manual_seed(11)
+    for N, P1, P2, tau in ((3, 7, 50, 0.05), (2, 70, 300, 0.01), (1, 1, 1, 0.1)):
+        x = torch.randn(N, P1, 3, generator=gen).to(dev).requires_grad_(True)
+        y = torch.randn(N, P2, 3, generator=gen).to(dev).requires_grad_(True)
+        w = (torch.rand(N, P1, generator=gen) > 0.2).float().to(dev)
+        w[0, 0] = 1.0
+        loss = soft_weighted_chamfer_distance(x, y, w, tau)[0]
+        gx, gy = torch.autograd.grad(loss, (x, y))
+        xd, yd = x.detach().double().requires_grad_(True), y.detach().double().requires_grad_(True)
+        d2 = ((xd[:, :, None] - yd[:, None]) ** 2).sum(-1)
+        ref = ((-tau * torch.logsumexp(-d2 / tau, dim=-1)) * w.double()).sum() / w.double().sum()
+        rgx, rgy = torch.autograd.grad(ref, (xd, yd))
+        assert float(loss) == pytest.approx(float(ref), rel=2e-5, abs=1e-6)
+        np.testing.assert_allclose(gx.cpu().numpy(), rgx.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(gy.cpu().numpy(), rgy.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        hard = weighted_chamfer_distance(x.detach(), y.detach(), w)[0]
+        assert float(soft_weighted_chamfer_distance(x.detach(), y.detach(), w, 1e-6)[0]) == pytest.approx(float(hard), rel=1e-4)
+        assert float(loss) <= float(hard) + 1e-6
+    g = golden("chamfer_stage.npz")
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).float().to(dev)
+    cfg = packaged_config("video_mocap")
+    cfg["stages"]["chamfer"]["num_iters"] = 15
+    del cfg["stages"]["chamfer"]["losses"]["full_chamfer"]
+    cfg["stages"]["chamfer"]["losses"]["soft_chamfer"] = 10.0
+    cfg["stages"]["chamfer"]["soft_tau"] = 1e-3
+    leaves = [t(k).clone().requires_grad_(True) for k in ("hmr_pose_body", "o_betas", "hmr_root_orient", "trans0")]
+    optim_chamfer(t("markers"), pose_body=leaves[0], o_pose_body=t("hmr_pose_body"), betas=leaves[1], o_betas=t("o_betas"),
+                  root_orient=leaves[2], trans=leaves[3], img_mask=t("img_mask"), marker_labels=None, smpl_inference=smpl,
+                  config=cfg)
+    st = last_stats("chamfer")
+    assert st["driver"] == "torch.optim.LBFGS" and st["loss_final"] < 0.7 * st["loss_first"]

@@ -53,6 +53,10 @@ _SIGNATURES = {
                               c_void_p, c_void_p]),
     "uuo_assign_mean_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "uuo_soft_nn_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "uuo_soft_nn_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
     "uuo_copy_to_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "uuo_mesh_closest_points": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),

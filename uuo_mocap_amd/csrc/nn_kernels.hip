@@ -396,6 +396,130 @@ extern "C" int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const f
 }
 
 // ----------------------------------------------------------------------------------------------------
+// EXTENSION (not reference behaviour; BASELINE's north star names a soft-assignment chamfer): soft-min nearest
+// neighbour.  softmin_i = -tau * log sum_j exp(-d2_ij / tau) = dmin_i - tau * log sum_j exp((dmin_i - d2_ij) / tau),
+// with dmin from the exact K=1 search so that every exponent is <= 0.  Forward: one wave per (cloud, query), lanes
+// stride the candidates, fixed-order wave sum.  Backward: softmax weights p_ij = exp((dmin_i - d2_ij)/tau) / S_i;
+//   d softmin_i / d y_j = -2 p_ij (x_i - y_j),  d softmin_i / d x_i = 2 sum_j p_ij (x_i - y_j)
+// gy: thread = candidate, loop over the queries (no atomics); gx: wave = query, loop over the candidates.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_soft_fwd(int P1, int P2, const float* __restrict__ x,
+                                                 const float* __restrict__ y, const float* __restrict__ dmin,
+                                                 float inv_tau, float tau, float* __restrict__ softmin,
+                                                 float* __restrict__ sumexp) {
+  const int n = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+  const float* px = x + ((size_t)n * P1 + q) * 3;
+  const float qx = px[0], qy = px[1], qz = px[2];
+  const float dm = dmin[(size_t)n * P1 + q];
+  const float* yn = y + (size_t)n * P2 * 3;
+  float s = 0.f;
+  for (int j = lane; j < P2; j += 64) {
+    const float d2 = sqdist(qx, qy, qz, yn[j * 3], yn[j * 3 + 1], yn[j * 3 + 2]);
+    s += __expf((dm - d2) * inv_tau);
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    sumexp[(size_t)n * P1 + q] = s;
+    softmin[(size_t)n * P1 + q] = dm - tau * __logf(s);
+  }
+}
+
+#define SOFT_QT 64  // queries staged per LDS tile of the candidate-gradient kernel
+__global__ __launch_bounds__(256) void k_soft_bwd_y(int P1, int P2, const float* __restrict__ x,
+                                                    const float* __restrict__ y, const float* __restrict__ dmin,
+                                                    const float* __restrict__ sumexp, const float* __restrict__ gq,
+                                                    float inv_tau, float* __restrict__ gy) {
+  __shared__ float sq[SOFT_QT * 5];  // x, y, z, dmin, g / S
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const float* yn = y + (size_t)n * P2 * 3;
+  const bool on = j < P2;
+  const float cx = on ? yn[j * 3] : 0.f, cy = on ? yn[j * 3 + 1] : 0.f, cz = on ? yn[j * 3 + 2] : 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int q0 = 0; q0 < P1; q0 += SOFT_QT) {
+    __syncthreads();
+    if (threadIdx.x < SOFT_QT) {
+      const int q = q0 + threadIdx.x;
+      const bool qon = q < P1;
+      const size_t o = (size_t)n * P1 + (qon ? q : 0);
+      sq[threadIdx.x * 5] = qon ? x[o * 3] : 0.f;
+      sq[threadIdx.x * 5 + 1] = qon ? x[o * 3 + 1] : 0.f;
+      sq[threadIdx.x * 5 + 2] = qon ? x[o * 3 + 2] : 0.f;
+      sq[threadIdx.x * 5 + 3] = qon ? dmin[o] : 0.f;
+      sq[threadIdx.x * 5 + 4] = qon ? gq[o] / sumexp[o] : 0.f;  // 0 switches the padding queries off
+    }
+    __syncthreads();
+    const int nq = min(SOFT_QT, P1 - q0);
+    for (int t = 0; t < nq; ++t) {
+      const float qx = sq[t * 5], qy = sq[t * 5 + 1], qz = sq[t * 5 + 2];
+      const float d2 = sqdist(qx, qy, qz, cx, cy, cz);
+      const float w = sq[t * 5 + 4] * __expf((sq[t * 5 + 3] - d2) * inv_tau);  // g_i p_ij
+      a0 = fmaf(w, qx - cx, a0);
+      a1 = fmaf(w, qy - cy, a1);
+      a2 = fmaf(w, qz - cz, a2);
+    }
+  }
+  if (on) {
+    float* o = gy + ((size_t)n * P2 + j) * 3;
+    o[0] = -2.f * a0; o[1] = -2.f * a1; o[2] = -2.f * a2;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_soft_bwd_x(int P1, int P2, const float* __restrict__ x,
+                                                   const float* __restrict__ y, const float* __restrict__ dmin,
+                                                   const float* __restrict__ sumexp, const float* __restrict__ gq,
+                                                   float inv_tau, float* __restrict__ gx) {
+  const int n = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+  const size_t o = (size_t)n * P1 + q;
+  const float qx = x[o * 3], qy = x[o * 3 + 1], qz = x[o * 3 + 2];
+  const float dm = dmin[o], sc = gq[o] / sumexp[o];
+  const float* yn = y + (size_t)n * P2 * 3;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = lane; j < P2; j += 64) {
+    const float cx = yn[j * 3], cy = yn[j * 3 + 1], cz = yn[j * 3 + 2];
+    const float w = __expf((dm - sqdist(qx, qy, qz, cx, cy, cz)) * inv_tau);
+    a0 = fmaf(w, qx - cx, a0);
+    a1 = fmaf(w, qy - cy, a1);
+    a2 = fmaf(w, qz - cz, a2);
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) {
+    gx[o * 3] = 2.f * sc * a0; gx[o * 3 + 1] = 2.f * sc * a1; gx[o * 3 + 2] = 2.f * sc * a2;
+  }
+}
+
+extern "C" int uuo_soft_nn_forward(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y, float tau,
+                                   float* d_softmin, float* d_dmin, float* d_sumexp, void* d_ws) {
+  UUO_REQUIRE(d_x && d_y && d_softmin && d_dmin && d_sumexp && d_ws, "uuo_soft_nn_forward: null argument");
+  UUO_REQUIRE(N >= 0 && P1 >= 0 && P2 > 0 && tau > 0.f, "uuo_soft_nn_forward: bad sizes / temperature");
+  if (N == 0 || P1 == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = uuo_launch_nn(s, N, P1, P2, d_x, d_y, nullptr, 0, (unsigned long long*)d_ws);
+  if (rc) return rc;
+  rc = uuo_launch_nn_unpack(s, N * P1, (const unsigned long long*)d_ws, d_dmin, nullptr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_soft_fwd, dim3(P1, N), dim3(64), 0, s, P1, P2, d_x, d_y, d_dmin, 1.f / tau, tau, d_softmin, d_sumexp);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int uuo_soft_nn_backward(void* stream, int N, int P1, int P2, const float* d_x, const float* d_y, float tau,
+                                    const float* d_dmin, const float* d_sumexp, const float* d_grad_softmin,
+                                    float* d_gx, float* d_gy) {
+  UUO_REQUIRE(d_x && d_y && d_dmin && d_sumexp && d_grad_softmin, "uuo_soft_nn_backward: null argument");
+  UUO_REQUIRE(N >= 0 && P1 >= 0 && P2 > 0 && tau > 0.f, "uuo_soft_nn_backward: bad sizes / temperature");
+  if (N == 0 || P1 == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_gy)
+    hipLaunchKernelGGL(k_soft_bwd_y, dim3((P2 + 255) / 256, N), dim3(256), 0, s, P1, P2, d_x, d_y, d_dmin, d_sumexp,
+                       d_grad_softmin, 1.f / tau, d_gy);
+  if (d_gx)
+    hipLaunchKernelGGL(k_soft_bwd_x, dim3(P1, N), dim3(64), 0, s, P1, P2, d_x, d_y, d_dmin, d_sumexp, d_grad_softmin,
+                       1.f / tau, d_gx);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Closest point on the body surface (the reference's barycentric placement: igl.signed_distance followed by
 // trimesh.triangles.points_to_barycentric, optimization.py:494-500,519-523).  Brute force over the faces with the
 // closest-point-on-triangle region test of Ericson, Real-Time Collision Detection 5.1.5 (what libigl's

@@ -68,6 +68,50 @@ def chamfer_distance(x, y, weights=None, single_directional: bool = False):
     return cham, None
 
 
+class _SoftMin(torch.autograd.Function):
+    """EXTENSION (not in the reference): soft-min of the squared distances to a cloud, uuo_soft_nn_forward/backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, tau):
+        lib = _lib.load()
+        xd, yd = _f32(x, "x"), _f32(y, "y")
+        N, P1, P2 = xd.shape[0], xd.shape[1], yd.shape[1]
+        soft = torch.empty((N, P1), dtype=torch.float32, device=xd.device)
+        dmin = torch.empty_like(soft)
+        sumexp = torch.empty_like(soft)
+        ws = torch.empty((max(N * P1, 1),), dtype=torch.int64, device=xd.device)
+        with torch.cuda.device(xd.device):
+            check(lib.uuo_soft_nn_forward(current_stream(xd.device), N, P1, P2, _ptr(xd), _ptr(yd), float(tau), _ptr(soft),
+                                          _ptr(dmin), _ptr(sumexp), _ptr(ws)), "uuo_soft_nn_forward")
+        ctx.save_for_backward(xd, yd, dmin, sumexp)
+        ctx.tau = float(tau)
+        return soft
+
+    @staticmethod
+    def backward(ctx, grad_soft):
+        x, y, dmin, sumexp = ctx.saved_tensors
+        lib = _lib.load()
+        g = _f32(grad_soft, "grad")
+        N, P1, P2 = x.shape[0], x.shape[1], y.shape[1]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(x.device):
+            check(lib.uuo_soft_nn_backward(current_stream(x.device), N, P1, P2, _ptr(x), _ptr(y), ctx.tau, _ptr(dmin),
+                                           _ptr(sumexp), _ptr(g), _ptr(gx), _ptr(gy)), "uuo_soft_nn_backward")
+        return gx, gy, None
+
+
+def soft_weighted_chamfer_distance(x: torch.Tensor, y: torch.Tensor, x_weights: torch.Tensor, tau: float):
+    """EXTENSION, not reference behaviour: `weighted_chamfer_distance` with the hard minimum over the vertices replaced
+    by the soft minimum  -tau log sum_j exp(-|x_i - y_j|^2 / tau)  (-> the hard term as tau -> 0).  Same normalisation."""
+    d = _SoftMin.apply(x, y, tau)
+    w = x_weights.to(d.dtype) if x_weights.dtype != d.dtype else x_weights
+    wsum = x_weights.sum()
+    if wsum == 0.0:
+        return (x.sum() * 0.0), None
+    return (d * w).sum() / wsum, None
+
+
 def weighted_chamfer_distance(x: torch.Tensor, y: torch.Tensor, x_weights: torch.Tensor,
                               single_directional: bool = False):
     """sum_{n,i} w[n,i] * min_j |x[n,i]-y[n,j]|^2 / sum(w)  (the reference flattens to one cloud per marker and

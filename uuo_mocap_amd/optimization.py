@@ -12,7 +12,8 @@ import torch
 import torch.nn.functional as F
 
 from .engine import MARKER_DISTANCE, ChamferProblem, MarkerProblem
-from .losses import MarkerLoss, chamfer_distance, weighted_chamfer_distance  # noqa: F401  (re-exported like the reference)
+from .losses import (MarkerLoss, chamfer_distance, soft_weighted_chamfer_distance,  # noqa: F401  (re-exported)
+                     weighted_chamfer_distance)
 from .smpl import SmplInference
 from .transforms import compute_root_orient_y, compute_root_orient_z, normalize_rot  # noqa: F401
 
@@ -111,14 +112,15 @@ _CHAMFER_FUSED_LOSSES = {"full_chamfer", "reg_pose_body", "reg_betas"}
 
 def _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, marker_labels,
                            smpl_inference, config, initial_angle, repeat, verbose, iter_fn):
-    """Chamfer stage with the reference's optional terms (`part_chamfer`, `trans_vel`, `ground`) and / or
+    """Chamfer stage with the reference's optional terms (`part_chamfer`, `trans_vel`, `ground`; plus the labelled
+    extension `soft_chamfer`, a soft-assignment data term the reference does not have) and / or
     `yaw_lock: False` (reference optimization.py:164-285; none is in a shipped config): the closure is composed from the
     differentiable HIP operators and driven by torch.optim.LBFGS with the reference's parameter list
     [trans, z_angle, betas, pose_body], lr 0.1.  `root_orient_vel` stops in a debugger in the reference (:241) and is
     refused.  Same in-place semantics as the fused path."""
     st = config["stages"]["chamfer"]
     w = st["losses"]
-    unknown = set(w) - _CHAMFER_FUSED_LOSSES - {"part_chamfer", "trans_vel", "ground"}
+    unknown = set(w) - _CHAMFER_FUSED_LOSSES - {"part_chamfer", "trans_vel", "ground", "soft_chamfer"}
     if unknown:
         raise NotImplementedError("chamfer-stage losses that cannot run in the reference: %s" % sorted(unknown))
     device = root_orient.device
@@ -152,6 +154,9 @@ def _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root
         if "full_chamfer" in w:
             loss = loss + weighted_chamfer_distance(x=markers, y=out["vertices"], x_weights=mask,
                                                     single_directional=st["single_directional"])[0] * w["full_chamfer"]
+        if "soft_chamfer" in w:  # EXTENSION (not in the reference): soft-assignment data term, temperature stages.chamfer.soft_tau
+            loss = loss + soft_weighted_chamfer_distance(markers, out["vertices"], mask,
+                                                         float(st.get("soft_tau", 1e-3)))[0] * w["soft_chamfer"]
         if "reg_pose_body" in w:
             loss = loss + F.mse_loss(p_pose, o_pose_body) * w["reg_pose_body"]
         if "trans_vel" in w:
