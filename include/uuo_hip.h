@@ -129,6 +129,9 @@ typedef struct {
   float w_pose;              /* reg_pose_body weight (0 = term absent) */
   float w_betas;             /* reg_betas weight (0 = term absent) */
   float marker_distance;     /* MARKER_DISTANCE, utils/settings.py:1 */
+  uint64_t pose_cache_id;    /* part stage: non-zero = the body pose d_o_pose is constant for every evaluation that
+                                carries this id, so the pose-corrective blend (207 x 20670 contraction, 70 % of the
+                                forward's arithmetic) is computed once and re-used; 0 = recompute every evaluation */
 } uuo_problem_t;
 
 int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out);

@@ -269,6 +269,28 @@ def test_part_closure_matches_oracle(smpl, oracle_smpl, golden, dev, tag, cfg_na
     assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
     _, i_ref = p3d_ref.knn1_loop(markers_subset.numpy(), out["vertices"][:, vidx].detach().numpy())
     assert int((nn.cpu().numpy() != i_ref).sum()) == 0
+    # second evaluation of the same problem at another point: the pose-corrective blend now comes from the cache the
+    # first evaluation built (the body pose is a constant of the part stage), only yaw / translation / shape moved
+    z2 = torch.full((1, 1, 1), -0.45, requires_grad=True)
+    trans2 = (trans.detach() * 0.97 + 0.02).clone().requires_grad_(True)
+    betas2 = (betas.detach() * -0.5 + 0.1).clone().requires_grad_(True)
+    lo2, out2, _ = stages_ref.part_stage_loss(markers_subset, _t(g["hmr_pose_body"]), betas2, _t(g["o_betas"]),
+                                              _t(g["hmr_root_orient"]), trans2, z2, vidx, oracle_smpl, cfg)
+    lo2.backward()
+    ref_grad2 = torch.cat([t.grad.reshape(-1) for t in (z2, trans2, betas2)]).numpy()
+    loss2, grad2, nn2 = prob.evaluate(prob.pack(z2.detach().to(dev), trans2.detach().to(dev), betas2.detach().to(dev)))
+    np.testing.assert_allclose(loss2, lo2.item(), rtol=2e-5)
+    assert _rel_err(grad2.cpu().numpy(), ref_grad2) < 2e-4
+    _, i_ref2 = p3d_ref.knn1_loop(markers_subset.numpy(), out2["vertices"][:, vidx].detach().numpy())
+    assert int((nn2.cpu().numpy() != i_ref2).sum()) == 0
+    # a new problem on the same workspace with ANOTHER pose must not see the old cache
+    pose_b = _t(g["hmr_pose_body"]).flip(0).contiguous()
+    lo3, _, _ = stages_ref.part_stage_loss(markers_subset, pose_b, betas2, _t(g["o_betas"]), _t(g["hmr_root_orient"]),
+                                           trans2, z2, vidx, oracle_smpl, cfg)
+    prob_b = PartProblem(smpl, markers_subset.to(dev), pose_b.to(dev), _t(g["o_betas"], dev), _t(g["hmr_root_orient"], dev),
+                         vidx.to(dev), cfg)
+    loss3, _, _ = prob_b.evaluate(prob_b.pack(z2.detach().to(dev), trans2.detach().to(dev), betas2.detach().to(dev)))
+    np.testing.assert_allclose(loss3, lo3.item(), rtol=2e-5)
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

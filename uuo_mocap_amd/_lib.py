@@ -20,6 +20,7 @@ class UuoProblem(ctypes.Structure):
         ("d_markers", c_void_p), ("d_o_pose", c_void_p), ("d_o_betas", c_void_p), ("d_root", c_void_p),
         ("d_assign", c_void_p), ("d_subset", c_void_p), ("n_subset", c_int32),
         ("w_data", c_float), ("w_pose", c_float), ("w_betas", c_float), ("marker_distance", c_float),
+        ("pose_cache_id", ctypes.c_uint64),
     ]
 
 

@@ -861,8 +861,33 @@ static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay,
 static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src) {
   if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
   const uuo_model* m = fit->model;
-  int rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
+  int rc = 0;
+  static const int no_cache = getenv("UUO_PART_NOCACHE") ? atoi(getenv("UUO_PART_NOCACHE")) : 0;  // comparison only
+  const bool cached = p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && m->nnz <= 4 && !no_cache;
+  if (cached && fit->pose_cache_id != p->pose_cache_id) {
+    // first evaluation of a solve whose body pose is constant: C = v_t + P . feat through the MFMA kernel with zero
+    // shape, identity skinning transforms and no translation
+    if (!fit->pose_cache) UUO_HIP_CHECK(hipMalloc((void**)&fit->pose_cache, (size_t)p->F * m->V * 3 * sizeof(float)));
+    UuoPoseSrc c = src;
+    c.betas = fit->zeros16;
+    c.betas_stride = 0;
+    c.trans = nullptr;
+    rc = uuo_launch_pose_prep(m, s, p->F, c, fit->pfaT, fit->A, nullptr, nullptr);
+    if (rc) return rc;
+    rc = uuo_launch_identity_transforms(s, p->F * UUO_NUM_JOINTS, fit->A);
+    if (rc) return rc;
+    rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, nullptr, fit->pose_cache, nullptr);
+    if (rc) return rc;
+    fit->pose_cache_id = p->pose_cache_id;
+  }
+  rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
   if (rc) return rc;
+  if (cached) {
+    rc = uuo_launch_skin_cached(m, s, p->F, fit->pose_cache, fit->A, src.betas, src.trans, p->d_subset, p->n_subset,
+                                fit->verts);
+    if (rc) return rc;
+    return uuo_launch_nn(s, p->F, p->M, m->V, p->d_markers, fit->verts, p->d_subset, p->n_subset, fit->nn);
+  }
   const bool cull = (p->d_subset == nullptr) && (m->VP / 16) <= 512 && p->M <= 512;
   rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
   if (rc) return rc;

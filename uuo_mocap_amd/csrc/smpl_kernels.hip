@@ -767,6 +767,86 @@ static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const fl
 // ----------------------------------------------------------------------------------------------------
 // 45 joints of smplx SMPL.forward: 24 posed joints + 21 vertex-picked joints (VertexJointSelector)
 // ----------------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------------
+// Part stage with a constant body pose (find_best_part_fits optimises yaw, translation and shape only): the template
+// plus pose-corrective offsets of every frame, C[f][v] = v_t + P . feat_f, do not change between the closure
+// evaluations of one solve.  They are produced once by the MFMA kernel (identity skinning transforms, zero shape) and
+// each evaluation then only adds the shape blend and skins the vertices the candidate body part owns:
+//   v = T_f(v) (C[f][v] + S[v] . beta) + trans_f,   T_f(v) = sum_n w_n A_f[j_n]
+// Thread = vertex (shape offset and skin weights in registers), loop over a group of frames whose skinning matrices sit
+// in LDS: 12 B read + 12 B written per vertex and frame instead of the 207-term contraction.
+// ----------------------------------------------------------------------------------------------------
+#define SKC_FB 10  // frames per block
+__global__ __launch_bounds__(256) void k_skin_cached(int F, int V, int ns, const int32_t* __restrict__ subset,
+                                                     const float* __restrict__ C, const float* __restrict__ ST,
+                                                     const int* __restrict__ Wi, const float* __restrict__ Ww,
+                                                     const float* __restrict__ A, const float* __restrict__ betas,
+                                                     const float* __restrict__ trans, float* __restrict__ verts) {
+  __shared__ float sA[SKC_FB * UUO_NUM_JOINTS * 12];
+  __shared__ float sTr[SKC_FB * 3];
+  const int f0 = blockIdx.y * SKC_FB, nf = min(SKC_FB, F - f0);
+  for (int i = threadIdx.x; i < nf * UUO_NUM_JOINTS * 12; i += 256) sA[i] = A[(size_t)f0 * UUO_NUM_JOINTS * 12 + i];
+  if (threadIdx.x < nf * 3) sTr[threadIdx.x] = trans ? trans[(size_t)f0 * 3 + threadIdx.x] : 0.f;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ns) return;
+  const int v = subset ? subset[i] : i;
+  if ((unsigned)v >= (unsigned)V) return;
+  float sb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int l = 0; l < 10; ++l) sb[c] = fmaf(ST[(size_t)v * 30 + c * 10 + l], betas[l], sb[c]);
+  const int4 wi = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
+  const float4 ww = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
+  const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
+  const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+  for (int q = 0; q < nf; ++q) {
+    const float* pc = C + ((size_t)(f0 + q) * V + v) * 3;
+    const float px = pc[0] + sb[0], py = pc[1] + sb[1], pz = pc[2] + sb[2];
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float* a = sA + (q * UUO_NUM_JOINTS + (wj[n] < 0 ? 0 : wj[n])) * 12;
+      const float w = (wj[n] < 0) ? 0.f : wv[n];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = fmaf(w, a[e], T[e]);
+    }
+    float* o = verts + ((size_t)(f0 + q) * V + v) * 3;
+    o[0] = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3] + sTr[q * 3];
+    o[1] = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7] + sTr[q * 3 + 1];
+    o[2] = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11] + sTr[q * 3 + 2];
+  }
+}
+
+int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
+                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts) {
+  UUO_REQUIRE(m->nnz <= 4, "uuo_launch_skin_cached: needs the sparse skin-weight tables");
+  const int ns = subset ? n_subset : m->V;
+  if (F <= 0 || ns <= 0) return 0;
+  hipLaunchKernelGGL(k_skin_cached, dim3((ns + 255) / 256, (F + SKC_FB - 1) / SKC_FB), dim3(256), 0, s, F, m->V, ns, subset,
+                     cache, m->ST, m->Wi, m->Ww, A, betas, trans, verts);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_identity_transforms(int count, float* __restrict__ A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count * 12) {
+    const int e = i % 12;
+    A[i] = (e == 0 || e == 5 || e == 10) ? 1.f : 0.f;
+  }
+}
+
+int uuo_launch_identity_transforms(hipStream_t s, int count, float* A) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_identity_transforms, dim3((count * 12 + 255) / 256), dim3(256), 0, s, count, A);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 __global__ __launch_bounds__(64) void k_joints45(const UuoTree* __restrict__ tree, int F, int V,
                                                   const float* __restrict__ jposed, const float* __restrict__ verts,
                                                   float* __restrict__ out) {

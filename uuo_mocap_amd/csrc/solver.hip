@@ -1700,6 +1700,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
   A((void**)&fit->frames, (size_t)F * sizeof(FrameLds));
   A((void**)&fit->mask, (size_t)F * M * sizeof(float));
   A((void**)&fit->scalars, 64 * sizeof(float));
+  A((void**)&fit->zeros16, 16 * sizeof(float));
   A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
   if (e == hipSuccess) e = hipEventCreate(&fit->ev0);
   if (e == hipSuccess) e = hipEventCreate(&fit->ev1);
@@ -1715,7 +1716,8 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
 
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
-  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs};
+  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs,
+                  fit->pose_cache, fit->zeros16};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);

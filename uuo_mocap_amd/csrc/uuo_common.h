@@ -101,6 +101,10 @@ struct uuo_fit {
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
   float* frames = nullptr;          // [F][sizeof(FrameLds)/4]: per-frame rotations / joints / world transforms left by
                                     // k_pose_prep for the backward kernel of the same closure
+  float* pose_cache = nullptr;      // [F][V][3] template + pose-corrective offsets of a constant body pose (part stage),
+                                    // allocated on first use
+  unsigned long long pose_cache_id = 0;  // the problem id the cache was built for (0 = none)
+  float* zeros16 = nullptr;         // 16 zero floats (betas of the cache build)
   float* mask = nullptr;            // [F][M] 0/1
   float* scalars = nullptr;         // device scalars block (see solver)
   float* vecs = nullptr;            // one work vector of n_max floats (timing helper gradient)
@@ -114,6 +118,9 @@ int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPose
                          float* joints_posed, float* frames = nullptr);
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox);
+int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
+                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts);
+int uuo_launch_identity_transforms(hipStream_t s, int count, float* A);
 int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
                        const float* bbox, unsigned long long* packed, int* flags);
 int uuo_launch_joints45(const uuo_model* m, hipStream_t s, int F, const float* joints_posed, const float* verts,

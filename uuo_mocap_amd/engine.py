@@ -6,6 +6,7 @@ is a kernel behind the C ABI (include/uuo_hip.h).
 from __future__ import annotations
 
 import ctypes
+import itertools
 import threading
 from ctypes import byref, c_float, c_void_p
 from typing import Callable, Dict, Optional
@@ -212,6 +213,9 @@ def mesh_closest_points(verts, faces, points):
     return dist, face, closest, bary
 
 
+_POSE_CACHE_IDS = itertools.count(1)  # unique per PartProblem (thread-safe: itertools.count.__next__ is atomic in CPython)
+
+
 class _StageProblem:
     """One L-BFGS problem of the fit on a flat device vector in the reference's parameter packing."""
 
@@ -390,6 +394,8 @@ class PartProblem(_StageProblem):
         super().__init__(smpl_inference.device_model, markers, pose_body, o_betas, root_orient,
                          float(losses.get("chamfer", 0.0)), 0.0, float(losses.get("reg_betas", 0.0)),
                          subset=vertex_indices)
+        # the body pose is a constant of this problem: let the library compute its pose-corrective blend once
+        self.problem.pose_cache_id = next(_POSE_CACHE_IDS)
 
     def pack(self, z_angle, trans, betas):
         return torch.cat([_f32(z_angle, "z").reshape(-1), _f32(trans, "trans").reshape(-1),
