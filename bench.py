@@ -224,14 +224,14 @@ def main():
     # the reference prints stage banners unconditionally; sys.stdout is process-wide, so it is redirected once around
     # the fits (not per fit: with sequences in flight the per-fit redirections would restore each other's streams)
     with contextlib.redirect_stdout(io.StringIO()):
-        # initialisation, not a step: a 20-frame fit with a handful of iterations loads every code object, creates the
-        # streams / thread pools and pays torch's lazy initialisations (2 s in a fresh process) even when --warmup is 0
+        # initialisation, not a step: a fit of the workload's size with a handful of iterations loads every code object,
+        # allocates the per-hypothesis workspaces and pays torch's lazy initialisations (2 s in a fresh process) even when
+        # --warmup is 0
         cfg_init = copy.deepcopy(cfg)
         for k in ("part", "chamfer", "marker"):
             if cfg_init["stages"][k]["num_iters"] > 0:
                 cfg_init["stages"][k]["num_iters"] = 3
-        fit_once(smpl, make_sequence(tables, seed=0, num_frames=20, num_markers=10 if limb else 12, limb_only=limb),
-                 cfg_init, dev)
+        fit_once(smpl, seqs[0], cfg_init, dev)
         fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
         barrier()
         t0 = time.perf_counter()
