@@ -1296,3 +1296,51 @@ def test_soft_assignment_chamfer_extension(smpl, golden, dev):
                   config=cfg)
     st = last_stats("chamfer")
     assert st["driver"] == "torch.optim.LBFGS" and st["loss_final"] < 0.7 * st["loss_first"]
+
+
+@pytest.mark.gpu
+def test_missing_markers_and_tiny_sequences(smpl, oracle_smpl, dev):
+    """Edge cases of the marker input (reference optimization.py:703-715, multimodal.py:188-189): NaN -> 0 -> masked
+    out; a frame with no marker at all; a marker that is never seen; the all-missing closure (loss = priors only, as
+    weighted_chamfer_distance returns 0 for a zero weight sum); one-frame and one-marker sequences."""
+    from uuo_mocap_amd.engine import ChamferProblem
+    from uuo_mocap_amd.multimodal import multimodal_video_mocap
+
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = 6
+    cfg["num_root_orient_angles"] = 2
+    seq = make_sequence(smpl.tables, seed=12, num_frames=6, num_markers=7)
+    pts = seq.markers.get_points().copy()
+    pts[2] = 0.0            # a frame without markers
+    pts[:, 3] = np.nan      # a marker that is never seen
+    pts[4, 0] = np.nan
+    out = multimodal_video_mocap(seq.img_smpl, SyntheticMarkers(pts, 30.0), dev, cfg, offset=0, print_options=[],
+                                 save_stages=False, smpl_inference=smpl)
+    for k in ("trans", "pose_body", "root_orient", "betas"):
+        assert torch.isfinite(out[k]).all(), k
+    assert not np.isnan(out["mocap_markers"].get_points()).any()   # the orchestrator hands the cleaned cloud back
+    # closure on an all-missing cloud: only the priors remain, exactly as in the oracle
+    F = 6
+    zeros = torch.zeros(F, 7, 3, device=dev)
+    img = seq.img_smpl
+    o_betas = (img.betas.sum(0, keepdim=True) / img.img_mask.sum()).to(dev)
+    prob = ChamferProblem(smpl, zeros, img.pose_body.to(dev), o_betas, img.root_orient.to(dev), cfg)
+    pose = (img.pose_body + 0.01).to(dev)
+    x = prob.pack(torch.zeros(F, 3, device=dev), torch.zeros(F, 1, 1, device=dev), o_betas + 0.1, pose)
+    loss, grad, _ = prob.evaluate(x)
+    expect = torch.nn.functional.mse_loss(pose, img.pose_body.to(dev)) * cfg["stages"]["chamfer"]["losses"]["reg_pose_body"] + \
+        0.01 * cfg["stages"]["chamfer"]["losses"]["reg_betas"]
+    assert loss == pytest.approx(float(expect), rel=1e-4)
+    assert torch.isfinite(grad).all() and float(grad[:4 * F].abs().max()) == 0.0   # no data term: trans / yaw untouched
+    # one frame; two markers (a single marker is refused by the rigid clustering, in the reference as here: sklearn's
+    # AgglomerativeClustering needs two samples)
+    for F1, M1 in ((1, 3), (4, 2)):
+        s1 = make_sequence(smpl.tables, seed=13, num_frames=F1, num_markers=M1, dropout=0.0)
+        o1 = multimodal_video_mocap(s1.img_smpl, copy.deepcopy(s1.markers), dev, cfg, offset=0, print_options=[],
+                                    save_stages=False, smpl_inference=smpl)
+        assert o1["trans"].shape == (F1, 3) and all(torch.isfinite(o1[k]).all() for k in ("trans", "pose_body", "betas"))
+    s1 = make_sequence(smpl.tables, seed=13, num_frames=4, num_markers=1, dropout=0.0)
+    with pytest.raises(ValueError, match="minimum of 2"):
+        multimodal_video_mocap(s1.img_smpl, copy.deepcopy(s1.markers), dev, cfg, offset=0, print_options=[],
+                               save_stages=False, smpl_inference=smpl)
