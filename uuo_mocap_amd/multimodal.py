@@ -301,6 +301,8 @@ def multimodal_video_mocap(
         return local
 
     n_threads = min(len(root_orient_angles), int(os.environ.get("UUO_HYPOTHESIS_THREADS", "4")))
+    if not run_chamfer and not run_marker:
+        n_threads = 1  # nothing to solve per hypothesis (hmr_full.yaml): worker threads would only add their start-up
     if recompute_labels and config["stages"]["segment"]["granularity"] == "part":
         # the reference's hypotheses run one after the other and each placement reads the labels the previous one
         # recomputed (only the "part" granularity looks at them): keep that order
