@@ -304,6 +304,9 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
 // ----------------------------------------------------------------------------------------------------
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 #define SK2_RING 7
+#ifndef UUO_SK2_PRIO
+#define UUO_SK2_PRIO 0  // raising the MFMA waves above the latency-bound kernels of other hypotheses cost 2 % of fit throughput
+#endif
 #define SK2_NPOS_LOG2 5  // 32 blocks per XCD: one 8-wave block per CU
 #define SK2_MAX_FT 31  // frame tiles per launch (a block's task run must stay within two frame tiles)
 
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __shared__ int sQ[64];                                        // sQ[0] = next unclaimed task of the block
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (UUO_SK2_PRIO) __builtin_amdgcn_s_setprio(UUO_SK2_PRIO);
   const unsigned long long stamp0 = (VAR & 8) ? __builtin_readcyclecounter() : 0ull;
   const int j = lane & 15, kq = lane >> 4;
   const int nunits = VP / 16;      // units of the blend-basis table (padded)
