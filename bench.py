@@ -277,6 +277,8 @@ def main():
             result["other_configs"] = {"hmr_full": {
                 "value": args.steps * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps,
                 "closure_evals_per_step": sum(sum(eval_counts(s_).values()) for s_ in hf_stats) / max(args.steps, 1),
+                "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
+                                  zip(hf_stats[-1]["timeline"], [0.0] + [t for _, t in hf_stats[-1]["timeline"][:-1]])},
                 "note": "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"}}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals)
