@@ -241,6 +241,15 @@ def find_best_part_fits(
     trans0 = torch.median(markers, dim=1)[0]
     valid = torch.ones(num_frames, dtype=torch.bool, device=device)
 
+    # vertices owned by each joint (dominant skin weight), in vertex order: one pass instead of 24 masked `nonzero`
+    # calls (each a device synchronisation) per candidate
+    order = torch.argsort(vertex_labels, stable=True)
+    counts = torch.bincount(vertex_labels, minlength=hierarchy.shape[0]).tolist()
+    joint_vertices = torch.split(order, counts)
+
+    def part_vertex_indices(subtree):
+        return torch.cat([joint_vertices[j] for j in subtree], dim=0)
+
     group = workspace_group()  # worker threads do not inherit thread-locals
 
     def fit_subtree(slot: int, subtree, stream):
@@ -250,7 +259,7 @@ def find_best_part_fits(
         set_workspace_slot(slot)
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         with ctx:
-            vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+            vertex_indices = part_vertex_indices(subtree)
             prob = PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vertex_indices, config)
             x = prob.pack(torch.zeros((1, 1, 1), device=device), trans0, o_betas)
             point_cb = None
@@ -297,7 +306,7 @@ def find_best_part_fits(
         reference's construction (:422-434,564)."""
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         with ctx:
-            vertex_indices = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in subtree], dim=0)
+            vertex_indices = part_vertex_indices(subtree)
             z_angle = torch.zeros((1, 1, 1), device=device).requires_grad_(True)
             trans = trans0.clone().requires_grad_(True)
             betas_s = o_betas.clone().requires_grad_(True)
