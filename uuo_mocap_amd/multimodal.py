@@ -243,6 +243,56 @@ def multimodal_video_mocap(
 
     group = workspace_group()  # worker threads do not inherit thread-locals
 
+    def yaw_score(r) -> float:
+        """Masked chamfer distance of a hypothesis' marker-stage result (reference :576-599)."""
+        angle_betas = torch.repeat_interleave(torch.from_numpy(r["betas"]).to(device)[None], dim=0,
+                                              repeats=r["pose_body"].shape[0])
+        with torch.no_grad():
+            vertices = smpl_inference(
+                poses=torch.from_numpy(r["pose_body"]).to(device), betas=angle_betas,
+                root_orient=torch.from_numpy(r["root_orient"]).to(device),
+                trans=torch.from_numpy(r["trans"]).to(device))["vertices"]
+            score = weighted_chamfer_distance(x=markers, y=vertices, x_weights=get_marker_mask(markers),
+                                              single_directional=True)[0]
+        return float(score)
+
+    def final_stage(r, labels):
+        """Final placement + marker L-BFGS from a hypothesis' marker-stage result (reference :601-677)."""
+        root_f = torch.from_numpy(r["root_orient"]).to(device).requires_grad_(True)
+        trans_f = torch.from_numpy(r["trans"]).to(device).requires_grad_(True)
+        pose_f = torch.from_numpy(r["pose_body"]).to(device).requires_grad_(True)
+        betas_f = torch.from_numpy(r["betas"][None]).to(device).requires_grad_(True)
+        final_np, final_stats = None, []
+        for stage_i in range(config["stage_repeats"]):
+            pose_stage = torch.clone(pose_f).detach().requires_grad_(False)
+            if "progress" in print_options:
+                print("Stage: computing marker placement... [{}/{}]".format(stage_i + 1, config["stage_repeats"]))
+            if run_marker:
+                one_hot = compute_nearest_points(
+                    markers=markers, pose_body=pose_f, betas=betas_f, root_orient=root_f, trans=trans_f,
+                    smpl_inference=smpl_inference, marker_labels=labels,
+                    granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
+                    config=config, o_pose_body=pose_stage, window_size=1,
+                    use_velocity=config["stages"]["compute_locations"]["use_velocity"])
+                if recompute_labels:
+                    labels = labels_from_placement(one_hot)
+                if "progress" in print_options:
+                    print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(stage_i + 1,
+                                                                                          config["stage_repeats"]))
+                root_f = root_f.clone().detach().requires_grad_(True)
+                pose_f = pose_f.clone().detach().requires_grad_(True)
+                optim_markers(markers=markers, pose_body=pose_f, o_pose_body=pose_stage, betas=betas_f,
+                              o_betas=o_betas, root_orient=root_f, trans=trans_f, barycentric_coords_one_hot=one_hot,
+                              img_mask=img_mask, smpl_inference=smpl_inference, config=config, initial_angle=0,
+                              repeat=1, verbose=verbose, iter_fn=save_iter_fn)
+                final_stats.append(optimization.last_stats("marker"))
+            root_f = normalize_rot(root_f).clone().detach().requires_grad_(True)
+            pose_f = normalize_rot(pose_f).clone().detach().requires_grad_(True)
+            final_np = {"trans": _np(trans_f), "root_orient": _np(root_f), "betas": _np(betas_f[0]),
+                        "pose_body": _np(pose_f)}
+        return {"trans": trans_f, "root_orient": root_f, "pose_body": pose_f, "betas": betas_f, "np": final_np,
+                "stats": final_stats, "labels": labels}
+
     def fit_hypothesis(index: int, root_orient_angle: float, stream, marker_labels=marker_labels):
         """One yaw hypothesis (reference multimodal.py:463-574): chamfer L-BFGS -> placement -> marker L-BFGS.
         Hypotheses are independent, so each runs on its own host thread, HIP stream and solver workspace."""
@@ -335,62 +385,27 @@ def multimodal_video_mocap(
             stats["marker"].append(local["marker_stats"])
 
     # ---- best yaw hypothesis by masked chamfer distance (first minimum wins)
-    best_angle_chamfer, best_angle = np.inf, None
+    best_angle_chamfer, best_angle, best_index = np.inf, None, 0
     yaw_scores = []
-    for root_orient_angle in root_orient_angles:
-        r = smpl_marker_rotations[root_orient_angle]
-        angle_betas = torch.repeat_interleave(torch.from_numpy(r["betas"]).to(device)[None], dim=0,
-                                              repeats=r["pose_body"].shape[0])
-        with torch.no_grad():
-            vertices = smpl_inference(
-                poses=torch.from_numpy(r["pose_body"]).to(device), betas=angle_betas,
-                root_orient=torch.from_numpy(r["root_orient"]).to(device),
-                trans=torch.from_numpy(r["trans"]).to(device))["vertices"]
-            score = weighted_chamfer_distance(x=markers, y=vertices, x_weights=get_marker_mask(markers),
-                                              single_directional=True)[0]
-        yaw_scores.append(float(score))
+    for k, (root_orient_angle, local) in enumerate(zip(root_orient_angles, results)):
+        score = yaw_score(smpl_marker_rotations[root_orient_angle])
+        yaw_scores.append(score)
         if score < best_angle_chamfer:
-            best_angle_chamfer, best_angle = score, root_orient_angle
+            best_angle_chamfer, best_angle, best_index = score, root_orient_angle, k
     stats["yaw_scores"] = yaw_scores
     stats["best_angle"] = best_angle
     mark("selection")
 
     smpl_chamfer = smpl_chamfer_rotations[best_angle]
     smpl_marker = smpl_marker_rotations[best_angle]
-    root_orient = torch.from_numpy(smpl_marker["root_orient"]).to(device).requires_grad_(True)
-    trans = torch.from_numpy(smpl_marker["trans"]).to(device).requires_grad_(True)
-    pose_body = torch.from_numpy(smpl_marker["pose_body"]).to(device).requires_grad_(True)
-    betas = torch.from_numpy(smpl_marker["betas"][None]).to(device).requires_grad_(True)
-
     print("Final marker optimization")
-    smpl_marker_final = None
-    for stage_i in range(config["stage_repeats"]):
-        pose_body_stage = torch.clone(pose_body).detach().requires_grad_(False)
-        if "progress" in print_options:
-            print("Stage: computing marker placement... [{}/{}]".format(stage_i + 1, config["stage_repeats"]))
-        if run_marker:
-            one_hot = compute_nearest_points(
-                markers=markers, pose_body=pose_body, betas=betas, root_orient=root_orient, trans=trans,
-                smpl_inference=smpl_inference, marker_labels=marker_labels,
-                granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device,
-                config=config, o_pose_body=pose_body_stage, window_size=1,
-                use_velocity=config["stages"]["compute_locations"]["use_velocity"])
-            if recompute_labels:
-                marker_labels = labels_from_placement(one_hot)
-            if "progress" in print_options:
-                print("Stage [marker]: optimizing SMPL parameters... [{}/{}]".format(stage_i + 1,
-                                                                                      config["stage_repeats"]))
-            root_orient = root_orient.clone().detach().requires_grad_(True)
-            pose_body = pose_body.clone().detach().requires_grad_(True)
-            optim_markers(markers=markers, pose_body=pose_body, o_pose_body=pose_body_stage, betas=betas,
-                          o_betas=o_betas, root_orient=root_orient, trans=trans, barycentric_coords_one_hot=one_hot,
-                          img_mask=img_mask, smpl_inference=smpl_inference, config=config, initial_angle=0, repeat=1,
-                          verbose=verbose, iter_fn=save_iter_fn)
-            stats["marker_final"].append(optimization.LAST_STATS["marker"])
-        root_orient = normalize_rot(root_orient).clone().detach().requires_grad_(True)
-        pose_body = normalize_rot(pose_body).clone().detach().requires_grad_(True)
-        smpl_marker_final = {"trans": _np(trans), "root_orient": _np(root_orient), "betas": _np(betas[0]),
-                             "pose_body": _np(pose_body)}
+    # (Running this stage speculatively inside the hypothesis threads -- for the best-scoring hypothesis finished so far
+    # -- was tried: the winner tends to be among the last to finish, so it saved nothing and cost extra solves.)
+    fin = final_stage(smpl_marker, marker_labels)
+    root_orient, trans, pose_body, betas = fin["root_orient"], fin["trans"], fin["pose_body"], fin["betas"]
+    smpl_marker_final = fin["np"]
+    stats["marker_final"].extend(fin["stats"])
+    marker_labels = fin["labels"]
 
     mark("final_marker")
     output = {
