@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import threading
 from collections.abc import Callable
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch
