@@ -49,6 +49,22 @@ def _np(t):
     return t.clone().detach().cpu().numpy()
 
 
+def _np_dict(**tensors):
+    """Host copies of several float tensors of one device with ONE device-to-host copy (packed into a flat buffer first)
+    instead of a blocking copy each."""
+    keys = list(tensors)
+    ts = [tensors[k].detach() for k in keys]
+    if not ts[0].is_cuda or any(t.dtype != ts[0].dtype for t in ts):
+        return {k: t.clone().cpu().numpy() for k, t in zip(keys, ts)}
+    flat = torch.cat([t.reshape(-1) for t in ts]).cpu().numpy()
+    out, o = {}, 0
+    for k, t in zip(keys, ts):
+        n = t.numel()
+        out[k] = flat[o:o + n].reshape(tuple(t.shape)).copy()
+        o += n
+    return out
+
+
 def multimodal_video_mocap(
     img_smpl,
     mocap_markers,
@@ -288,8 +304,7 @@ def multimodal_video_mocap(
                 final_stats.append(optimization.last_stats("marker"))
             root_f = normalize_rot(root_f).clone().detach().requires_grad_(True)
             pose_f = normalize_rot(pose_f).clone().detach().requires_grad_(True)
-            final_np = {"trans": _np(trans_f), "root_orient": _np(root_f), "betas": _np(betas_f[0]),
-                        "pose_body": _np(pose_f)}
+            final_np = _np_dict(trans=trans_f, root_orient=root_f, betas=betas_f[0], pose_body=pose_f)
         return {"trans": trans_f, "root_orient": root_f, "pose_body": pose_f, "betas": betas_f, "np": final_np,
                 "stats": final_stats, "labels": labels}
 
@@ -317,9 +332,8 @@ def multimodal_video_mocap(
                               img_mask=img_mask, smpl_inference=smpl_inference, initial_angle=root_orient_angle,
                               repeat=0, config=config, verbose=verbose, iter_fn=save_iter_fn)
                 local["chamfer_stats"] = optimization.last_stats("chamfer")
-            local["chamfer"] = {
-                "trans": _np(trans_angle), "root_orient": _np(normalize_rot(z_root)), "betas": _np(betas_angle[0]),
-                "pose_body": _np(normalize_rot(pose_angle))}
+            local["chamfer"] = _np_dict(trans=trans_angle, root_orient=normalize_rot(z_root), betas=betas_angle[0],
+                                        pose_body=normalize_rot(pose_angle))
             if "progress" in print_options:
                 print("Stage: computing marker placement... [{}/{}]".format(1, config["stage_repeats"]))
             if run_marker:
@@ -341,11 +355,15 @@ def multimodal_video_mocap(
                               config=config, initial_angle=root_orient_angle, repeat=0, verbose=verbose,
                               iter_fn=save_iter_fn)
                 local["marker_stats"] = optimization.last_stats("marker")
-            z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
-            pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
-            local["marker"] = {
-                "trans": _np(trans_angle), "root_orient": _np(z_root), "betas": _np(betas_angle[0]),
-                "pose_body": _np(pose_angle)}
+            if not run_chamfer and not run_marker:
+                # nothing was optimised: the marker-stage record is the chamfer-stage record (both hold the normalised
+                # rotations of the yawed part-stage result)
+                local["marker"] = {k: v.copy() for k, v in local["chamfer"].items()}
+            else:
+                z_root = normalize_rot(z_root).clone().detach().requires_grad_(True)
+                pose_angle = normalize_rot(pose_angle).clone().detach().requires_grad_(True)
+                local["marker"] = _np_dict(trans=trans_angle, root_orient=z_root, betas=betas_angle[0],
+                                           pose_body=pose_angle)
             if stream is not None:
                 stream.synchronize()
         return local
