@@ -285,11 +285,8 @@ def find_best_part_fits(
                                        root_orient=z_root, trans=trans)["vertices"]
                 verts_sub = verts[:, vertex_indices].contiguous()
                 distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0].item()
-                # label of marker i = dominant joint of argmin_v mean_f |v - x_i| over ALL vertices (:592-597)
-                near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
-                labels = vertex_labels[near].clone()
             out = {"stats": stats, "distance": distance, "betas": betas_s.clone(), "root_orient": z_root.clone(),
-                   "trans": trans.clone(), "labels": labels}
+                   "trans": trans.clone()}
             if stream is not None:
                 stream.synchronize()
         return out
@@ -351,12 +348,10 @@ def find_best_part_fits(
                 verts = out["vertices"]
                 distance = chamfer_distance(markers_subset, verts[:, vertex_indices].contiguous(),
                                             single_directional=False)[0].item()
-                near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
-                labels = vertex_labels[near].clone()
             res = {"stats": {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)),
                              "device_ms": 0.0, "driver": "torch.optim.LBFGS"},
                    "distance": distance, "betas": betas_s.detach().clone(), "root_orient": z_root.clone(),
-                   "trans": trans.detach().clone(), "labels": labels}
+                   "trans": trans.detach().clone()}
             if stream is not None:
                 stream.synchronize()
         return res
@@ -405,7 +400,15 @@ def find_best_part_fits(
                 "trans": res["trans"],
                 "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
             }
-            final_marker_labels[:, indices] = res["labels"][None, :].to(final_marker_labels.dtype)
+
+    # The reference relabels the markers every time a candidate improves on the best so far (:586-597); only the last
+    # such relabelling survives, i.e. the winner's: label of marker i = dominant joint of argmin_v mean_f |v - x_i| over
+    # ALL vertices of the winning candidate's body.  Computed once, for the winner.
+    with torch.no_grad():
+        verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(best["betas"], dim=0, repeats=num_frames),
+                               root_orient=best["root_orient"], trans=best["trans"])["vertices"]
+        near = smpl_inference.device_model.assign_mean_argmin(verts, markers_subset, valid).long()
+        final_marker_labels[:, indices] = vertex_labels[near][None, :].to(final_marker_labels.dtype)
 
     if len(subtree_losses) > 1:
         subtree_losses = sorted(subtree_losses, key=lambda e: e[1])
