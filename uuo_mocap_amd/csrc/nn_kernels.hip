@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void k_nn_fewq(const float* __restrict__ x, co
                                                  const int* __restrict__ ysub, int P1, int P2, int nc, int S,
                                                  unsigned long long* __restrict__ out) {
   __shared__ float sq[NNQ_MAX * 3];
+  __shared__ unsigned long long sk[NNQ_MAX];  // the block's minima: with one split they ARE the result (no zero-fill
+                                              // of the output, no global atomic)
   const int n = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   if (tid < P1 * 3) sq[tid] = x[(size_t)n * P1 * 3 + tid];
+  if (tid < NNQ_MAX) sk[tid] = ~0ull;
   __syncthreads();
   const int per = (nc + S - 1) / S;
   const int c0 = s * per, c1 = min(nc, c0 + per);
@@ -104,27 +107,35 @@ __global__ __launch_bounds__(256) void k_nn_fewq(const float* __restrict__ x, co
         const unsigned long long o = __shfl_xor(k, off, 64);
         k = o < k ? o : k;
       }
-      if ((tid & 63) == 0 && k != ~0ull) atomicMin(&out[(size_t)n * P1 + q], k);
+      if ((tid & 63) == 0 && k != ~0ull) atomicMin(&sk[q], k);
     }
+  }
+  __syncthreads();
+  if (tid < P1) {
+    if (S == 1)
+      out[(size_t)n * P1 + tid] = sk[tid];
+    else if (sk[tid] != ~0ull)
+      atomicMin(&out[(size_t)n * P1 + tid], sk[tid]);
   }
 }
 
 int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub, int P2s,
                   unsigned long long* packed) {
   const int nc = ysub ? P2s : P2;
-  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
-  if (nc <= 0 || N <= 0 || P1 <= 0) return 0;
-  if (P1 <= NNQ_MAX) {
+  if (nc > 0 && N > 0 && P1 > 0 && P1 <= NNQ_MAX) {
     // splits so that N * S blocks of 256 threads cover the chip a few times, each lane seeing >= 4 candidates
     int S = 1;
     if (N < 1024) S = (1024 + N - 1) / N;
     const int maxS = (nc + 1023) / 1024;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
+    if (S > 1) UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_nn_fewq, dim3(N, S), dim3(256), 0, s, x, y, ysub, P1, P2, nc, S, packed);
     UUO_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
+  if (nc <= 0 || N <= 0 || P1 <= 0) return 0;
   const int qgroups = (P1 + 63) / 64;
   // enough waves to fill the chip: target >= 4096 waves, at least 256 candidates per split
   int S = 1;
