@@ -30,6 +30,19 @@ PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix 
 # algorithmic FLOPs of the skin kernel per frame: pose blend 2*207*20670 + skinning 2*6890*24*12 + apply 6890*24
 SKIN_FLOPS_PER_FRAME = 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 6890 * 24
 NN_FLOPS_PER_FRAME_MARKER = 6890 * 8
+# what the kernel's matrix pipe usefully executes per frame: the [pose feature | betas] x [posedirs | shapedirs] blend
+# (the <=4-weight skinning runs on the VALU, not as the dense 24-joint product SURVEY 8d's figure credits)
+SKIN_MFMA_FLOPS_PER_FRAME = 2 * 217 * 20670
+# algorithmic FLOPs of one frame through one closure (forward + backward)
+CHAMFER_FLOPS_PER_FRAME_EVAL = 15.5e6
+MARKER_FLOPS_PER_FRAME_EVAL = 0.28e6
+CHAMFER_CEILING_FRAME_EVALS_PER_S = PEAK_FP32_TFLOPS * 1e12 / CHAMFER_FLOPS_PER_FRAME_EVAL  # 10.1 M/s
+
+
+def part_flops_per_frame_eval(n_subset, n_markers):
+    """part-stage closure with the pose-corrective blend cached per solve: shape blend + skinning of the candidate
+    part's vertices + the K=1 search over them."""
+    return n_subset * (2 * 10 * 3 + 2 * 24 * 12 + 24) + 8.0 * n_markers * n_subset
 
 
 def parse():
@@ -45,7 +58,8 @@ def parse():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the timing loops of the roofline section (one warm-up fit): the command profiled into "
                          "profiles/r1_roofline_kernel_stats.csv")
-    ap.add_argument("--cpu-evals", type=int, default=3, help="closure evaluations per stage type timed on the CPU")
+    ap.add_argument("--cpu-evals", type=int, default=20, help="closure evaluations per stage type timed on the CPU")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the hmr_full / hmr_part / mht_rotation legs")
     return ap.parse_args()
 
 
@@ -67,6 +81,47 @@ def eval_counts(stats):
         for s in stats.get(key, []):
             n["marker"] += s["n_eval"]
     return n
+
+
+def stage_summary(stats):
+    """Final loss, stop reason and work of every solve of one fit, by stage (what the fit converged to, not only how
+    fast it ran)."""
+    out = {}
+    for key in ("part", "chamfer", "marker", "marker_final"):
+        solves = stats.get(key, [])
+        if not solves:
+            continue
+        entry = {"solves": len(solves),
+                 "n_iter": [int(s["n_iter"]) for s in solves][:8], "n_eval": [int(s["n_eval"]) for s in solves][:8],
+                 "final_loss": [float(s["final_loss"]) for s in solves][:8],
+                 "stop_reason": sorted(set(str(s["stop_reason"]) for s in solves))}
+        if len(solves) > 8:
+            entry["final_loss_min"] = float(min(s["final_loss"] for s in solves))
+            entry["n_eval_total"] = int(sum(s["n_eval"] for s in solves))
+        out[key] = entry
+    if "yaw_scores" in stats:
+        out["yaw_scores"] = [float(v) for v in stats["yaw_scores"]]
+        out["best_angle"] = float(stats["best_angle"]) if stats.get("best_angle") is not None else None
+    return out
+
+
+def fit_quality(smpl, seq, out, dev):
+    """Error of a fit against the synthetic ground truth (uuo_mocap_amd/synthetic.py: float64 SMPL equations): mean
+    per-vertex and per-joint Euclidean error in millimetres (V2V / MPJPE over the 24 skeleton joints, reference
+    evaluation/metrics.py definitions), the shape error and the masked marker-to-nearest-vertex chamfer score."""
+    from uuo_mocap_amd.optimization import get_marker_mask, weighted_chamfer_distance
+
+    with torch.no_grad():
+        res = smpl(out["pose_body"].to(dev), out["betas"].to(dev), out["root_orient"].to(dev), out["trans"].to(dev))
+        gt_v = torch.from_numpy(seq.gt["verts"]).to(dev)
+        gt_j = torch.from_numpy(seq.gt["joints"]).to(dev)
+        v2v = (res["vertices"] - gt_v).norm(dim=-1).mean().item()
+        mpjpe = (res["joints"][:, :24] - gt_j).norm(dim=-1).mean().item()
+        markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+        score = weighted_chamfer_distance(markers, res["vertices"], get_marker_mask(markers))[0].item()
+    beta_err = float(np.abs(out["betas"][0].numpy() - seq.gt["betas"][0]).mean())
+    return {"v2v_mm": 1e3 * v2v, "mpjpe_mm": 1e3 * mpjpe, "betas_mean_abs_err": beta_err,
+            "marker_chamfer_m2": score}
 
 
 def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals):
@@ -148,9 +203,19 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
     # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r1_pmc_summary.json):
     # FETCH_SIZE 15 084 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 400 KB, at F=300
     traffic = (15084 * 2 + 30400) * 1024 if (F == 300) else None
+    mfma_useful = SKIN_MFMA_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12
+    closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "traffic_source": "profiles/r1_pmc_summary.json (offline PMC passes)", "kernel": "k_skin2<true,0>",
+                "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel at F=300 "
+                                  "(profiles/r1_pmc_summary.json), not measured by this run",
+                "kernel": "k_skin2<true,0>",
+                # frac credits SURVEY 8d's dense 24-joint skinning product; the kernel does that part as <=4-weight VALU
+                # work, so the matrix pipe's own useful rate is the blend contraction alone:
+                "frac_mfma_useful": mfma_useful / PEAK_FP32_TFLOPS, "achieved_mfma_useful": mfma_useful,
+                # one whole chamfer closure (forward + backward, five kernels) alone on the GPU against SURVEY 8d's
+                # FP32 ceiling of 157.3 TF / 15.5 MFLOP = 10.1 M frame-evals/s
+                "closure_frac": closure_rate / CHAMFER_CEILING_FRAME_EVALS_PER_S,
                 "kernel_ms": skin_ms, "flops_per_launch": skin_flops,
                 # SURVEY 8d asks for the HBM fraction as well: algorithmic bytes of the launch (blend basis once +
                 # vertices + unit boxes written) over its duration against the 8 TB/s spec; small by construction
@@ -201,8 +266,10 @@ def main():
     F, M = args.frames, args.markers
     n_seq = args.warmup + args.steps
     limb = args.config == "hmr_part"
-    seqs = [make_sequence(tables, seed=(rank * n_seq + i) % 8 if world > 1 else i % 8, num_frames=F,
-                          num_markers=10 if limb else M, limb_only=limb) for i in range(n_seq)]
+    # distinct seeds for every warm-up and timed sequence of every rank (the solves stop on tolerances, so time depends on
+    # the data: a timed step must not repeat a warm-up step)
+    seqs = [make_sequence(tables, seed=rank * n_seq + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb)
+            for i in range(n_seq)]
 
     if args.roofline_only:
         # no fit: the dominant kernel and the chamfer closure alone on an idle GPU (the command behind
@@ -235,14 +302,26 @@ def main():
         fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
         barrier()
         t0 = time.perf_counter()
-        all_stats = [st for _, st in fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev),
-                                              inflight=args.inflight, device=dev)]
+        fits = fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight,
+                        device=dev)
         barrier()
         elapsed = time.perf_counter() - t0
+    all_stats = [st for _, st in fits]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # fit quality of every timed step of this rank against the synthetic ground truth (outside the timed region)
+    quality = [fit_quality(smpl, sq, out, dev) for sq, (out, _) in zip(seqs[args.warmup:n_seq], fits)]
+    q_mean = {k: float(np.mean([q[k] for q in quality])) for k in quality[0]}
+    q_worst = {k: float(np.max([q[k] for q in quality])) for k in quality[0]}
+    if world > 1:
+        # every rank fitted different sequences: report the mean / worst over the whole job
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (q_mean, q_worst))
+        q_mean = {k: float(np.mean([g[0][k] for g in gathered])) for k in q_mean}
+        q_worst = {k: float(np.max([g[1][k] for g in gathered])) for k in q_worst}
 
     if rank == 0:
         n_eval = eval_counts(all_stats[-1])
@@ -250,6 +329,18 @@ def main():
         frames = world * args.steps * F
         value = frames / elapsed
         roofline = measure_roofline(smpl, seqs[-1], dev, F)
+        # whole-fit arithmetic rate: SURVEY 8d's algorithmic FLOPs of every closure evaluation the timed fits executed
+        # (rank 0's counts; all ranks run the same workload) over the wall time, against the FP32 peak
+        n_sub = int(tables.v_template.shape[0])
+        fit_flops = 0.0
+        for st in all_stats:
+            c = eval_counts(st)
+            fit_flops += F * (c["chamfer"] * CHAMFER_FLOPS_PER_FRAME_EVAL + c["marker"] * MARKER_FLOPS_PER_FRAME_EVAL)
+            for ps in st.get("part", []):
+                fit_flops += F * ps["n_eval"] * part_flops_per_frame_eval(ps.get("n_subset", n_sub),
+                                                                           ps.get("n_markers", M))
+        roofline["fit_frac"] = fit_flops / elapsed / (PEAK_FP32_TFLOPS * 1e12)
+        roofline["fit_achieved"] = fit_flops / elapsed / 1e12
         result = {
             "metric": "mocap frames/sec fitted (300-frame seq, 50 markers)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -261,25 +352,44 @@ def main():
                        "sequences_in_flight": args.inflight},
             "closure_evals_per_step": total_evals / max(args.steps, 1), "closure_evals_last_step": n_eval,
             "frame_evals_per_s": world * total_evals * F / elapsed if world == 1 else None,
+            "fit_quality": {"mean": q_mean, "worst": q_worst, "steps": len(quality) * world,
+                            "against": "synthetic ground truth (float64 SMPL equations, uuo_mocap_amd/synthetic.py); "
+                                       "HMR stand-in starts 100 deg off in yaw with 0.1 rad pose / 0.5 shape noise"},
+            "stages_last_step": stage_summary(all_stats[-1]),
             "roofline": roofline,
         }
-        if world == 1 and args.config == "video_mocap" and not args.roofline_only:
-            # BASELINE configs[1] (hmr_full.yaml) on the same sequences, reported beside the headline: it disables the
-            # chamfer and marker stages, so it times the part stage only and is not the metric's workload
-            cfg_hf = packaged_config("hmr_full")
-            with contextlib.redirect_stdout(io.StringIO()):
-                fit_once(smpl, seqs[0], cfg_hf, dev)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                hf_stats = [fit_once(smpl, sq, cfg_hf, dev)[1] for sq in seqs[args.warmup:n_seq]]
-                torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t1
-            result["other_configs"] = {"hmr_full": {
-                "value": args.steps * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps,
-                "closure_evals_per_step": sum(sum(eval_counts(s_).values()) for s_ in hf_stats) / max(args.steps, 1),
-                "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
-                                  zip(hf_stats[-1]["timeline"], [0.0] + [t for _, t in hf_stats[-1]["timeline"][:-1]])},
-                "note": "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"}}
+        if world == 1 and args.config == "video_mocap" and not args.no_other_configs:
+            # the other shipped configurations on sequences of the same size, beside the headline (not the metric's
+            # workload): hmr_full.yaml = BASELINE configs[1] as written (part stage on the full skeleton only: SURVEY F9),
+            # hmr_part.yaml = configs[2] (10 markers on one limb, sub-tree search), mht_rotation.yaml = configs[4]'s
+            # config (one yaw hypothesis)
+            result["other_configs"] = {}
+            n_other = min(args.steps, 4)
+            for name in ("hmr_full", "hmr_part", "mht_rotation"):
+                cfg_o = packaged_config(name)
+                limb_o = name == "hmr_part"
+                seqs_o = [make_sequence(tables, seed=1000 + i, num_frames=F, num_markers=10 if limb_o else M,
+                                        limb_only=limb_o) for i in range(n_other + 1)]
+                with contextlib.redirect_stdout(io.StringIO()):
+                    fit_once(smpl, seqs_o[0], cfg_o, dev)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    fits_o = [fit_once(smpl, sq, cfg_o, dev) for sq in seqs_o[1:]]
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t1
+                q_o = [fit_quality(smpl, sq, out, dev) for sq, (out, _) in zip(seqs_o[1:], fits_o)]
+                st_o = [st for _, st in fits_o]
+                result["other_configs"][name] = {
+                    "value": n_other * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n_other, "steps": n_other,
+                    "markers": 10 if limb_o else M,
+                    "closure_evals_per_step": sum(sum(eval_counts(s_).values()) for s_ in st_o) / max(n_other, 1),
+                    "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
+                                      zip(st_o[-1]["timeline"], [0.0] + [t for _, t in st_o[-1]["timeline"][:-1]])},
+                    "fit_quality_mean": {k: float(np.mean([q[k] for q in q_o])) for k in q_o[0]},
+                    "stages_last_step": stage_summary(st_o[-1]),
+                }
+            result["other_configs"]["hmr_full"]["note"] = \
+                "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals)
             if result["cpu_baseline"]["value"]:

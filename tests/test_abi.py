@@ -19,6 +19,41 @@ def test_library_loads_and_exports_every_header_symbol():
     assert set(_lib._SIGNATURES) == set(names), "ctypes signature table and include/uuo_hip.h disagree"
 
 
+def test_product_library_exports_the_header_and_nothing_else():
+    """The shipped library's dynamic symbol table is include/uuo_hip.h: no uuo_debug_* hook, no self-test entry, no C++
+    launcher; and it reads no environment variable (the ablation knobs live in libuuo_hip_debug.so only)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+    assert exported == _lib.header_symbols(), set(exported) ^ set(_lib.header_symbols())
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], check=True, capture_output=True,
+                               text=True).stdout
+    assert "getenv" not in undefined
+    dbg = _lib.load_debug()
+    for name in _lib._DEBUG_SIGNATURES:
+        assert hasattr(dbg, name), name
+    for name in _lib.header_symbols():
+        assert hasattr(dbg, name), name
+
+
+def test_marker_loss_known_answer():
+    """Product MarkerLoss (losses.py; reference losses/losses.py:43-51) against SURVEY.md K-B, on the CPU: it is plain
+    torch arithmetic on the caller's tensors."""
+    from uuo_mocap_amd.losses import MarkerLoss
+    from uuo_mocap_amd.optimization import get_marker_mask
+
+    m = torch.tensor([[[0, 0, 0], [1, 2, 2]], [[0, 3, 4], [0, 0, 0]]]).float()
+    vm = torch.tensor([[[1, 0, 0], [1, 2, 2.0095]], [[0, 0, 0], [5, 5, 5]]]).float()
+    out = MarkerLoss(m, vm, get_marker_mask(m), 0.0095)
+    assert out.shape == (2, 2)
+    assert out[0, 0].item() == 0.0 and out[1, 1].item() == 0.0
+    assert out[1, 0].item() == 24.90509033203125
+    assert out.mean().item() == 6.2262725830078125
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.npz"))
+    np.testing.assert_array_equal(out.numpy(), g["kb"])
+
+
 def test_problem_sizes_follow_the_reference_packing():
     lib = _lib.load()
     for stage, per_frame, const in ((_lib.UUO_STAGE_CHAMFER, 211, 10), (_lib.UUO_STAGE_MARKER, 219, 10),

@@ -1,0 +1,301 @@
+"""Oracle parity of the HIP path AT the BASELINE sizes (run with -m gpu on the MI355X box).
+
+BASELINE.json quotes the metric on 300 frames x 50 markers (``configs[1]``) and names the reference's own
+CPU-runnable case, 30 frames x 41 markers (``configs[0]``).  The fixtures under tests/golden are 8 x 12; here the
+CPU oracle (oracle/stages_ref.py: the reference's dense closures under torch autograd) is evaluated once per stage type
+at the full sizes -- about 2 s per closure at 300 x 50 -- and compared with one evaluation of the fused HIP closure at the
+same, non-trivial point (perturbed yaw, shape, pose, translation):
+
+* loss rtol 2e-5, flat gradient relative L2 error < 2e-4 (the bars of the small-size tests);
+* nearest-vertex indices: bit-exact against pytorch3d's CPU loop when both see the SAME (oracle) vertices, and the
+  flip rate when the HIP path searches its own MFMA-computed vertices is reported and bounded: a flip
+  is only legitimate on a near-tie, which is checked per flipped pair;
+* vertices within 1e-4 m (north_star's tolerance).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import p3d_ref, stages_ref  # noqa: E402
+from uuo_mocap_amd.config import packaged_config  # noqa: E402
+from uuo_mocap_amd.synthetic import make_sequence  # noqa: E402
+
+SIZES = [(300, 50, 0), (30, 41, 11)]  # (frames, markers, sequence seed): BASELINE configs[1] size and configs[0]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def smpl(tables, dev):
+    from uuo_mocap_amd.smpl import SmplInference
+
+    return SmplInference(dev, tables=tables)
+
+
+def _rel_err(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _inputs(tables, F, M, seed):
+    seq = make_sequence(tables, seed=seed, num_frames=F, num_markers=M)
+    markers = torch.from_numpy(seq.markers.get_points()).float()
+    o_pose = seq.img_smpl.pose_body.clone()
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).clone()
+    root = seq.img_smpl.root_orient.clone()
+    trans = torch.median(markers, dim=1)[0].clone()
+    return seq, markers, o_pose, o_betas, root, trans
+
+
+def _perturbed(F, o_pose, o_betas, root, trans, seed):
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    return (trans + 0.02 * r(F, 3), 0.3 * r(F, 1, 1), o_betas + 0.3 * r(1, 10), o_pose + 0.05 * r(F, 23, 3, 3),
+            root + 0.05 * r(F, 1, 3, 3))
+
+
+def _check_flips(nn_hip, i_ref, markers, verts_ref, record_property, tag):
+    """The HIP closure searched ITS vertices (MFMA blend, <= 2e-5 m from the oracle's): report how many assignments
+    differ from pytorch3d's loop on the oracle's vertices and require every difference to be a near-tie there."""
+    flips = np.argwhere(nn_hip != i_ref)
+    rate = len(flips) / i_ref.size
+    record_property("nn_flip_rate_%s" % tag, rate)
+    print("nn flips %s: %d of %d (%.2e)" % (tag, len(flips), i_ref.size, rate))
+    for f, m in flips:
+        da = float(np.sum((markers[f, m] - verts_ref[f, nn_hip[f, m]]).astype(np.float64) ** 2))
+        db = float(np.sum((markers[f, m] - verts_ref[f, i_ref[f, m]]).astype(np.float64) ** 2))
+        # vertices agree to 2e-5 m, so squared distances agree to ~2*sqrt(d)*4e-5
+        assert abs(da - db) <= 4.0 * np.sqrt(max(da, db)) * 4e-5 + 1e-9, (f, m, da, db)
+    assert rate <= 1e-3, "flip rate %.2e" % rate
+    return rate
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_smpl_forward_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, seed):
+    _, _, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    t, _, b, p, r = _perturbed(F, o_pose, o_betas, root, trans, 1)
+    p, r = stages_ref.normalize_rot(p), stages_ref.normalize_rot(r)
+    ref = oracle_smpl(poses=p, betas=b.expand(F, 10), root_orient=r, trans=t)
+    out = smpl(p.to(dev), b.expand(F, 10).to(dev), r.to(dev), t.to(dev))
+    dv = (out["vertices"].cpu() - ref["vertices"]).norm(dim=-1).max().item()
+    dj = (out["joints"].cpu() - ref["joints"]).norm(dim=-1).max().item()
+    assert dv <= 1e-4 and dj <= 1e-4, (dv, dj)   # north_star: within 1e-4 on vertex positions
+    # shared-betas call ([1,10]) is the same computation
+    out1 = smpl(p.to(dev), b.to(dev), r.to(dev), t.to(dev))
+    assert torch.equal(out1["vertices"], out["vertices"])
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_nn_indices_bit_exact_on_oracle_vertices(smpl, oracle_smpl, tables, dev, F, M, seed):
+    """Assignment indices AND squared distances, bit for bit, at the full size: same vertices in, same answer out."""
+    _, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    verts = oracle_smpl(poses=o_pose, betas=o_betas.expand(F, 10), root_orient=root, trans=trans)["vertices"]
+    d_ref, i_ref = p3d_ref.knn1_loop(markers.numpy(), verts.numpy())
+    dist, idx = smpl.device_model.nn_argmin(markers.to(dev), verts.to(dev))
+    np.testing.assert_array_equal(idx.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(dist.cpu().numpy(), d_ref)
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_chamfer_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, record_property, F, M, seed):
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    cfg = packaged_config("video_mocap")
+    _, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    t, z, b, p, _ = _perturbed(F, o_pose, o_betas, root, trans, 2)
+    leaves = [x.clone().requires_grad_(True) for x in (t, z, b, p)]
+    lo, out = stages_ref.chamfer_stage_loss(markers, leaves[3], o_pose, leaves[2], o_betas, root, leaves[0], leaves[1],
+                                            oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([x.grad.reshape(-1) for x in leaves]).numpy()
+    prob = ChamferProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), cfg)
+    assert prob.n == 211 * F + 10
+    x = prob.pack(t.to(dev), z.to(dev), b.to(dev), p.to(dev))
+    loss, grad, nn = prob.evaluate(x)
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
+    verts_ref = out["vertices"].detach().numpy()
+    _, i_ref = p3d_ref.knn1_loop(markers.numpy(), verts_ref)
+    _check_flips(nn.cpu().numpy(), i_ref, markers.numpy(), verts_ref, record_property, "chamfer_%dx%d" % (F, M))
+    # second evaluation nearby: the culled search starts from the previous assignment and must stay exact
+    t2 = t + 0.004
+    leaves2 = [x.clone().requires_grad_(True) for x in (t2, z, b, p)]
+    lo2, out2 = stages_ref.chamfer_stage_loss(markers, leaves2[3], o_pose, leaves2[2], o_betas, root, leaves2[0],
+                                              leaves2[1], oracle_smpl, cfg)
+    loss2, _, nn2 = prob.evaluate(prob.pack(t2.to(dev), z.to(dev), b.to(dev), p.to(dev)))
+    np.testing.assert_allclose(loss2, lo2.item(), rtol=2e-5)
+    v2 = out2["vertices"].detach().numpy()
+    _, i_ref2 = p3d_ref.knn1_loop(markers.numpy(), v2)
+    _check_flips(nn2.cpu().numpy(), i_ref2, markers.numpy(), v2, record_property, "chamfer_culled_%dx%d" % (F, M))
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_marker_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, seed):
+    from uuo_mocap_amd.engine import MarkerProblem
+
+    cfg = packaged_config("video_mocap")
+    seq, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    t, _, b, p, r = _perturbed(F, o_pose, o_betas, root, trans, 3)
+    vids = torch.from_numpy(np.asarray(seq.gt["marker_vids"])).long()
+    one_hot = torch.zeros(M, 6890)
+    one_hot[torch.arange(M), vids] = 1.0
+    leaves = [x.clone().requires_grad_(True) for x in (p, b, r, t)]
+    lo, _ = stages_ref.marker_stage_loss(markers, leaves[0], o_pose, leaves[1], o_betas, leaves[2], leaves[3], one_hot,
+                                         oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([x.grad.reshape(-1) for x in leaves]).numpy()
+    prob = MarkerProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), vids.to(dev), cfg)
+    assert prob.n == 219 * F + 10
+    loss, grad, _ = prob.evaluate(prob.pack(p.to(dev), b.to(dev), r.to(dev), t.to(dev)))
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+@pytest.mark.parametrize("subtree", ["full", "leg"])
+def test_part_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, record_property, F, M, seed, subtree):
+    from uuo_mocap_amd.engine import PartProblem
+
+    cfg = packaged_config("hmr_full" if subtree == "full" else "hmr_part")
+    _, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    vertex_labels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    joints = list(range(24)) if subtree == "full" else [0, 1, 4, 7, 10]      # pelvis + the left leg chain
+    vidx = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in joints], dim=0)
+    msub = markers if subtree == "full" else markers[:, : max(4, M // 5)].contiguous()
+    gen = torch.Generator().manual_seed(4)
+    z = torch.full((1, 1, 1), 0.4, requires_grad=True)
+    t = (trans + 0.02 * torch.randn(F, 3, generator=gen)).requires_grad_(True)
+    b = (o_betas + 0.3 * torch.randn(1, 10, generator=gen)).requires_grad_(True)
+    lo, out, _ = stages_ref.part_stage_loss(msub, o_pose, b, o_betas, root, t, z, vidx, oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([x.grad.reshape(-1) for x in (z, t, b)]).numpy()
+    prob = PartProblem(smpl, msub.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), vidx.to(dev), cfg)
+    assert prob.n == 3 * F + 11
+    loss, grad, nn = prob.evaluate(prob.pack(z.detach().to(dev), t.detach().to(dev), b.detach().to(dev)))
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    assert _rel_err(grad.cpu().numpy(), ref_grad) < 2e-4
+    vs = out["vertices"][:, vidx].detach().numpy()
+    _, i_ref = p3d_ref.knn1_loop(msub.numpy(), vs)
+    _check_flips(nn.cpu().numpy(), i_ref, msub.numpy(), vs, record_property, "part_%s_%dx%d" % (subtree, F, M))
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_marker_placement_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, seed):
+    """compute_nearest_points (use_mean, full): bit-exact indices against the numpy-semantics restatement at full size,
+    vertices fed from the oracle so that both sides see the same numbers."""
+    cfg = packaged_config("video_mocap")
+    seq, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    img_mask = seq.img_smpl.img_mask.clone()
+    img_mask[1::7] = False
+    one_hot = stages_ref.compute_nearest_points(markers, o_pose, o_betas, root, trans, oracle_smpl, img_mask, cfg)
+    ref_idx = torch.argmax(one_hot, dim=-1).numpy()
+    verts = oracle_smpl(poses=stages_ref.normalize_rot(o_pose), betas=o_betas.expand(F, 10),
+                        root_orient=stages_ref.normalize_rot(root), trans=trans)["vertices"]
+    idx = smpl.device_model.assign_mean_argmin(verts.to(dev), markers.to(dev), img_mask.to(dev))
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[0]
+def test_end_to_end_config0_against_the_reference_fit(smpl, oracle_smpl, golden, dev, record_property):
+    """BASELINE ``configs[0]``: 30 frames x 41 markers, ``video_mocap.yaml`` as shipped (10000-iteration budgets, 4 yaw
+    hypotheses).  tests/golden/e2e_config0.npz holds the reference's OWN ``multimodal_video_mocap`` run on these inputs
+    (oracle/make_golden_config0.py: 434 s on the CPU, 2345 closure evaluations).  Converged quantities are compared, not
+    trajectories (hard assignments make two fp32 trajectories part after some dozens of iterations: SURVEY.md section 7):
+    stage structure, every solve's starting loss where the start is determined by the inputs alone, part labels and
+    chain, the selected hypothesis' quality, and the distance between the two fitted bodies."""
+    from uuo_mocap_amd.multimodal import LAST_RUN_STATS, multimodal_video_mocap
+    from uuo_mocap_amd.synthetic import SyntheticImgSmpl, SyntheticMarkers
+
+    g = golden("e2e_config0.npz")
+    cfg = packaged_config("video_mocap")
+    F, M = g["markers"].shape[:2]
+    assert (F, M) == (30, 41)
+    t = lambda a: torch.from_numpy(np.asarray(a)).clone()
+    img = SyntheticImgSmpl(
+        trans=t(g["hmr_trans"]), root_orient=t(g["hmr_root_orient"]), hmr_root_orient=t(g["hmr_root_orient"]),
+        pose_body=t(g["hmr_pose_body"]), betas=t(g["hmr_betas"]), foot_contacts=torch.zeros(F, 2),
+        camera_bbox=torch.zeros(F, 3), center=torch.zeros(F, 2), scale=torch.zeros(F, 1), size=torch.zeros(F, 2),
+        img_mask=t(g["img_mask"]), freq=30.0)
+    out = multimodal_video_mocap(img, SyntheticMarkers(g["markers"].copy(), 30.0), dev, cfg, offset=0,
+                                 print_options=[], save_stages=True, smpl_inference=smpl)
+    st = LAST_RUN_STATS
+    ref_stage = [str(s) for s in g["solve_stage"]]
+    assert len(st["part"]) == ref_stage.count("part")
+    assert len(st["chamfer"]) == ref_stage.count("chamfer") == 4
+    assert len(st["marker"]) + len(st["marker_final"]) == ref_stage.count("marker") == 5
+    assert sorted(out["stages"].keys()) == sorted(str(s) for s in g["stage_keys"])
+    # starting losses fixed by the inputs: the part solve and the four chamfer solves (full-body input: they start from
+    # median(markers) / the HMR estimate rotated by the hypothesis' yaw, reference multimodal.py:372-375,463-470)
+    ref_first = {k: [float(v) for v, s in zip(g["first_losses"], ref_stage) if s == k] for k in ("part", "chamfer")}
+    np.testing.assert_allclose([s["first_loss"] for s in st["part"]], ref_first["part"], rtol=2e-5)
+    np.testing.assert_allclose([s["first_loss"] for s in st["chamfer"]], ref_first["chamfer"], rtol=2e-5)
+    # every solve ran to a tolerance, none hit the iteration budget
+    for k in ("part", "chamfer", "marker", "marker_final"):
+        for s in st[k]:
+            assert s["stop_reason"].startswith("tolerance") or s["stop_reason"] == "directional_derivative", s
+    np.testing.assert_array_equal(out["chain"], g["out_chain"])
+    labels_agree = float((np.asarray(out["markers_labels"]) == g["out_markers_labels"]).mean())
+    assert labels_agree >= 0.95, labels_agree
+    # the two fitted bodies
+    ref_v = oracle_smpl(t(g["out_pose_body"]), t(g["out_betas"]), t(g["out_root_orient"]), t(g["out_trans"]))["vertices"]
+    our_v = oracle_smpl(out["pose_body"], out["betas"], out["root_orient"], out["trans"])["vertices"]
+    between = (ref_v - our_v).norm(dim=-1).mean().item()
+    gt = torch.from_numpy(g["gt_verts_stride13"])
+    err_ref = (ref_v[:, ::13] - gt).norm(dim=-1).mean().item()
+    err_our = (our_v[:, ::13] - gt).norm(dim=-1).mean().item()
+    ref_final = float(g["final_losses"][-1])
+    our_final = float(st["marker_final"][-1]["final_loss"])
+    for k, v in (("between_fits_m", between), ("v2v_ref_m", err_ref), ("v2v_ours_m", err_our),
+                 ("final_marker_loss_ref", ref_final), ("final_marker_loss_ours", our_final),
+                 ("labels_agree", labels_agree),
+                 ("n_eval_ours", sum(s["n_eval"] for k2 in ("part", "chamfer", "marker", "marker_final") for s in st[k2])),
+                 ("n_eval_ref", int(g["n_evals"].sum()))):
+        record_property("config0_" + k, v)
+    print("config0: bodies %.2e m apart; error vs ground truth ref %.2e ours %.2e m; final marker loss ref %.3e ours %.3e"
+          % (between, err_ref, err_our, ref_final, our_final))
+    assert between < 2e-2, between                 # two converged fits of the same inputs
+    assert err_our < max(1.25 * err_ref, err_ref + 2e-3), (err_our, err_ref)   # no worse than the reference's own fit
+    assert our_final < max(2.0 * ref_final, 5e-5), (our_final, ref_final)
+
+
+def test_workspaces_are_evicted_and_memory_returns(tables, dev):
+    """One SmplInference fitting sequences of several different lengths (a dataset run) must not keep every (F, M)
+    workspace it ever met: at most DeviceModel.MAX_SHAPES_PER_SLOT shapes per slot stay cached, evicted workspaces are
+    freed, and closing the model returns the memory."""
+    import copy
+    import gc
+
+    from uuo_mocap_amd.multimodal import multimodal_video_mocap
+    from uuo_mocap_amd.smpl import SmplInference
+
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = 3
+    torch.cuda.synchronize(dev)
+    gc.collect()
+    free_start = torch.cuda.mem_get_info(dev)[0]
+    s2 = SmplInference(dev, tables=tables)
+    used = []
+    for F in (64, 96, 128, 160, 192):
+        seq = make_sequence(tables, seed=F, num_frames=F, num_markers=16)
+        multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                               save_stages=False, smpl_inference=s2)
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        used.append(free_start - torch.cuda.mem_get_info(dev)[0])
+        slots = {k[0] for k in s2.device_model._fits}
+        assert s2.device_model.cached_workspaces() <= len(slots) * s2.device_model.MAX_SHAPES_PER_SLOT
+    # memory follows the two most recent shapes, not the history: the fifth length costs no more than +35 % over the
+    # third although F grew by 50 % and five shapes have been seen
+    assert used[4] <= 1.6 * used[2], used
+    s2.device_model.close()
+    del s2
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    leaked = free_start - torch.cuda.mem_get_info(dev)[0]
+    assert leaked < 64 << 20, leaked   # torch's caching allocator may keep a few blocks of the fits' tensors

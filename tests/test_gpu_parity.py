@@ -294,15 +294,7 @@ def test_part_closure_matches_oracle(smpl, oracle_smpl, golden, dev, tag, cfg_na
 
 
 # ------------------------------------------------------------------------------------------------ optimiser
-@pytest.mark.parametrize("kind,n,lr", [(0, 300, 1.0), (1, 40, 1.0), (0, 5000, 0.1)])
-def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
-    """device L-BFGS against torch.optim.LBFGS (CPU) on a convex quadratic and chained Rosenbrock."""
-    import ctypes
-
-    from uuo_mocap_amd import _lib
-
-    lib = _lib.load()
-
+def _analytic_objective(kind, n):
     def objective(x):
         if kind == 0:
             a = 1.0 + 99.0 * torch.arange(n, dtype=torch.float32) / max(n - 1, 1)
@@ -310,35 +302,89 @@ def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
             return 0.5 * (a * (x - b) ** 2).sum()
         return (100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2).sum()
 
+    return objective
+
+
+def _run_both_lbfgs(dev, kind, n, lr, max_iter, tolerance_change=1e-9):
+    """torch.optim.LBFGS on the CPU and the device driver (debug library's self-test objective, same formulas) from the
+    same start: every closure evaluation's loss and point, iteration / evaluation counts, final iterates."""
+    import ctypes
+
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load_debug()
+    objective = _analytic_objective(kind, n)
     x0 = torch.full((n,), -0.5) if kind == 1 else torch.zeros(n)
     xt = x0.clone().requires_grad_(True)
-    opt = torch.optim.LBFGS([xt], max_iter=200, tolerance_grad=1e-7, tolerance_change=1e-9, lr=lr,
+    opt = torch.optim.LBFGS([xt], max_iter=max_iter, tolerance_grad=1e-7, tolerance_change=tolerance_change, lr=lr,
                             line_search_fn="strong_wolfe")
-    evals = []
+    ref = {"loss": [], "x": []}
 
     def closure():
         opt.zero_grad()
         l = objective(xt)
         l.backward()
-        evals.append(float(l))
+        ref["loss"].append(float(l))
+        ref["x"].append(xt.detach().clone().numpy())
         return l
 
     opt.step(closure)
+    ref["n_iter"] = int(opt.state[opt._params[0]]["n_iter"])
+    ref["x_final"] = xt.detach().numpy().copy()
     xd = x0.clone().to(dev).contiguous()
-    o = _lib.UuoLbfgsOptions(200, 100, lr, 1e-7, 1e-9, 0, 0)
+    o = _lib.UuoLbfgsOptions(max_iter, 100, lr, 1e-7, tolerance_change, 0, 0)
     st = _lib.UuoLbfgsStats()
-    _lib.check(lib.uuo_lbfgs_selftest(None, kind, n, ctypes.c_void_p(xd.data_ptr()), ctypes.byref(o), ctypes.byref(st)),
-               "uuo_lbfgs_selftest")
-    f_ref = objective(xt.detach()).item()
-    f_dev = objective(xd.cpu()).item()
-    assert st.first_loss == pytest.approx(evals[0], rel=1e-5)
+    got = {"loss": [], "x": []}
+
+    def on_eval(user, i, loss, d_x_eval):
+        host = np.empty(n, np.float32)
+        _lib.check(lib.uuo_copy_to_host(None, d_x_eval, host.ctypes.data, n), "uuo_copy_to_host")
+        got["loss"].append(float(loss))
+        got["x"].append(host)
+
+    cb = _lib.EVAL_CALLBACK(on_eval)
+    _lib.check(lib.uuo_lbfgs_selftest(None, kind, n, ctypes.c_void_p(xd.data_ptr()), ctypes.byref(o), ctypes.byref(st),
+                                      ctypes.cast(cb, ctypes.c_void_p), None), "uuo_lbfgs_selftest")
+    got["n_iter"], got["n_eval"] = st.n_iter, st.n_eval
+    got["x_final"] = xd.cpu().numpy()
+    return ref, got, objective
+
+
+@pytest.mark.parametrize("n,lr,tol_change", [(300, 1.0, 1e-9), (5000, 0.1, 1e-9), (300, 1.0, 1e-6), (64, 0.5, 1e-4)])
+def test_lbfgs_follows_torch_evaluation_by_evaluation_on_a_quadratic(dev, n, lr, tol_change):
+    """On a convex quadratic fp32 round-off cannot flip a line-search branch for dozens of iterations, so the device
+    driver and torch.optim.LBFGS must agree evaluation by evaluation: every trial point and loss of the first 30
+    iterations, and the same iteration / evaluation counts.  A wrong bracket / zoom branch, step guess, history update or
+    termination test shows up here.  tolerance_change != 1e-9 checks that only the OUTER tests use the optimiser's value
+    (torch's line search always runs with its own default 1e-9)."""
+    ref, got, _ = _run_both_lbfgs(dev, 0, n, lr, max_iter=30, tolerance_change=tol_change)
+    assert got["n_iter"] == ref["n_iter"], (got["n_iter"], ref["n_iter"])
+    assert got["n_eval"] == len(ref["loss"]) == len(got["loss"]), (got["n_eval"], len(ref["loss"]))
+    scale = ref["loss"][0]
+    np.testing.assert_allclose(got["loss"], ref["loss"], rtol=1e-5, atol=1e-6 * scale)
+    for k, (a, b) in enumerate(zip(got["x"], ref["x"])):
+        np.testing.assert_allclose(a, b, atol=1e-5, rtol=1e-5, err_msg="trial point of evaluation %d" % k)
+    np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind,n,lr", [(0, 300, 1.0), (1, 40, 1.0), (0, 5000, 0.1)])
+def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
+    """Run to convergence (200 iterations): same minimiser, same work.  The chained Rosenbrock valley is where the two
+    fp32 trajectories may part after a few dozen evaluations, so its early evaluations are compared one by one and its
+    end state by value."""
+    ref, got, objective = _run_both_lbfgs(dev, kind, n, lr, max_iter=200)
+    f_ref = objective(torch.from_numpy(ref["x_final"])).item()
+    f_dev = objective(torch.from_numpy(got["x_final"])).item()
+    assert got["loss"][0] == pytest.approx(ref["loss"][0], rel=1e-6)
+    head = min(20, len(ref["loss"]), len(got["loss"]))
+    np.testing.assert_allclose(got["loss"][:head], ref["loss"][:head], rtol=1e-4)
     if kind == 0:
-        assert f_dev <= max(f_ref * 10, 1e-6), (f_dev, f_ref)
-        np.testing.assert_allclose(xd.cpu().numpy(), xt.detach().numpy(), atol=2e-3)
+        assert got["n_iter"] == ref["n_iter"] and got["n_eval"] == len(ref["loss"])
+        assert f_dev <= max(f_ref * 1.5, 1e-7), (f_dev, f_ref)
+        np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=2e-4)
     else:
         assert f_dev <= max(5 * f_ref, 1e-3), (f_dev, f_ref)
-    # same algorithm -> comparable work
-    assert st.n_eval <= 2 * len(evals) + 10, (st.n_eval, len(evals))
+        assert abs(got["n_eval"] - len(ref["loss"])) <= max(10, len(ref["loss"]) // 4), (got["n_eval"], len(ref["loss"]))
 
 
 def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
@@ -538,12 +584,10 @@ def _closure_buffers(prob, F, V):
 
     from uuo_mocap_amd import _lib
 
-    lib = _lib.load()
+    lib = _lib.load_debug()  # read-back hook of the debug flavour; the workspace itself belongs to the product library
     nur = (V + 15) // 16
     verts = np.zeros((F, V, 3), np.float32)
     bbox = np.zeros((F, nur, 6), np.float32)
-    lib.uuo_debug_fit_buffers.restype = ctypes.c_int
-    lib.uuo_debug_fit_buffers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     torch.cuda.synchronize()
     assert lib.uuo_debug_fit_buffers(prob.fit, verts.ctypes.data, bbox.ctypes.data) == 0
     return verts, bbox
@@ -597,6 +641,8 @@ def test_skin_kernel_variants_agree_bitwise(smpl, dev, tmp_path):
     code = (
         "import numpy as np, torch, sys\n"
         "sys.path.insert(0, %r)\n"
+        "from uuo_mocap_amd import _lib\n"
+        "_lib.LIB_PATH = _lib.LIB_DEBUG_PATH  # the kernel-variant knob exists in the debug flavour only\n"
         "from uuo_mocap_amd.body_model import synthetic_smpl\n"
         "from uuo_mocap_amd.smpl import SmplInference\n"
         "d = np.load(%r)\n"
@@ -646,9 +692,7 @@ def test_direction_coefficients_block_inverse_vs_serial(dev, k):
 
     from uuo_mocap_amd import _lib
 
-    lib = _lib.load()
-    lib.uuo_debug_small_coeffs.restype = ctypes.c_int
-    lib.uuo_debug_small_coeffs.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib = _lib.load_debug()
     for seed in (1, 7):
         ref = np.zeros(209)
         new = np.zeros(209)

@@ -70,13 +70,21 @@ _SIGNATURES = {
     "uuo_time_closure": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_int, c_int,
                                  POINTER(c_float)]),
 }
-# not in the public header: optimiser self-test hook used by tests/test_lbfgs.py
-_EXTRA_SIGNATURES = {
+# libuuo_hip_debug.so only (same sources built with -DUUO_DEBUG_HOOKS; loaded by tests/ and tools/, never by the
+# package): the optimiser self-test on analytic objectives (tests/test_gpu_parity.py::test_lbfgs_*), buffer read-backs,
+# kernel-variant knobs.  The shipped library exports include/uuo_hip.h and nothing else and reads no environment variable.
+LIB_DEBUG_PATH = os.path.join(_HERE, "libuuo_hip_debug.so")
+_DEBUG_SIGNATURES = {
     "uuo_lbfgs_selftest": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(UuoLbfgsOptions),
-                                   POINTER(UuoLbfgsStats)]),
+                                   POINTER(UuoLbfgsStats), c_void_p, c_void_p]),
+    "uuo_debug_fit_buffers": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "uuo_debug_nn_flags": (c_int, [c_void_p, c_void_p]),
+    "uuo_debug_small_coeffs": (c_int, [c_int, c_int, c_int, c_void_p]),
+    "uuo_debug_time_small": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }
 
 _lib = None
+_lib_debug = None
 
 
 def header_symbols():
@@ -99,11 +107,27 @@ def load():
     for name in header_symbols():
         if not hasattr(lib, name):
             raise RuntimeError("libuuo_hip.so does not export %s declared in include/uuo_hip.h" % name)
-    for name, (res, args) in list(_SIGNATURES.items()) + list(_EXTRA_SIGNATURES.items()):
+    for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_debug():
+    """The debug flavour of the library (tests/ and tools/ only): every public symbol plus the hooks above."""
+    global _lib_debug
+    if _lib_debug is not None:
+        return _lib_debug
+    if not os.path.isfile(LIB_DEBUG_PATH):
+        raise RuntimeError("libuuo_hip_debug.so is missing (%s): run `python __graft_entry__.py`" % LIB_DEBUG_PATH)
+    lib = ctypes.CDLL(LIB_DEBUG_PATH)
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_DEBUG_SIGNATURES.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib_debug = lib
     return lib
 
 

@@ -862,7 +862,7 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
   const uuo_model* m = fit->model;
   int rc = 0;
-  static const int no_cache = getenv("UUO_PART_NOCACHE") ? atoi(getenv("UUO_PART_NOCACHE")) : 0;  // comparison only
+  static const int no_cache = UUO_ENV_INT("UUO_PART_NOCACHE", 0);  // comparison only
   const bool cached = p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && m->nnz <= 4 && !no_cache;
   if (cached && fit->pose_cache_id != p->pose_cache_id) {
     // first evaluation of a solve whose body pose is constant: C = v_t + P . feat through the MFMA kernel with zero
@@ -942,7 +942,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.g_trans = d_grad + lay.off_trans;
   a.frame_part = fit->frame_part;
   a.frames = (p->stage == UUO_STAGE_MARKER) ? nullptr : fit->frames;
-  static const int bwd_stop = getenv("UUO_BWD_STOP") ? atoi(getenv("UUO_BWD_STOP")) : 0;
+  static const int bwd_stop = UUO_ENV_INT("UUO_BWD_STOP", 0);
   a.stop = bwd_stop;
   a.dir = d_dir;
   a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
@@ -1033,6 +1033,7 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   return 0;
 }
 
+#ifdef UUO_DEBUG_HOOKS
 // debug/test hook (not in the public header): survivor counts of the last pruned nearest-neighbour search
 extern "C" int uuo_debug_nn_flags(uuo_fit_t* fit, int* h_out) {
   UUO_REQUIRE(fit && h_out, "uuo_debug_nn_flags: null argument");
@@ -1049,6 +1050,8 @@ extern "C" int uuo_debug_fit_buffers(uuo_fit_t* fit, float* h_verts, float* h_bb
     UUO_HIP_CHECK(hipMemcpy(h_bbox, fit->bbox, (size_t)fit->F * ((fit->model->V + 15) / 16) * 6 * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
+
+#endif  // UUO_DEBUG_HOOKS
 
 
 // ----------------------------------------------------------------------------------------------------

@@ -699,7 +699,7 @@ static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const fl
 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
                     float* verts, float* bbox) {
-  static const int force_v1 = getenv("UUO_SKIN_V1") ? atoi(getenv("UUO_SKIN_V1")) : 0;  // ablation / comparison only
+  static const int force_v1 = UUO_ENV_INT("UUO_SKIN_V1", 0);  // ablation / comparison only
   const int nur = (m->V + 15) / 16;  // units with vertices = stride of the box table
   const int npos = 1 << SK2_NPOS_LOG2;  // 8 XCDs x 32 CUs, one 8-wave block per CU
   if (m->nnz > 4 || force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
@@ -713,7 +713,7 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
     const float* pA = A + (size_t)f0 * UUO_NUM_JOINTS * 12;
     const float* pt = trans ? trans + (size_t)f0 * 3 : nullptr;
     float* pv = verts + (size_t)f0 * m->V * 3;
-    static const int var2 = getenv("UUO_SK2_VAR") ? atoi(getenv("UUO_SK2_VAR")) : 0;  // ablation (timing) only
+    static const int var2 = UUO_ENV_INT("UUO_SK2_VAR", 0);  // ablation (timing) only
 #define SK2_LAUNCH(BB, VAR)                                                                             \
   hipLaunchKernelGGL((k_skin2<BB, VAR>), dim3(8 * npos), dim3(SKIN_WAVES * 64), 0, s,                   \
                      reinterpret_cast<const float4*>(m->P3), m->vt3, m->Wi, m->Ww, pf, pA, pt, pv,      \
@@ -736,23 +736,25 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
   return 0;
 }
 
+#ifdef UUO_DEBUG_HOOKS
 extern "C" int uuo_debug_skin_stamps(unsigned long long* h_out) {  // 2048 waves x 8 stamps (UUO_SK2_VAR=9)
   UUO_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sk2_stamps), sizeof(unsigned long long) * 2048 * 16));
   return 0;
 }
+#endif  // UUO_DEBUG_HOOKS
 
 static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                               const float* trans, float* verts, float* bbox) {
   const int nFT = (F + UUO_FT - 1) / UUO_FT;
   const int nunits = m->VP / 16;
   // vertex ranges per frame tile: one resident round of <= 256 blocks, every wave gets at least one unit
-  static const int slots = getenv("UUO_SKIN_SLOTS") ? atoi(getenv("UUO_SKIN_SLOTS")) : 256;
+  static const int slots = UUO_ENV_INT("UUO_SKIN_SLOTS", 256);
   int nVB = slots / nFT;
   const int maxVB = (nunits + SKIN_WAVES - 1) / SKIN_WAVES;
   if (nVB > maxVB) nVB = maxVB;
   if (nVB < 1) nVB = 1;
   const int nblocks = nFT * nVB;
-  static const int variant = getenv("UUO_SKIN_VARIANT") ? atoi(getenv("UUO_SKIN_VARIANT")) : 0;  // ablation only
+  static const int variant = UUO_ENV_INT("UUO_SKIN_VARIANT", 0);  // ablation only
 #define SKIN_LAUNCH(SP, VAR)                                                                                     \
   hipLaunchKernelGGL((k_skin<SP, VAR>), dim3(nblocks), dim3(SKIN_WAVES * 64), 0, s, m->P3, m->vt3, m->Wi, m->Ww, \
                      m->W, pfaT, A, trans, verts, bbox, F, m->V, m->VP, nFT, nVB, nblocks)
@@ -884,25 +886,32 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   UUO_REQUIRE(d_verts != nullptr, "uuo_smpl_forward: d_verts is required (joints 24..44 are picked from it)");
   hipStream_t s = (hipStream_t)stream;
   const int nFT = (F + UUO_FT - 1) / UUO_FT;
-  uuo_model::FwdScratch sc;
+  // Scratch (operand tiles, skinning matrices, posed joints) is kept per stream.  torch hands out stream handles from a
+  // small pool, so two host threads may hold the same hipStream_t: the entry's own mutex is held across the reallocation
+  // AND the three launches, so the two callers' launch sequences never interleave on the shared buffers (in-stream
+  // order then makes the reuse safe), and nobody keeps a copy of pointers another caller may free.
+  uuo_model::FwdScratch* scp;
   {
     std::lock_guard<std::mutex> lock(m->fwd_mutex);
-    uuo_model::FwdScratch& ref = m->fwd[s];
-    if (ref.cap < nFT) {
-      if (ref.pfaT) (void)hipFree(ref.pfaT);
-      if (ref.A) (void)hipFree(ref.A);
-      if (ref.jp) (void)hipFree(ref.jp);
-      ref = uuo_model::FwdScratch();
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
-      UUO_HIP_CHECK(hipMalloc((void**)&ref.jp, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 3 * sizeof(float)));
-      // on the caller's stream: a null-stream memset is not ordered with torch's non-blocking streams and could land
-      // after the first pose_prep has written the tiles
-      UUO_HIP_CHECK(hipMemsetAsync(ref.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float), s));
-      UUO_HIP_CHECK(hipMemsetAsync(ref.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float), s));
-      ref.cap = nFT;
-    }
-    sc = ref;
+    scp = &m->fwd[s];  // std::map nodes never move
+  }
+  uuo_model::FwdScratch& sc = *scp;
+  std::lock_guard<std::mutex> entry_lock(sc.mu);
+  if (sc.cap < nFT) {
+    // hipFree waits for the device, so kernels of an earlier call that still read the old buffers have finished
+    if (sc.pfaT) (void)hipFree(sc.pfaT);
+    if (sc.A) (void)hipFree(sc.A);
+    if (sc.jp) (void)hipFree(sc.jp);
+    sc.pfaT = sc.A = sc.jp = nullptr;
+    sc.cap = 0;
+    UUO_HIP_CHECK(hipMalloc((void**)&sc.pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
+    UUO_HIP_CHECK(hipMalloc((void**)&sc.A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
+    UUO_HIP_CHECK(hipMalloc((void**)&sc.jp, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 3 * sizeof(float)));
+    // on the caller's stream: a null-stream memset is not ordered with torch's non-blocking streams and could land
+    // after the first pose_prep has written the tiles
+    UUO_HIP_CHECK(hipMemsetAsync(sc.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float), s));
+    UUO_HIP_CHECK(hipMemsetAsync(sc.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float), s));
+    sc.cap = nFT;
   }
   UuoPoseSrc src;
   src.body = d_poses;

@@ -1349,7 +1349,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   // Stage closures report through pinned memory: their finalize kernel copies the read-back block into w->h_out and
   // then publishes a sequence number that this thread polls -- no copy command, no stream synchronisation.  A stuck
   // or failed stream is caught by a periodic hipStreamQuery.
-  static const int poll_mode = getenv("UUO_LBFGS_POLL") ? atoi(getenv("UUO_LBFGS_POLL")) : 1;
+  static const int poll_mode = UUO_ENV_INT("UUO_LBFGS_POLL", 1);
+  // the slowest evaluation of the path (first closure at F = 3000) is ~10 ms; a minute means the device is gone
+  const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
   unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(w->h_out);
   auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
     const float* dir = with_dir ? d : (const float*)nullptr;
@@ -1362,14 +1364,27 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr, poll ? &rep : nullptr);
     if (rc) return rc;
     if (poll) {
+      // Bounded wait: the report word is polled; every ~1M polls the stream is queried (a failed or drained stream that
+      // never reported is an error) and the wall clock is checked against eval_timeout_s -- a kernel that never finishes
+      // must not pin this host thread for ever.
       unsigned long spins = 0;
+      timespec t_start;
+      clock_gettime(CLOCK_MONOTONIC, &t_start);
       while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
         __builtin_ia32_pause();
-        if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls: has the stream died or drained without reporting?
+        if ((++spins & 0xFFFFF) == 0) {
           const hipError_t q = hipStreamQuery(s);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
             uuo_set_error(std::string("lbfgs: closure evaluation did not report: ") + hipGetErrorString(q));
             return -5;
+          }
+          timespec t_now;
+          clock_gettime(CLOCK_MONOTONIC, &t_now);
+          const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
+          if (waited > eval_timeout_s) {
+            uuo_set_error("lbfgs: closure evaluation " + std::to_string(evals_total) + " did not finish within " +
+                          std::to_string((int)eval_timeout_s) + " s (stream still busy); giving up on the solve");
+            return -62;  // -ETIME
           }
         }
       }
@@ -1433,9 +1448,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         const int nrows = 2 * (count + 1) + 1;
         hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, LB_DRS), dim3(256), 0, s, n, cap, w->cap, head, count, cand, w->S,
                            w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part);
-        static const int small_stop = getenv("UUO_SMALL_STOP") ? atoi(getenv("UUO_SMALL_STOP")) : 0;  // ablation only
-        static const int small_ref = getenv("UUO_SMALL_REF") ? atoi(getenv("UUO_SMALL_REF")) : 0;  // comparison only
-        static const int small_block = getenv("UUO_SMALL_BLOCK") ? atoi(getenv("UUO_SMALL_BLOCK")) : 0;  // comparison only
+        static const int small_stop = UUO_ENV_INT("UUO_SMALL_STOP", 0);  // ablation only
+        static const int small_ref = UUO_ENV_INT("UUO_SMALL_REF", 0);  // comparison only
+        static const int small_block = UUO_ENV_INT("UUO_SMALL_BLOCK", 0);  // comparison only
         if (small_ref)
           hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         else if (small_block)
@@ -1558,7 +1573,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         high_pos = 0;
       }
       while (!done && ls_iter < max_ls) {
-        if (std::fabs(br[1].t - br[0].t) * d_norm < tol_change) break;
+        // torch 2.10's LBFGS.step does not hand its tolerance_change to _strong_wolfe (lbfgs.py:486-488): the line
+        // search always uses that function's default, 1e-9
+        if (std::fabs(br[1].t - br[0].t) * d_norm < 1e-9) break;
         double tz = cubic_interpolate(br[0].t, br[0].f, br[0].gtd, br[1].t, br[1].f, br[1].gtd, false, 0, 0);
         const double bmax = std::fmax(br[0].t, br[1].t), bmin = std::fmin(br[0].t, br[1].t);
         const double eps = 0.1 * (bmax - bmin);
@@ -1736,11 +1753,19 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve: max_iter must be positive");
   hipStream_t s = (hipStream_t)stream;
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  // The optimiser's workspace (history S, Y: 2 x (hist+1) x n floats, 53 MB at n = 65 710) is sized for THIS problem,
+  // not for the largest stage of the sequence: a workspace that only ever solves the part stage (n = 3F + 11) stays
+  // ~70x smaller.  It is re-created only when the parameter count or the history grows.
+  const int n_params = uuo_problem_num_params(p);
   LbWs* w = (LbWs*)fit->lbws;
-  if (!w || w->cap < hist + 1) {
-    if (w) lbws_destroy(w);
+  if (!w || w->cap < hist + 1 || w->n_cap < n_params) {
+    const int keep_hist = w ? std::max(hist, w->cap - 1) : hist;
+    if (w) {
+      UUO_HIP_CHECK(hipStreamSynchronize(s));
+      lbws_destroy(w);
+    }
     fit->lbws = nullptr;
-    rc = lbws_create(fit->n_max, hist, &w);
+    rc = lbws_create(n_params, keep_hist, &w);
     if (rc) return rc;
     fit->lbws = w;
   }
@@ -1764,9 +1789,12 @@ extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, 
   return 0;
 }
 
-// optimiser self-test on analytic objectives (tests/test_lbfgs.py compares with torch.optim.LBFGS on the CPU)
+#ifdef UUO_DEBUG_HOOKS
+// ---- everything below exists only in libuuo_hip_debug.so (tests/ and tools/) ------------------------------------------
+// optimiser self-test on analytic objectives (tests/test_gpu_parity.py::test_lbfgs_* compare with torch.optim.LBFGS on
+// the CPU, evaluation by evaluation through `cb`)
 extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, const uuo_lbfgs_options_t* opt,
-                                  uuo_lbfgs_stats_t* stats) {
+                                  uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
   UUO_REQUIRE(d_x && opt && stats && n > 0 && (kind == 0 || kind == 1), "uuo_lbfgs_selftest: bad arguments");
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
   LbWs* w = nullptr;
@@ -1776,7 +1804,7 @@ extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, con
   obj.kind = kind;
   obj.n = n;
   std::memset(stats, 0, sizeof(*stats));
-  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, nullptr, nullptr);
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, cb, cb_user);
   lbws_destroy(w);
   return rc;
 }
@@ -1915,3 +1943,4 @@ extern "C" int uuo_debug_small_coeffs(int k, int use_ref, int seed, double* out)
   lbws_destroy(w);
   return 0;
 }
+#endif  // UUO_DEBUG_HOOKS

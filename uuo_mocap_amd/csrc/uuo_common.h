@@ -16,6 +16,16 @@
 
 void uuo_set_error(const std::string& msg);
 
+// Ablation / comparison knobs (kernel variants, phase cut-offs) and the uuo_debug_* hooks exist only in the debug
+// flavour of the library (libuuo_hip_debug.so, built with -DUUO_DEBUG_HOOKS and loaded by tests/ and tools/ only).
+// The shipped libuuo_hip.so reads no environment variable and exports nothing outside include/uuo_hip.h.
+#ifdef UUO_DEBUG_HOOKS
+#include <cstdlib>
+#define UUO_ENV_INT(name, dflt) (std::getenv(name) ? std::atoi(std::getenv(name)) : (dflt))
+#else
+#define UUO_ENV_INT(name, dflt) (dflt)
+#endif
+
 #define UUO_HIP_CHECK(expr)                                                                      \
   do {                                                                                           \
     hipError_t _e = (expr);                                                                      \
@@ -62,8 +72,9 @@ struct uuo_model {
   float* Ww = nullptr;    // [VP][4]
   UuoTree* tree = nullptr;  // device copy
   UuoTree h_tree;
-  // scratch of uuo_smpl_forward, one set per stream so concurrent callers (one host thread per stream) never share
+  // scratch of uuo_smpl_forward, one set per stream; `mu` serialises callers that hold the same stream handle
   struct FwdScratch {
+    std::mutex mu;
     int cap = 0;
     float* pfaT = nullptr;
     float* A = nullptr;

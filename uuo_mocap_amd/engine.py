@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import itertools
 import threading
+from collections import OrderedDict
 from ctypes import byref, c_float, c_void_p
 from typing import Callable, Dict, Optional
 
@@ -71,6 +72,23 @@ def current_stream(device) -> c_void_p:
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _FitHandle:
+    """Owner of one uuo_fit_t.  Problems hold a reference for as long as they may launch on the workspace; the
+    workspace is destroyed (uuo_fit_destroy: hipFree waits for the device) when the last reference goes."""
+
+    def __init__(self, lib, ptr: c_void_p, device):
+        self._lib, self.ptr, self._device = lib, ptr, device
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                with torch.cuda.device(self._device):
+                    self._lib.uuo_fit_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class DeviceModel:
     """Owns a uuo_model_t (device copies of the SMPL tables) and the per-(F, M) fit workspaces."""
 
@@ -89,23 +107,42 @@ class DeviceModel:
         with torch.cuda.device(self.device):
             check(self.lib.uuo_model_create(*[a.ctypes.data for a in arrs], self.V, byref(handle)), "uuo_model_create")
         self.handle = handle
-        self._fits: Dict = {}
+        self._fits: "OrderedDict" = OrderedDict()   # (slot, F, M) -> _FitHandle, least recently used first
         self._fits_lock = threading.Lock()
 
-    def fit(self, F: int, M: int) -> c_void_p:
-        key = (int(F), int(M), workspace_slot())
+    #: sequence shapes (F, M) whose workspaces stay cached per slot.  A dataset of sequences of many different lengths
+    #: fitted through one SmplInference would otherwise keep every (F, M) workspace it ever met (F*V*3 vertex floats +
+    #: the optimiser's history each) until hipMalloc fails.
+    MAX_SHAPES_PER_SLOT = 2
+
+    def fit(self, F: int, M: int) -> "_FitHandle":
+        """The calling thread's workspace for sequences of F frames x M markers (created on first use).  The returned
+        handle keeps the workspace alive: the cache holds the MAX_SHAPES_PER_SLOT most recently used shapes of every
+        slot, an evicted workspace is destroyed when the last problem that uses it is gone."""
+        slot = workspace_slot()
+        key = (slot, int(F), int(M))
         with self._fits_lock:
-            if key not in self._fits:
-                h = c_void_p()
-                with torch.cuda.device(self.device):
-                    check(self.lib.uuo_fit_create(self.handle, key[0], key[1], byref(h)), "uuo_fit_create")
-                self._fits[key] = h
-            return self._fits[key]
+            h = self._fits.get(key)
+            if h is not None:
+                self._fits.move_to_end(key)
+                return h
+            ptr = c_void_p()
+            with torch.cuda.device(self.device):
+                check(self.lib.uuo_fit_create(self.handle, key[1], key[2], byref(ptr)), "uuo_fit_create")
+            h = _FitHandle(self.lib, ptr, self.device)
+            self._fits[key] = h
+            same_slot = [k for k in self._fits if k[0] == slot]
+            for k in same_slot[:max(0, len(same_slot) - self.MAX_SHAPES_PER_SLOT)]:
+                del self._fits[k]  # the handle frees the workspace once no problem references it any more
+            return h
+
+    def cached_workspaces(self) -> int:
+        with self._fits_lock:
+            return len(self._fits)
 
     def close(self):
-        for h in self._fits.values():
-            self.lib.uuo_fit_destroy(h)
-        self._fits = {}
+        with self._fits_lock:
+            self._fits.clear()
         if self.handle:
             self.lib.uuo_model_destroy(self.handle)
             self.handle = None
@@ -233,7 +270,8 @@ class _StageProblem:
         self.root = _f32(root, "root_orient").reshape(self.F, 9) if root is not None else None
         self.assign = assign.to(device=self.device, dtype=torch.int32).contiguous() if assign is not None else None
         self.subset = subset.to(device=self.device, dtype=torch.int32).contiguous() if subset is not None else None
-        self.fit = model.fit(self.F, self.M)
+        self._fit_ref = model.fit(self.F, self.M)  # keeps the workspace alive while this problem exists
+        self.fit = self._fit_ref.ptr
         p = UuoProblem()
         p.stage, p.F, p.M = self.stage, self.F, self.M
         p.d_markers = self.markers.data_ptr()

@@ -278,6 +278,7 @@ def find_best_part_fits(
             stats = prob.solve(x, max_iter=st["num_iters"], lr=1.0,
                                tolerance_grad=config["optimizer"]["tolerance_grad"],
                                tolerance_change=config["optimizer"]["tolerance_change"], point_callback=point_cb)
+            stats["n_subset"], stats["n_markers"] = int(vertex_indices.numel()), int(markers_subset.shape[1])
             z_angle, trans, betas_s = prob.unpack(x)
             with torch.no_grad():
                 z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
