@@ -59,8 +59,23 @@ struct BwdArgs {
 // Phase 2: joints on lanes -- A -> G, reverse kinematic sweep (parents pull from children in a fixed
 // order, so the result is deterministic), Gram-Schmidt backward, priors, parameter gradients.
 // ----------------------------------------------------------------------------------------------------
-#define BWD_SLOTS 16  // (wave, 16-lane group) pairs: items in flight per block
-#define BWD_NW 4  // waves per frame block (8 waves needs <= 128 VGPRs for 2 blocks/CU and spills: 43 -> 73 us)
+#ifdef UUO_DEBUG_HOOKS
+// debug flavour only: shader-clock stamps of wave 0 at the phase boundaries of bwd_body (tools/bwd_phases.py --stamps)
+#define BWD_NSTAMP 12
+__device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
+#define BWD_STAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (a.stop == 9 && threadIdx.x == 0 && blockIdx.x < 4096)                                                 \
+      g_bwd_stamps[blockIdx.x * BWD_NSTAMP + (i)] = __builtin_amdgcn_s_memtime();                              \
+  } while (0)
+#else
+#define BWD_STAMP(i) do {} while (0)
+#endif
+#define BWD_NW 4  // waves per frame block: one per SIMD, so up to three blocks share a CU at 168 VGPRs.  (6 waves -- 24 item
+                  // slots, 3 rounds for M = 50 instead of 4 -- place 2,2,1,1 waves on the SIMDs and a second block no longer
+                  // fits at 3 waves per SIMD: 300 blocks then run in two rounds on 256 CUs, 24.8 -> 38.5 us.  8 waves need
+                  // <= 128 VGPRs for two blocks per CU and spill: 43 -> 73 us.)
+#define BWD_SLOTS (BWD_NW * 4)  // (wave, 16-lane group) pairs: items in flight per block
 template <bool SPARSE>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   __builtin_amdgcn_s_setprio(2);  // latency-bound kernel: do not queue behind co-resident MFMA waves
@@ -76,10 +91,23 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   __shared__ float sdGR[UUO_NUM_JOINTS][9], sdGt[UUO_NUM_JOINTS][3], sdJ[UUO_NUM_JOINTS][3], sdR[UUO_NUM_JOINTS][9];
   __shared__ float spsq[UUO_NUM_JOINTS];
   __shared__ float sstat[28][4];  // per writer: g.d, sum|g|, g.g, max|g| (0..22 body joints, 23 root/z, 24..26 transl)
+  __shared__ int s_lvl_n[UUO_MAX_DEPTH], s_lvl_j[UUO_MAX_DEPTH][UUO_LEVEL_W], s_lvl_p[UUO_MAX_DEPTH][UUO_LEVEL_W];
+  __shared__ int s_nch[UUO_NUM_JOINTS], s_ch[UUO_NUM_JOINTS][4];
 
   const int f = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int F = a.F, M = a.M;
+  BWD_STAMP(0);
+  {  // the tree's tables for the kinematic tail: fetched now (one round trip hidden behind the item loop), read from LDS there
+    const UuoTree* tr_ = a.tree;
+    if (tid < UUO_MAX_DEPTH) s_lvl_n[tid] = tr_->level_n[tid];
+    if (tid < UUO_MAX_DEPTH * UUO_LEVEL_W) {
+      (&s_lvl_j[0][0])[tid] = (&tr_->level_j[0][0])[tid];
+      (&s_lvl_p[0][0])[tid] = (&tr_->level_p[0][0])[tid];
+    }
+    if (tid >= 64 && tid < 64 + UUO_NUM_JOINTS) s_nch[tid - 64] = tr_->nchild[tid - 64];
+    if (tid >= 128 && tid < 128 + UUO_NUM_JOINTS * 4) (&s_ch[0][0])[tid - 128] = (&tr_->child[0][0])[tid - 128];
+  }
   if (a.frames) {  // block-uniform
     constexpr int NW = sizeof(FrameLds) / 4;
     float* dst_l = reinterpret_cast<float*>(&L);
@@ -98,12 +126,17 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     spf[tid] = v;
   }
   for (int i = tid; i < BWD_SLOTS * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
-  for (int i = tid; i < BWD_SLOTS * UUO_KB; i += BWD_NW * 64) (&w_dpf[0][0])[i] = 0.f;
-  for (int i = tid; i < BWD_SLOTS * 16; i += BWD_NW * 64) (&w_red[0][0])[i] = 0.f;
+  // w_dpf is written whole by plain stores at the end of the item loop; w_red's used entries likewise (sparse path: every
+  // slot stores its 14 sums; dense path: waves 0..3 store theirs, the other slots must read as zero)
+  if constexpr (!SPARSE) {
+    for (int i = tid; i < BWD_SLOTS * UUO_KB; i += BWD_NW * 64) (&w_dpf[0][0])[i] = 0.f;
+    for (int i = tid; i < BWD_SLOTS * 16; i += BWD_NW * 64) (&w_red[0][0])[i] = 0.f;
+  }
   if (tid < 28 * 4) (&sstat[0][0])[tid] = 0.f;
   __syncthreads();
 
   if (a.stop == 1) return;
+  BWD_STAMP(1);
   float tr[3] = {0.f, 0.f, 0.f};
   if (a.src.trans) {
     tr[0] = a.src.trans[(size_t)f * 3];
@@ -448,8 +481,10 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   }
 
   if (a.stop == 2) return;
+  BWD_STAMP(2);
   // ---- block reduction over the accumulation slots (fixed order -> deterministic)
   __syncthreads();
+  BWD_STAMP(3);
   if (tid < UUO_KB) {
     float acc = w_dpf[0][tid];
 #pragma unroll
@@ -471,74 +506,101 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   __syncthreads();
 
   if (a.stop == 3) return;
-  // ---- phase 2: joints on lanes
+  BWD_STAMP(4);
+  // ---- phase 2: the kinematic chain backwards.  Entries 0..8 of a joint are the 3x3 of dG_j^R, entries 9..11 the 3 of
+  // dG_j^t.  The tree is swept leaves -> root one depth per step: wave 0 holds the (joint, entry) pairs of the parents at
+  // depth d and PULLS their children's finished totals in ascending child order (no float atomics: bit-reproducible),
+  // wave 1 holds the pairs of the children at depth d + 1 and turns the same finished totals into the local-rotation
+  // gradient dR_c = G_p^R^T dG_c^R and the joint gradients.  SMPL has <= 5 joints per level, so each role fits 60 lanes.
+  // Each pair's arithmetic is what the 24-lane version did serially (same operands, same order): bit-identical to it; a
+  // step is two LDS round trips and a few FMAs instead of hundreds of dependent instructions on one lane.
   const UuoTree* tree = a.tree;
   const int j = tid;
-  if (j < UUO_NUM_JOINTS) {
-    float dAt[3] = {sdA[j * 12 + 3], sdA[j * 12 + 7], sdA[j * 12 + 11]};
+  // this thread's rotation inputs for the epilogue: issued here so their round trip overlaps the sweep
+  float raw_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, po_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j >= 1 && j < UUO_NUM_JOINTS && a.g_pose) {
+    const float* pr = a.raw_pose + ((size_t)f * 23 + (j - 1)) * 9;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int e = 0; e < 9; ++e) raw_pre[e] = pr[e];
+    if (a.cpose != 0.f) {
+      const float* po = a.o_pose + ((size_t)f * 23 + (j - 1)) * 9;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sdGR[j][r * 3 + c] = sdA[j * 12 + r * 4 + c] - dAt[r] * L.J[j][c];
-      // joints 0..23 of SMPL.forward are the world translations G_j^t (+ transl): their upstream gradient enters here
-      const float uj = (a.stage == UUO_STAGE_UPSTREAM && a.up_joints) ? a.up_joints[((size_t)f * 45 + j) * 3 + r] : 0.f;
-      sdGt[j][r] = dAt[r] + uj;
+      for (int e = 0; e < 9; ++e) po_pre[e] = po[e];
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      sdJ[j][c] = -(fmaf(L.GR[j][6 + c], dAt[2], fmaf(L.GR[j][3 + c], dAt[1], L.GR[j][c] * dAt[0])));
+  }
+  for (int t = tid; t < UUO_NUM_JOINTS * 12; t += BWD_NW * 64) {  // 288 pairs on 256 threads
+    const int jj = t / 12, e = t - jj * 12;
+    if (e < 9) {
+      const int r = e / 3, c = e - r * 3;
+      sdGR[jj][e] = sdA[jj * 12 + r * 4 + c] - sdA[jj * 12 + r * 4 + 3] * L.J[jj][c];
+    } else {
+      const int r = e - 9;
+      // joints 0..23 of SMPL.forward are the world translations G_j^t (+ transl): their upstream gradient enters here
+      const float uj = (a.stage == UUO_STAGE_UPSTREAM && a.up_joints) ? a.up_joints[((size_t)f * 45 + jj) * 3 + r] : 0.f;
+      const float dAt0 = sdA[jj * 12 + 3], dAt1 = sdA[jj * 12 + 7], dAt2 = sdA[jj * 12 + 11];
+      sdGt[jj][r] = sdA[jj * 12 + r * 4 + 3] + uj;
+      sdJ[jj][r] = -(fmaf(L.GR[jj][6 + r], dAt2, fmaf(L.GR[jj][3 + r], dAt1, L.GR[jj][r] * dAt0)));
+    }
   }
   __syncthreads();
-  const int my_depth = (j < UUO_NUM_JOINTS) ? tree->depth[j] : -1;
-  for (int d = tree->max_depth - 1; d >= 0; --d) {
-    if (my_depth == d) {
-      const int nch = tree->nchild[j];
-      for (int ci = 0; ci < nch; ++ci) {
-        const int c = tree->child[j][ci];
-        float dGRc[9], dGtc[3], Rc[9];
+  BWD_STAMP(5);
+  {
+    const int role = tid >> 6;             // 0: parents of the step, 1: children of the step
+    const int rl = tid & 63, k = rl / 12, e = rl - k * 12;
+    const int max_depth = tree->max_depth;
+    for (int d = max_depth - 1; d >= 0; --d) {
+      if (role == 0 && rl < 12 * UUO_LEVEL_W && k < s_lvl_n[d]) {  // pull from the children (depth d + 1, totals final)
+        const int jj = s_lvl_j[d][k];
+        const int nch = s_nch[jj];
+        const int c0 = s_ch[jj][0], c1 = s_ch[jj][1], c2 = s_ch[jj][2], c3 = s_ch[jj][3];
+        if (e < 9) {
+          const int r = e / 3, aa = e - r * 3;
+          float acc = sdGR[jj][e];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
-          dGRc[e] = sdGR[c][e];
-          Rc[e] = L.R[c][e];
-        }
-#pragma unroll
-        for (int e = 0; e < 3; ++e) dGtc[e] = sdGt[c][e];
-        // dR_c = G_j^R^T dG_c^R
-#pragma unroll
-        for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb)
-            sdR[c][aa * 3 + bb] =
-                fmaf(L.GR[j][6 + aa], dGRc[6 + bb], fmaf(L.GR[j][3 + aa], dGRc[3 + bb], L.GR[j][aa] * dGRc[bb]));
-        const float rel[3] = {L.J[c][0] - L.J[j][0], L.J[c][1] - L.J[j][1], L.J[c][2] - L.J[j][2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-          for (int aa = 0; aa < 3; ++aa) {
-            float add = fmaf(dGRc[r * 3 + 2], Rc[aa * 3 + 2], fmaf(dGRc[r * 3 + 1], Rc[aa * 3 + 1], dGRc[r * 3] * Rc[aa * 3]));
-            add = fmaf(dGtc[r], rel[aa], add);
-            sdGR[j][r * 3 + aa] += add;
+          for (int ci = 0; ci < 4; ++ci) {
+            if (ci < nch) {
+              const int c = (ci == 0) ? c0 : ((ci == 1) ? c1 : ((ci == 2) ? c2 : c3));
+              float add = fmaf(sdGR[c][r * 3 + 2], L.R[c][aa * 3 + 2],
+                               fmaf(sdGR[c][r * 3 + 1], L.R[c][aa * 3 + 1], sdGR[c][r * 3] * L.R[c][aa * 3]));
+              add = fmaf(sdGt[c][r], L.J[c][aa] - L.J[jj][aa], add);
+              acc += add;
+            }
           }
-          sdGt[j][r] += dGtc[r];
-        }
+          sdGR[jj][e] = acc;
+        } else {
+          const int r = e - 9;
+          float acc_t = sdGt[jj][r], acc_j = sdJ[jj][r];
 #pragma unroll
-        for (int aa = 0; aa < 3; ++aa) {
-          const float tmp = fmaf(L.GR[j][6 + aa], dGtc[2], fmaf(L.GR[j][3 + aa], dGtc[1], L.GR[j][aa] * dGtc[0]));
-          sdJ[c][aa] += tmp;
-          sdJ[j][aa] -= tmp;
+          for (int ci = 0; ci < 4; ++ci) {
+            if (ci < nch) {
+              const int c = (ci == 0) ? c0 : ((ci == 1) ? c1 : ((ci == 2) ? c2 : c3));
+              acc_t += sdGt[c][r];
+              acc_j -= fmaf(L.GR[jj][6 + r], sdGt[c][2], fmaf(L.GR[jj][3 + r], sdGt[c][1], L.GR[jj][r] * sdGt[c][0]));
+            }
+          }
+          sdGt[jj][r] = acc_t;
+          sdJ[jj][r] = acc_j;
+        }
+      } else if (role == 1 && rl < 12 * UUO_LEVEL_W && k < s_lvl_n[d + 1]) {  // own totals final, parent's G^R an input
+        const int jj = s_lvl_j[d + 1][k], p = s_lvl_p[d + 1][k];
+        if (e < 9) {
+          const int aa = e / 3, bb = e - aa * 3;
+          sdR[jj][e] = fmaf(L.GR[p][6 + aa], sdGR[jj][6 + bb], fmaf(L.GR[p][3 + aa], sdGR[jj][3 + bb], L.GR[p][aa] * sdGR[jj][bb]));
+        } else {
+          const int aa = e - 9;
+          sdJ[jj][aa] += fmaf(L.GR[p][6 + aa], sdGt[jj][2], fmaf(L.GR[p][3 + aa], sdGt[jj][1], L.GR[p][aa] * sdGt[jj][0]));
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  if (j == 0) {
-#pragma unroll
-    for (int e = 0; e < 9; ++e) sdR[0][e] = sdGR[0][e];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sdJ[0][c] += sdGt[0][c];
+  if (tid < 12) {  // the root: its world transform is its local one
+    if (tid < 9) sdR[0][tid] = sdGR[0][tid];
+    else sdJ[0][tid - 9] += sdGt[0][tid - 9];
   }
   __syncthreads();
 
+  BWD_STAMP(6);
   // shape gradient of this frame: direct (blend shapes) + joint path (240 threads: one (joint, beta) pair each)
   if (tid < 240) {
     const int jj = tid / 10, l = tid - jj * 10;
@@ -551,16 +613,16 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     a.frame_part[(size_t)f * UUO_FP + 4 + tid] = acc;
     if (a.stage == UUO_STAGE_UPSTREAM) a.g_betas_frame[(size_t)f * 10 + tid] = acc;
   }
+  BWD_STAMP(7);
   // body rotations
   if (j >= 1 && j < UUO_NUM_JOINTS) {
     float psq = 0.f;
     if (a.g_pose) {
       float dR[9], raw[9], gout[9];
-      const float* pr = a.raw_pose + ((size_t)f * 23 + (j - 1)) * 9;
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
         dR[e] = sdR[j][e] + sdpf[(j - 1) * 9 + e];
-        raw[e] = pr[e];
+        raw[e] = raw_pre[e];
       }
       if (a.src.norm_body) {
         float da[6];
@@ -573,10 +635,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
         for (int e = 0; e < 9; ++e) gout[e] = dR[e];
       }
       if (a.cpose != 0.f) {
-        const float* po = a.o_pose + ((size_t)f * 23 + (j - 1)) * 9;
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
-          const float diff = raw[e] - po[e];
+          const float diff = raw[e] - po_pre[e];
           gout[e] = fmaf(a.cpose, diff, gout[e]);
           psq = fmaf(diff, diff, psq);
         }
@@ -652,7 +713,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     sstat[24 + c][0] = gt * dpre[0];
     sstat[24 + c][1] = fabsf(gt); sstat[24 + c][2] = gt * gt; sstat[24 + c][3] = fabsf(gt);
   }
+  BWD_STAMP(8);
   __syncthreads();
+  BWD_STAMP(9);
   if (tid < 4) {  // fixed-order sum of the writers' statistics
     float acc = 0.f;
     if (tid < 3) {
@@ -669,6 +732,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     a.frame_part[(size_t)f * UUO_FP + 2] = ps;
     if (a.stage != UUO_STAGE_PART) a.frame_part[(size_t)f * UUO_FP + 1] = 0.f;
   }
+  BWD_STAMP(10);
 }
 
 // Two entry points so that each gets its own register budget.  The sparse one (<= 4 skin weights per vertex: SMPL) is
@@ -1034,6 +1098,12 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
 }
 
 #ifdef UUO_DEBUG_HOOKS
+// debug hook: shader-clock stamps left by the last k_bwd launch with UUO_BWD_STOP=9 ([4096][BWD_NSTAMP] cycles)
+extern "C" int uuo_debug_bwd_stamps(unsigned long long* h_out) {
+  UUO_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * 4096 * BWD_NSTAMP));
+  return 0;
+}
+
 // debug/test hook (not in the public header): survivor counts of the last pruned nearest-neighbour search
 extern "C" int uuo_debug_nn_flags(uuo_fit_t* fit, int* h_out) {
   UUO_REQUIRE(fit && h_out, "uuo_debug_nn_flags: null argument");

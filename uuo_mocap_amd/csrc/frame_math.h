@@ -93,6 +93,30 @@ __device__ __forceinline__ void rz_entries(float z, float* o) {
 __device__ __forceinline__ void frame_forward(const UuoPoseSrc& src, const UuoTree* __restrict__ tree, int f,
                                               FrameLds& L) {
   const int l = threadIdx.x;
+  // the tree's level tables for the kinematic steps below: issued first, so their round trip overlaps the pose loads
+  const int max_depth = tree->max_depth;
+  const int lk = l / 12, le = l - lk * 12;
+  int lvl_j[UUO_MAX_DEPTH], lvl_p[UUO_MAX_DEPTH];
+#pragma unroll
+  for (int d = 1; d < UUO_MAX_DEPTH; ++d) {
+    const bool on = d <= max_depth && l < 12 * UUO_LEVEL_W && lk < tree->level_n[d];
+    lvl_j[d] = on ? tree->level_j[d][lk] : -1;
+    lvl_p[d] = on ? tree->level_p[d][lk] : 0;
+  }
+  // every global load of the frame (raw rotations, shape, yaw) is issued before the first barrier: one round trip
+  float raw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (l < UUO_NUM_JOINTS) {
+    const float* pr = (l == 0) ? src.root + (size_t)f * 9 : src.body + ((size_t)f * 23 + (l - 1)) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) raw[e] = pr[e];
+  }
+  float jt[3] = {0.f, 0.f, 0.f}, js[3][10];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (l < UUO_NUM_JOINTS) jt[c] = tree->Jt[l][c];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) js[c][k] = (l < UUO_NUM_JOINTS) ? tree->JS[l][c][k] : 0.f;
+  }
   if (l < 10) L.beta[l] = src.betas[(size_t)f * src.betas_stride + l];
   if (l == 32 && src.root_mode >= UUO_ROOT_Z_GS) {
     float z = (src.root_mode == UUO_ROOT_Z_GS) ? src.z[f] : src.z[0];
@@ -100,11 +124,8 @@ __device__ __forceinline__ void frame_forward(const UuoPoseSrc& src, const UuoTr
   }
   __syncthreads();
   if (l < UUO_NUM_JOINTS) {
-    float raw[9], R[9];
+    float R[9];
     if (l == 0) {
-      const float* pr = src.root + (size_t)f * 9;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) raw[e] = pr[e];
       if (src.root_mode >= UUO_ROOT_Z_GS) {
         float m[9];
         const float c00 = L.Rz[0], c01 = L.Rz[1], c10 = L.Rz[2], c11 = L.Rz[3];
@@ -127,9 +148,6 @@ __device__ __forceinline__ void frame_forward(const UuoPoseSrc& src, const UuoTr
         for (int e = 0; e < 9; ++e) R[e] = raw[e];
       }
     } else {
-      const float* pb = src.body + ((size_t)f * 23 + (l - 1)) * 9;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) raw[e] = pb[e];
       if (src.norm_body) {
         gs6d_forward(raw, R);
       } else {
@@ -141,37 +159,38 @@ __device__ __forceinline__ void frame_forward(const UuoPoseSrc& src, const UuoTr
     for (int e = 0; e < 9; ++e) L.R[l][e] = R[e];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float acc = tree->Jt[l][c];
+      float acc = jt[c];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) acc = fmaf(tree->JS[l][c][k], L.beta[k], acc);
+      for (int k = 0; k < 10; ++k) acc = fmaf(js[c][k], L.beta[k], acc);
       L.J[l][c] = acc;
     }
   }
   __syncthreads();
-  if (l == 0) {
-#pragma unroll
-    for (int e = 0; e < 9; ++e) L.GR[0][e] = L.R[0][e];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) L.Gt[0][c] = L.J[0][c];
+  // Kinematic chain, one depth per step, one lane per (joint of the level, entry): entries 0..8 are G_j^R = G_p^R R_j,
+  // 9..11 are G_j^t = G_p^R (J_j - J_p) + G_p^t.  SMPL has <= 5 joints per level, so a step occupies <= 60 lanes of wave 0
+  // and costs an LDS round trip and three FMAs (the 24-lane version spent ~40 dependent instructions per joint per
+  // step); every entry is the same FMA chain as mat3_mul, so the result is bit-identical to it.
+  if (l < 12) {
+    if (l < 9) L.GR[0][l] = L.R[0][l];
+    else L.Gt[0][l - 9] = L.J[0][l - 9];
   }
   __syncthreads();
-  const int max_depth = tree->max_depth;
-  const int my_depth = (l < UUO_NUM_JOINTS) ? tree->depth[l] : -1;
-  const int my_parent = (l < UUO_NUM_JOINTS) ? tree->parent[l] : 0;
-  for (int d = 1; d <= max_depth; ++d) {
-    if (my_depth == d) {
-      const int p = my_parent;
-      float g[9];
-      mat3_mul(L.GR[p], L.R[l], g);
-      float rel[3] = {L.J[l][0] - L.J[p][0], L.J[l][1] - L.J[p][1], L.J[l][2] - L.J[p][2]};
 #pragma unroll
-      for (int e = 0; e < 9; ++e) L.GR[l][e] = g[e];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        L.Gt[l][r] = fmaf(L.GR[p][r * 3 + 2], rel[2], fmaf(L.GR[p][r * 3 + 1], rel[1], L.GR[p][r * 3] * rel[0])) +
-                     L.Gt[p][r];
+  for (int d = 1; d < UUO_MAX_DEPTH; ++d) {
+    if (d <= max_depth) {  // block-uniform
+      const int j = lvl_j[d], p = lvl_p[d];
+      if (j >= 0) {
+        if (le < 9) {
+          const int r = le / 3, c = le - r * 3;
+          L.GR[j][le] = fmaf(L.GR[p][r * 3 + 2], L.R[j][6 + c], fmaf(L.GR[p][r * 3 + 1], L.R[j][3 + c], L.GR[p][r * 3] * L.R[j][c]));
+        } else {
+          const int r = le - 9;
+          const float rel0 = L.J[j][0] - L.J[p][0], rel1 = L.J[j][1] - L.J[p][1], rel2 = L.J[j][2] - L.J[p][2];
+          L.Gt[j][r] = fmaf(L.GR[p][r * 3 + 2], rel2, fmaf(L.GR[p][r * 3 + 1], rel1, L.GR[p][r * 3] * rel0)) + L.Gt[p][r];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 

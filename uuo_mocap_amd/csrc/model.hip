@@ -102,6 +102,16 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
       t.child[p][t.nchild[p]++] = j;
     }
   }
+  for (int j = 0; j < UUO_NUM_JOINTS; ++j) {  // joints by depth, ascending joint id inside a level
+    const int d = t.depth[j];
+    if (t.level_n[d] >= UUO_LEVEL_W) {
+      delete m;
+      uuo_set_error("uuo_model_create: more than 5 joints on one level of the kinematic tree (SMPL has at most 5)");
+      return -22;
+    }
+    t.level_p[d][t.level_n[d]] = t.parent[j];
+    t.level_j[d][t.level_n[d]++] = j;
+  }
   for (int j = 0; j < UUO_NUM_JOINTS; ++j)
     for (int c = 0; c < 3; ++c) {
       double acc = 0.0;

@@ -1165,9 +1165,12 @@ __global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const f
   __shared__ double sh[4];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
-    if (kind == 0) {
-      const float a = 1.0f + 99.0f * (float)i / (float)(n > 1 ? n - 1 : 1);
-      const float b = sinf(0.37f * (float)i);
+    if (kind == 0 || kind == 2) {
+      // kind 2: well-scaled quadratic (condition 4, |g0|_1 < 1 so the first step length is lr itself): every line-search
+      // decision has a healthy margin, so two fp32 implementations must agree evaluation by evaluation
+      const float a = (kind == 0) ? 1.0f + 99.0f * (float)i / (float)(n > 1 ? n - 1 : 1)
+                                  : 1.0f + 3.0f * (float)i / (float)(n > 1 ? n - 1 : 1);
+      const float b = (kind == 0) ? sinf(0.37f * (float)i) : 1e-3f * sinf(0.37f * (float)i);
       const float r = x[i] - b;
       acc += 0.5 * (double)a * (double)r * (double)r;
       grad[i] = a * r;
@@ -1795,7 +1798,7 @@ extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, 
 // the CPU, evaluation by evaluation through `cb`)
 extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, const uuo_lbfgs_options_t* opt,
                                   uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
-  UUO_REQUIRE(d_x && opt && stats && n > 0 && (kind == 0 || kind == 1), "uuo_lbfgs_selftest: bad arguments");
+  UUO_REQUIRE(d_x && opt && stats && n > 0 && kind >= 0 && kind <= 2, "uuo_lbfgs_selftest: bad arguments");
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
   LbWs* w = nullptr;
   int rc = lbws_create(n, hist, &w);

@@ -12,6 +12,7 @@
 #define UUO_KB 208        // padded K of the per-vertex transposed posedirs rows
 #define UUO_FT 16         // frames per MFMA row tile (v_mfma_f32_16x16x4_f32)
 #define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
+#define UUO_LEVEL_W 5     // joints per tree level the level-parallel sweeps support (SMPL: 1,3,3,3,5,3,2,2,2)
 #define UUO_FP 24         // floats per frame of the closure's partial-sum block
 
 void uuo_set_error(const std::string& msg);
@@ -51,6 +52,11 @@ struct UuoTree {
   int max_depth;
   int nchild[UUO_NUM_JOINTS];
   int child[UUO_NUM_JOINTS][4];  // children in ascending joint order (deterministic backward sweep)
+  // joints by depth: the kinematic sweeps walk one depth per step with one lane per (joint of the level, matrix entry);
+  // SMPL has at most 5 joints per level (5 x 12 entries = 60 lanes of one wave)
+  int level_n[UUO_MAX_DEPTH];
+  int level_j[UUO_MAX_DEPTH][UUO_LEVEL_W];
+  int level_p[UUO_MAX_DEPTH][UUO_LEVEL_W];  // parent of level_j[d][k]
   float Jt[UUO_NUM_JOINTS][3];      // J_regressor . v_template
   float JS[UUO_NUM_JOINTS][3][10];  // J_regressor . shapedirs
   int extra_vids[UUO_NUM_EXTRA_JOINTS];

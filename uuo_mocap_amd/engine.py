@@ -54,6 +54,48 @@ def workspace_slot() -> int:
     return workspace_group() * WORKSPACE_GROUP_STRIDE + getattr(_tls, "slot", 0)
 
 
+_worker_streams: Dict = {}
+_worker_streams_lock = threading.Lock()
+
+
+def worker_streams(device, count: int, role: str = "") -> list:
+    """`count` persistent side streams of `device` for the calling thread's workspace group and a role ("hypothesis",
+    "subtree", "sequence").  Created once per process and reused by every fit: torch hands out stream handles round-robin
+    from a pool of 32 and keeps a BLAS workspace (76 MB on this build) alive per stream it has seen, so fresh
+    `torch.cuda.Stream()` objects per fit grow the process by up to 2.4 GB and let two live worker threads meet on one
+    handle."""
+    device = torch.device(device)
+    out = []
+    with _worker_streams_lock:
+        for i in range(count):
+            key = (device.index, workspace_group(), role, i)
+            st = _worker_streams.get(key)
+            if st is None:
+                st = torch.cuda.Stream(device=device)
+                _worker_streams[key] = st
+            out.append(st)
+    return out
+
+
+_worker_pools: Dict = {}
+
+
+def worker_pool(count: int, role: str = ""):
+    """A persistent ThreadPoolExecutor of `count` threads for the calling thread's workspace group and a role.  Worker
+    threads are kept for the life of the process: every NEW host thread that touches the GPU costs a BLAS handle (and its
+    device workspace) and the runtime's per-thread state, which a dataset run would otherwise pay once per stage per
+    sequence."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    key = (workspace_group(), role, int(count))
+    with _worker_streams_lock:
+        pool = _worker_pools.get(key)
+        if pool is None:
+            pool = ThreadPoolExecutor(max_workers=int(count), thread_name_prefix="uuo-%s-g%d" % (role, key[0]))
+            _worker_pools[key] = pool
+    return pool
+
+
 def _require_cuda(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU: the fitted path has no CPU implementation" % name)
@@ -76,8 +118,11 @@ class _FitHandle:
     """Owner of one uuo_fit_t.  Problems hold a reference for as long as they may launch on the workspace; the
     workspace is destroyed (uuo_fit_destroy: hipFree waits for the device) when the last reference goes."""
 
+    live = 0  # workspaces currently allocated in this process (diagnostics / tests)
+
     def __init__(self, lib, ptr: c_void_p, device):
         self._lib, self.ptr, self._device = lib, ptr, device
+        _FitHandle.live += 1
 
     def __del__(self):
         try:
@@ -85,6 +130,7 @@ class _FitHandle:
                 with torch.cuda.device(self._device):
                     self._lib.uuo_fit_destroy(self.ptr)
                 self.ptr = None
+                _FitHandle.live -= 1
         except Exception:
             pass
 

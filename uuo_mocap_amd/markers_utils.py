@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .body_model import SMPL_JOINT_NAMES
-from .engine import PartProblem, set_workspace_group, set_workspace_slot, workspace_group
+from .engine import PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
 from .losses import chamfer_distance
 from .transforms import compute_root_orient_z
 
@@ -365,7 +365,7 @@ def find_best_part_fits(
         n_threads = 1  # autograd graphs of concurrent candidates would share the engine's forward scratch
     if n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
-        streams = [torch.cuda.Stream(device=device) for _ in range(n_threads)]
+        streams = worker_streams(device, n_threads, "subtree")
         for s_ in streams:
             s_.wait_stream(main_stream)
         free_slots = queue.Queue()
@@ -379,8 +379,7 @@ def find_best_part_fits(
             finally:
                 free_slots.put(i)
 
-        with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            results = list(pool.map(worker, subtrees))
+        results = list(worker_pool(n_threads, "subtree").map(worker, subtrees))
         for s_ in streams:
             main_stream.wait_stream(s_)
         set_workspace_slot(0)

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import markers_utils, optimization
-from .engine import set_workspace_group, set_workspace_slot, workspace_group
+from .engine import set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
 from .markers_utils import find_best_part_fits, get_aabb, get_aabb_volume, segment_rigid
 from .optimization import (compute_marker_labels_from_coords, compute_nearest_points, get_marker_mask,
                            optim_chamfer, optim_markers, weighted_chamfer_distance)
@@ -377,12 +377,12 @@ def multimodal_video_mocap(
         n_threads = 1
     if n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
-        streams = [torch.cuda.Stream(device=device) for _ in root_orient_angles]
+        streams = worker_streams(device, len(root_orient_angles), "hypothesis")
         for st_ in streams:
             st_.wait_stream(main_stream)
-        with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            futures = [pool.submit(fit_hypothesis, i, a, streams[i]) for i, a in enumerate(root_orient_angles)]
-            results = [f.result() for f in futures]
+        pool = worker_pool(n_threads, "hypothesis")  # persistent threads: no per-fit thread / BLAS-handle churn
+        futures = [pool.submit(fit_hypothesis, i, a, streams[i]) for i, a in enumerate(root_orient_angles)]
+        results = [f.result() for f in futures]
         for st_ in streams:
             main_stream.wait_stream(st_)
     else:

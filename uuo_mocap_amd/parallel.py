@@ -75,7 +75,7 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None) 
     Results come back in the order of `items`."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from .engine import set_workspace_group, set_workspace_slot
+    from .engine import set_workspace_group, set_workspace_slot, worker_streams
 
     if inflight <= 1 or len(items) <= 1:
         return [fit_fn(it) for it in items]
@@ -93,7 +93,7 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None) 
             set_workspace_group(g)
             set_workspace_slot(0)
             if use_cuda:
-                st = torch.cuda.Stream(device=device)
+                st = worker_streams(device, 1, "sequence")[0]  # persistent, one per workspace group
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     out = fit_fn(it)
