@@ -180,6 +180,21 @@ int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float*
                     const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
                     void* cb_user);
 
+/* ---- lock-step batches of independent solves ---------------------------------------------------------
+ * The reference solves the candidate body parts of find_best_part_fits one after the other
+ * (markers/markers_utils.py:416-610: one torch.optim.LBFGS(...).step(closure) per sub-tree, 202 of them for a 10-marker
+ * limb) and likewise the yaw hypotheses (multimodal.py:462-574).  They are independent problems of one stage and one
+ * (F, M): a batch steps up to B of them together -- one round = one closure evaluation of every live problem, every
+ * kernel of the round launched ONCE for all of them -- with the decisions and the arithmetic of uuo_lbfgs_solve
+ * (results are bit-identical to solving each problem alone).  Part-stage problems of one batch share the body pose
+ * (d_o_pose) and hence one pose-blend cache.  uuo_batch_solve synchronises `stream`; stats[i].device_ms is 0. */
+typedef struct uuo_batch uuo_batch_t;
+int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int B, uuo_batch_t** out);
+int uuo_batch_destroy(uuo_batch_t* batch);
+int uuo_batch_solve(uuo_batch_t* batch, void* stream, const uuo_problem_t* problems /* [nb] */,
+                    float* const* d_xs /* [nb] device vectors, updated in place */, int nb,
+                    const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats /* [nb] */);
+
 /* device -> host copy of n floats, ordered on `stream`, complete on return (for uuo_eval_callback_t users that only
  * hold the raw pointer, e.g. the iter_fn adapter). */
 int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n);

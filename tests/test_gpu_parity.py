@@ -1398,3 +1398,67 @@ def test_missing_markers_and_tiny_sequences(smpl, oracle_smpl, dev):
     with pytest.raises(ValueError, match="minimum of 2"):
         multimodal_video_mocap(s1.img_smpl, copy.deepcopy(s1.markers), dev, cfg, offset=0, print_options=[],
                                save_stages=False, smpl_inference=smpl)
+
+
+# ------------------------------------------------------------------------------------------------ lock-step batches
+@pytest.mark.gpu
+def test_lockstep_batch_is_bit_identical_to_solving_one_by_one(smpl, dev):
+    """uuo_batch_solve steps independent problems together (one launch per kernel and round for all of them); every
+    problem must end exactly where uuo_lbfgs_solve takes it alone: same iterates bit for bit, same iteration and
+    evaluation counts, same stop reason -- for the part stage (candidates with different vertex subsets sharing one
+    pose-blend cache), the chamfer stage (different yaw hypotheses) and the marker stage."""
+    from uuo_mocap_amd.engine import ChamferProblem, MarkerProblem, PartProblem, solve_batch
+    from uuo_mocap_amd.transforms import compute_root_orient_z
+
+    F, M = 21, 9
+    seq = make_sequence(smpl.tables, seed=31, num_frames=F, num_markers=M)
+    cfg = packaged_config("video_mocap")
+    markers = _t(seq.markers.get_points(), dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    trans = torch.median(markers, dim=1)[0]
+    vlabels = torch.argmax(smpl.get_lbs_weights(), dim=-1)
+
+    def check(make_problems, make_x, max_iter, lr):
+        probs_a, probs_b = make_problems(), make_problems()
+        xs_a = [make_x(p, i) for i, p in enumerate(probs_a)]
+        xs_b = [x.clone() for x in xs_a]
+        alone = [p.solve(x, max_iter=max_iter, lr=lr) for p, x in zip(probs_a, xs_a)]
+        together = solve_batch(probs_b, xs_b, max_iter=max_iter, lr=lr)
+        for i, (sa, sb, xa, xb) in enumerate(zip(alone, together, xs_a, xs_b)):
+            assert (sa["n_iter"], sa["n_eval"], sa["stop_reason"]) == (sb["n_iter"], sb["n_eval"], sb["stop_reason"]), (i, sa, sb)
+            assert sa["first_loss"] == sb["first_loss"] and sa["final_loss"] == sb["final_loss"], (i, sa, sb)
+            assert torch.equal(xa, xb), "problem %d: iterates differ" % i
+        assert len({s_["n_eval"] for s_ in alone}) > 1, "the problems should not all take the same number of evaluations"
+
+    # part stage: five candidate sub-trees
+    subtrees = [[0, 1, 4, 7, 10], [0, 2, 5, 8, 11], [3, 6, 9, 12, 15], [9, 13, 16, 18, 20], [9, 14, 17, 19, 21]]
+    cfg_p = packaged_config("hmr_part")
+
+    def part_problems():
+        ps = [PartProblem(smpl, markers, o_pose, o_betas, root,
+                          torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in st_]), cfg_p) for st_ in subtrees]
+        for p in ps[1:]:
+            p.problem.pose_cache_id = ps[0].problem.pose_cache_id
+        return ps
+
+    check(part_problems, lambda p, i: p.pack(torch.zeros(1, 1, 1, device=dev), trans, o_betas), max_iter=60, lr=1.0)
+
+    # chamfer stage: four yaw hypotheses
+    def chamfer_problems():
+        out = []
+        for k in range(4):
+            ang = torch.full((F, 1, 1), k * np.pi / 2, device=dev)
+            out.append(ChamferProblem(smpl, markers, o_pose, o_betas, (compute_root_orient_z(ang) @ root).contiguous(), cfg))
+        return out
+
+    check(chamfer_problems, lambda p, i: p.pack(trans, torch.zeros(F, 1, 1, device=dev), o_betas, o_pose), max_iter=25, lr=0.1)
+
+    # marker stage: different placements
+    gt_vids = torch.from_numpy(seq.gt["marker_vids"]).to(dev)
+
+    def marker_problems():
+        return [MarkerProblem(smpl, markers, o_pose, o_betas, (gt_vids + 7 * k) % 6890, cfg) for k in range(3)]
+
+    check(marker_problems, lambda p, i: p.pack(o_pose, o_betas, root, trans + 0.01 * i), max_iter=30, lr=1.0)

@@ -11,6 +11,7 @@
 #define UUO_STAGE_UPSTREAM 3  // internal: not a fitting stage (uuo_smpl_backward)
 
 struct BwdArgs {
+  UuoGridHdr h;  // grid extent of this problem (lock-step batches: uuo_common.h)
   // model
   const float* PT;
   const float* ST;
@@ -743,12 +744,17 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
   bwd_body<true>(a);
 }
 __global__ __launch_bounds__(BWD_NW * 64) void k_bwd_dense(BwdArgs a) { bwd_body<false>(a); }
+__global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bwd_sparse_b(const BwdArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(BwdArgs, batch)
+  bwd_body<true>(a);
+}
 
 // ----------------------------------------------------------------------------------------------------
 // K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
 // prior, writes the loss and the shared-parameter gradients (betas; z for the part stage).
 // ----------------------------------------------------------------------------------------------------
 struct FinArgs {
+  UuoGridHdr h;
   int stage, F;
   const float* frame_part;
   const float* betas;
@@ -766,7 +772,7 @@ struct FinArgs {
   unsigned long long rep_seq;
 };
 
-__global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
+__device__ __forceinline__ void finalize_body(const FinArgs& a) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ double sh[32][32];
   const int tid = threadIdx.x;
@@ -836,6 +842,25 @@ __global__ __launch_bounds__(1024) void k_finalize(FinArgs a) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void k_finalize(FinArgs a) { finalize_body(a); }
+__global__ __launch_bounds__(1024) void k_finalize_b(const FinArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(FinArgs, batch)
+  finalize_body(a);
+}
+
+// batched launches of this file's kernels (uuo_common.h): 0 = launched, 1 = not one of mine, < 0 = error
+int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int count, int gx, int gy) {
+  if (op == UUO_OP_BWD) {
+    hipLaunchKernelGGL(k_bwd_sparse_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
+  } else if (op == UUO_OP_FIN) {
+    hipLaunchKernelGGL(k_finalize_b, dim3(gx, gy, count), dim3(1024), 0, s, (const FinArgs*)d_args);
+  } else {
+    return 1;
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -931,6 +956,7 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   if (cached && fit->pose_cache_id != p->pose_cache_id) {
     // first evaluation of a solve whose body pose is constant: C = v_t + P . feat through the MFMA kernel with zero
     // shape, identity skinning transforms and no translation
+    UUO_REQUIRE(!uuo_recorder, "closure: the pose cache of a lock-step batch is built before its first round");
     if (!fit->pose_cache) UUO_HIP_CHECK(hipMalloc((void**)&fit->pose_cache, (size_t)p->F * m->V * 3 * sizeof(float)));
     UuoPoseSrc c = src;
     c.betas = fit->zeros16;
@@ -962,6 +988,29 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
 
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return validate_problem(fit, p); }
 
+// Builds the pose-corrective blend cache of a part-stage problem now (normally the first evaluation does): a lock-step
+// batch shares ONE cache among its candidates (same body pose) and must have it before its first recorded round.
+int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {
+  if (p->stage != UUO_STAGE_PART || p->pose_cache_id == 0 || fit->model->nnz > 4) return 0;
+  if (fit->pose_cache_id == p->pose_cache_id) return 0;
+  const StageLayout lay = stage_layout(p->stage, p->F);
+  const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
+  const uuo_model* m = fit->model;
+  if (!fit->pose_cache) UUO_HIP_CHECK(hipMalloc((void**)&fit->pose_cache, (size_t)p->F * m->V * 3 * sizeof(float)));
+  UuoPoseSrc c = src;
+  c.betas = fit->zeros16;
+  c.betas_stride = 0;
+  c.trans = nullptr;
+  int rc = uuo_launch_pose_prep(m, s, p->F, c, fit->pfaT, fit->A, nullptr, nullptr);
+  if (rc) return rc;
+  rc = uuo_launch_identity_transforms(s, p->F * UUO_NUM_JOINTS, fit->A);
+  if (rc) return rc;
+  rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, nullptr, fit->pose_cache, nullptr);
+  if (rc) return rc;
+  fit->pose_cache_id = p->pose_cache_id;
+  return 0;
+}
+
 // closure evaluation proper; the marker mask must be current (uuo_ensure_mask)
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
                           float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
@@ -986,6 +1035,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const double data_c = (denom > 0.0) ? (double)p->w_data / denom : 0.0;
 
   BwdArgs a;
+  std::memset(&a, 0, sizeof(a));
   a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wd = m->W; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
   a.src = src;
   a.stage = p->stage; a.F = F; a.M = M;
@@ -1010,13 +1060,18 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.stop = bwd_stop;
   a.dir = d_dir;
   a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
-  if (m->nnz <= 4)
-    hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
-  else
+  a.h.gx = F;
+  a.h.gy = 1;
+  if (m->nnz <= 4) {
+    if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  } else {
+    UUO_REQUIRE(!uuo_recorder, "lock-step batches need the sparse skin-weight tables (<= 4 weights per vertex)");
     hipLaunchKernelGGL(k_bwd_dense, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  }
   UUO_HIP_CHECK(hipGetLastError());
 
   FinArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
   fa.stage = p->stage; fa.F = F;
   fa.frame_part = fit->frame_part;
   fa.betas = d_x + lay.off_betas;
@@ -1032,7 +1087,9 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   fa.stats = d_stats;
   fa.rep_host = (report && d_stats) ? report->host : nullptr;
   fa.rep_seq = report ? report->seq : 0ull;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
+  fa.h.gx = 1;
+  fa.h.gy = 1;
+  if (!uuo_record(UUO_OP_FIN, 1, 1, fa)) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

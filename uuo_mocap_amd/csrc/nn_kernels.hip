@@ -23,11 +23,11 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, 
 // same lexicographic order and is exact and order-independent.
 // Replaces pytorch3d knn_points(K=1) behind chamfer_distance (reference losses/chamfer_distance.py:15-20).
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_nn(const float* __restrict__ x, const float* __restrict__ y,
-                                            const int* __restrict__ ysub, int P1, int P2, int nc, int S,
-                                            unsigned long long* __restrict__ out) {
+__device__ __forceinline__ void nn_body(const float* __restrict__ x, const float* __restrict__ y,
+                                        const int* __restrict__ ysub, int P1, int P2, int nc, int S,
+                                        unsigned long long* __restrict__ out, int n, int qg, int s) {
   __shared__ float4 sc[64];
-  const int n = blockIdx.x, qg = blockIdx.y, s = blockIdx.z, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const int q = qg * 64 + lane;
   const bool valid = q < P1;
   float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -66,14 +66,40 @@ __global__ __launch_bounds__(64) void k_nn(const float* __restrict__ x, const fl
   if (valid && besti != 0xFFFFFFFFu) atomicMin(&out[(size_t)n * P1 + q], pack_key(best, besti));
 }
 
+struct NnArgs {
+  UuoGridHdr h;  // batched form: gy = query groups x splits
+  const float* x;
+  const float* y;
+  const int* ysub;
+  int P1, P2, nc, S;
+  unsigned long long* out;
+};
+__global__ __launch_bounds__(64) void k_nn(NnArgs a) {
+  nn_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+__global__ __launch_bounds__(64) void k_nn_b(const NnArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(NnArgs, batch)
+  nn_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out, blockIdx.x, (int)blockIdx.y / a.S, (int)blockIdx.y % a.S);
+}
+struct FillArgs {  // UUO_OP_FILL: all-ones fill of the packed (distance, index) keys before a split search
+  UuoGridHdr h;
+  unsigned long long* p;
+  int count;
+};
+__global__ void k_fill_keys_b(const FillArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(FillArgs, batch)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.count) a.p[i] = ~0ull;
+}
+
 // Few queries per cloud (partial marker sets: P1 <= 16): lane = query would leave most of the wave idle, so here
 // lane = candidate.  Every lane keeps the running (dist, index) key of each query over its candidates
 // (c = lane, lane + 64, ... in ascending order, strict '<' on the packed key = first index on ties), the wave merges
 // with 64-bit minima and one atomicMin per query and split.  Same packed-key order as k_nn: bit-identical results.
 #define NNQ_MAX 16
-__global__ __launch_bounds__(256) void k_nn_fewq(const float* __restrict__ x, const float* __restrict__ y,
-                                                 const int* __restrict__ ysub, int P1, int P2, int nc, int S,
-                                                 unsigned long long* __restrict__ out) {
+__device__ __forceinline__ void nn_fewq_body(const float* __restrict__ x, const float* __restrict__ y,
+                                             const int* __restrict__ ysub, int P1, int P2, int nc, int S,
+                                             unsigned long long* __restrict__ out) {
   __shared__ float sq[NNQ_MAX * 3];
   __shared__ unsigned long long sk[NNQ_MAX];  // the block's minima: with one split they ARE the result (no zero-fill
                                               // of the output, no global atomic)
@@ -119,22 +145,45 @@ __global__ __launch_bounds__(256) void k_nn_fewq(const float* __restrict__ x, co
   }
 }
 
+__global__ __launch_bounds__(256) void k_nn_fewq(NnArgs a) { nn_fewq_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out); }
+__global__ __launch_bounds__(256) void k_nn_fewq_b(const NnArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(NnArgs, batch)
+  nn_fewq_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out);
+}
+
+static int fill_keys(hipStream_t s, unsigned long long* packed, size_t count) {
+  FillArgs f{{(int)((count + 255) / 256), 1}, packed, (int)count};
+  if (uuo_record(UUO_OP_FILL, f.h.gx, 1, f)) return 0;
+  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, count * sizeof(unsigned long long), s));
+  return 0;
+}
+
 int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const float* y, const int32_t* ysub, int P2s,
                   unsigned long long* packed) {
   const int nc = ysub ? P2s : P2;
   if (nc > 0 && N > 0 && P1 > 0 && P1 <= NNQ_MAX) {
-    // splits so that N * S blocks of 256 threads cover the chip a few times, each lane seeing >= 4 candidates
+    // splits so that N * S blocks of 256 threads cover the chip a few times, each lane seeing >= 4 candidates (the
+    // result is the exact first-index minimum whatever the split, so the choice never shows in the numbers); a
+    // lock-step batch fills the chip with its other problems: one split, no zero-fill, no global atomics
     int S = 1;
     if (N < 1024) S = (1024 + N - 1) / N;
     const int maxS = (nc + 1023) / 1024;
     if (S > maxS) S = maxS;
-    if (S < 1) S = 1;
-    if (S > 1) UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_nn_fewq, dim3(N, S), dim3(256), 0, s, x, y, ysub, P1, P2, nc, S, packed);
+    if (S < 1 || uuo_recorder) S = 1;
+    if (S > 1) {
+      const int rc = fill_keys(s, packed, (size_t)N * P1);
+      if (rc) return rc;
+    }
+    NnArgs a{{N, S}, x, y, ysub, P1, P2, nc, S, packed};
+    if (uuo_record(UUO_OP_NN_FEWQ, N, S, a)) return 0;
+    hipLaunchKernelGGL(k_nn_fewq, dim3(N, S), dim3(256), 0, s, a);
     UUO_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  UUO_HIP_CHECK(hipMemsetAsync(packed, 0xFF, (size_t)N * P1 * sizeof(unsigned long long), s));
+  {
+    const int rc = fill_keys(s, packed, (size_t)N * P1);
+    if (rc) return rc;
+  }
   if (nc <= 0 || N <= 0 || P1 <= 0) return 0;
   const int qgroups = (P1 + 63) / 64;
   // enough waves to fill the chip: target >= 4096 waves, at least 256 candidates per split
@@ -144,7 +193,9 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
   const int maxS = (nc + 255) / 256;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
-  hipLaunchKernelGGL(k_nn, dim3(N, qgroups, S), dim3(64), 0, s, x, y, ysub, P1, P2, nc, S, packed);
+  NnArgs a{{N, qgroups * S}, x, y, ysub, P1, P2, nc, S, packed};
+  if (uuo_record(UUO_OP_NN, N, qgroups * S, a)) return 0;
+  hipLaunchKernelGGL(k_nn, dim3(N, qgroups, S), dim3(64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -169,9 +220,9 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
 #ifndef CULL_T
 #define CULL_T 256  // threads per block (128: 7 us slower alone and 2 % slower fits; 512: no faster)
 #endif
-__global__ __launch_bounds__(CULL_T) void k_nn_cull(int M, int V, int nunits, int mper, const float* __restrict__ x,
-                                                  const float* __restrict__ verts, const float* __restrict__ bbox,
-                                                  unsigned long long* __restrict__ packed, int* __restrict__ stats) {
+__device__ __forceinline__ void nn_cull_body(int M, int V, int nunits, int mper, const float* __restrict__ x,
+                                             const float* __restrict__ verts, const float* __restrict__ bbox,
+                                             unsigned long long* __restrict__ packed, int* __restrict__ stats) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ float sbox[CULL_MAXU * 6];
   __shared__ float smx[CULL_MG * 3];
@@ -285,6 +336,23 @@ __global__ __launch_bounds__(CULL_T) void k_nn_cull(int M, int V, int nunits, in
   if (tid == 0 && stats) stats[f * CULL_MAXG + blockIdx.y] = overflow ? -found : found;
 }
 
+struct NnCullArgs {
+  UuoGridHdr h;
+  int M, V, nunits, mper;
+  const float* x;
+  const float* verts;
+  const float* bbox;
+  unsigned long long* packed;
+  int* stats;
+};
+__global__ __launch_bounds__(CULL_T) void k_nn_cull(NnCullArgs a) {
+  nn_cull_body(a.M, a.V, a.nunits, a.mper, a.x, a.verts, a.bbox, a.packed, a.stats);
+}
+__global__ __launch_bounds__(CULL_T) void k_nn_cull_b(const NnCullArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(NnCullArgs, batch)
+  nn_cull_body(a.M, a.V, a.nunits, a.mper, a.x, a.verts, a.bbox, a.packed, a.stats);
+}
+
 int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
                        const float* bbox, unsigned long long* packed, int* stats) {
   if (F <= 0 || M <= 0) return 0;
@@ -294,7 +362,26 @@ int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const flo
   while (G < CULL_MAXG && (long)F * G < 1024 && (M + G) / (G + 1) >= 8) ++G;
   const int mper = (M + G - 1) / G;
   UUO_REQUIRE(mper <= CULL_MG && G <= CULL_MAXG, "uuo_launch_nn_cull: too many markers per frame for the pruned search");
-  hipLaunchKernelGGL(k_nn_cull, dim3(F, G), dim3(CULL_T), 0, s, M, V, nunits, mper, markers, verts, bbox, packed, stats);
+  NnCullArgs a{{F, G}, M, V, nunits, mper, markers, verts, bbox, packed, stats};
+  if (uuo_record(UUO_OP_NN_CULL, F, G, a)) return 0;
+  hipLaunchKernelGGL(k_nn_cull, dim3(F, G), dim3(CULL_T), 0, s, a);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// batched launches of this file's kernels (uuo_common.h): 0 = launched, 1 = not one of mine, < 0 = error
+int uuo_batched_launch_nn(int op, hipStream_t s, const void* d_args, int count, int gx, int gy) {
+  if (op == UUO_OP_FILL) {
+    hipLaunchKernelGGL(k_fill_keys_b, dim3(gx, gy, count), dim3(256), 0, s, (const FillArgs*)d_args);
+  } else if (op == UUO_OP_NN) {
+    hipLaunchKernelGGL(k_nn_b, dim3(gx, gy, count), dim3(64), 0, s, (const NnArgs*)d_args);
+  } else if (op == UUO_OP_NN_FEWQ) {
+    hipLaunchKernelGGL(k_nn_fewq_b, dim3(gx, gy, count), dim3(256), 0, s, (const NnArgs*)d_args);
+  } else if (op == UUO_OP_NN_CULL) {
+    hipLaunchKernelGGL(k_nn_cull_b, dim3(gx, gy, count), dim3(CULL_T), 0, s, (const NnCullArgs*)d_args);
+  } else {
+    return 1;
+  }
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -10,9 +10,9 @@
 // K_A  pose_prep: one wave per frame.  Writes the A operand of the blend GEMM (pose features | betas) in
 // MFMA-operand order pfaT[ft][14][64][4], the 24 skinning matrices A[f][j][3x4] and posed joints.
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree* __restrict__ tree, int F,
-                                                   float* __restrict__ pfaT, float* __restrict__ A,
-                                                   float* __restrict__ jposed, float* __restrict__ frames) {
+__device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoTree* __restrict__ tree, int F,
+                                               float* __restrict__ pfaT, float* __restrict__ A,
+                                               float* __restrict__ jposed, float* __restrict__ frames) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   const int f = blockIdx.x;
@@ -47,9 +47,29 @@ __global__ __launch_bounds__(64) void k_pose_prep(UuoPoseSrc src, const UuoTree*
   }
 }
 
+struct PosePrepArgs {
+  UuoGridHdr h;
+  UuoPoseSrc src;
+  const UuoTree* tree;
+  int F;
+  float* pfaT;
+  float* A;
+  float* jposed;
+  float* frames;
+};
+__global__ __launch_bounds__(64) void k_pose_prep(PosePrepArgs a) {
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames);
+}
+__global__ __launch_bounds__(64) void k_pose_prep_b(const PosePrepArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(PosePrepArgs, batch)
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames);
+}
+
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
                          float* jposed, float* frames) {
-  hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, src, m->tree, F, pfaT, A, jposed, frames);
+  PosePrepArgs a{{F, 1}, src, m->tree, F, pfaT, A, jposed, frames};
+  if (uuo_record(UUO_OP_POSE_PREP, F, 1, a)) return 0;
+  hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -697,8 +717,23 @@ static bool sk2_fits(int nFT, int nur, int npos) {
 static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                               const float* trans, float* verts, float* bbox);
 
+struct SkinCallArgs {  // UUO_OP_SKIN: a whole-GPU kernel; a lock-step batch replays these calls one problem after the other
+  UuoGridHdr h;
+  const uuo_model* m;
+  int F;
+  const float* pfaT;
+  const float* A;
+  const float* trans;
+  float* verts;
+  float* bbox;
+};
+
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
                     float* verts, float* bbox) {
+  {
+    SkinCallArgs c{{1, 1}, m, F, pfaT, A, trans, verts, bbox};
+    if (uuo_record(UUO_OP_SKIN, 1, 1, c)) return 0;
+  }
   static const int force_v1 = UUO_ENV_INT("UUO_SKIN_V1", 0);  // ablation / comparison only
   const int nur = (m->V + 15) / 16;  // units with vertices = stride of the box table
   const int npos = 1 << SK2_NPOS_LOG2;  // 8 XCDs x 32 CUs, one 8-wave block per CU
@@ -783,11 +818,11 @@ static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const fl
 // in LDS: 12 B read + 12 B written per vertex and frame instead of the 207-term contraction.
 // ----------------------------------------------------------------------------------------------------
 #define SKC_FB 10  // frames per block
-__global__ __launch_bounds__(256) void k_skin_cached(int F, int V, int ns, const int32_t* __restrict__ subset,
-                                                     const float* __restrict__ C, const float* __restrict__ ST,
-                                                     const int* __restrict__ Wi, const float* __restrict__ Ww,
-                                                     const float* __restrict__ A, const float* __restrict__ betas,
-                                                     const float* __restrict__ trans, float* __restrict__ verts) {
+__device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int32_t* __restrict__ subset,
+                                                 const float* __restrict__ C, const float* __restrict__ ST,
+                                                 const int* __restrict__ Wi, const float* __restrict__ Ww,
+                                                 const float* __restrict__ A, const float* __restrict__ betas,
+                                                 const float* __restrict__ trans, float* __restrict__ verts) {
   __shared__ float sA[SKC_FB * UUO_NUM_JOINTS * 12];
   __shared__ float sTr[SKC_FB * 3];
   const int f0 = blockIdx.y * SKC_FB, nf = min(SKC_FB, F - f0);
@@ -827,13 +862,36 @@ __global__ __launch_bounds__(256) void k_skin_cached(int F, int V, int ns, const
   }
 }
 
+struct SkinCachedArgs {
+  UuoGridHdr h;
+  int F, V, ns;
+  const int32_t* subset;
+  const float* C;
+  const float* ST;
+  const int* Wi;
+  const float* Ww;
+  const float* A;
+  const float* betas;
+  const float* trans;
+  float* verts;
+};
+__global__ __launch_bounds__(256) void k_skin_cached(SkinCachedArgs a) {
+  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts);
+}
+__global__ __launch_bounds__(256) void k_skin_cached_b(const SkinCachedArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(SkinCachedArgs, batch)
+  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts);
+}
+
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
                            const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts) {
   UUO_REQUIRE(m->nnz <= 4, "uuo_launch_skin_cached: needs the sparse skin-weight tables");
   const int ns = subset ? n_subset : m->V;
   if (F <= 0 || ns <= 0) return 0;
-  hipLaunchKernelGGL(k_skin_cached, dim3((ns + 255) / 256, (F + SKC_FB - 1) / SKC_FB), dim3(256), 0, s, F, m->V, ns, subset,
-                     cache, m->ST, m->Wi, m->Ww, A, betas, trans, verts);
+  const int gx = (ns + 255) / 256, gy = (F + SKC_FB - 1) / SKC_FB;
+  SkinCachedArgs a{{gx, gy}, F, m->V, ns, subset, cache, m->ST, m->Wi, m->Ww, A, betas, trans, verts};
+  if (uuo_record(UUO_OP_SKIN_CACHED, gx, gy, a)) return 0;
+  hipLaunchKernelGGL(k_skin_cached, dim3(gx, gy), dim3(256), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -928,4 +986,23 @@ extern "C" int uuo_smpl_forward(uuo_model_t* m, void* stream, int F, const float
   if (rc) return rc;
   if (d_joints) rc = uuo_launch_joints45(m, s, F, sc.jp, d_verts, d_joints);
   return rc;
+}
+
+// batched launches of this file's kernels (uuo_common.h): 0 = launched, 1 = not one of mine, < 0 = error
+int uuo_batched_launch_smpl(int op, hipStream_t s, const void* d_args, int count, int gx, int gy) {
+  if (op == UUO_OP_POSE_PREP) {
+    hipLaunchKernelGGL(k_pose_prep_b, dim3(gx, gy, count), dim3(64), 0, s, (const PosePrepArgs*)d_args);
+  } else if (op == UUO_OP_SKIN_CACHED) {
+    hipLaunchKernelGGL(k_skin_cached_b, dim3(gx, gy, count), dim3(256), 0, s, (const SkinCachedArgs*)d_args);
+  } else {
+    return 1;
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// replay of one recorded UUO_OP_SKIN call (host copy of its arguments), outside record mode
+int uuo_replay_skin_call(hipStream_t s, const void* h_args) {
+  const SkinCallArgs* c = (const SkinCallArgs*)h_args;
+  return uuo_launch_skin(c->m, s, c->F, c->pfaT, c->A, c->trans, c->verts, c->bbox);
 }

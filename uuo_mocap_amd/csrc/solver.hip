@@ -50,7 +50,7 @@ __global__ void k_lb_init(LbDev* st) {
 
 // ---------------------------------------------------------------------------------------------------- kernels
 // first iteration: d = -g and the first trial point x + t d in one pass
-__global__ void k_lb_neg(int n, const float* __restrict__ g, float* __restrict__ d, const float* __restrict__ x,
+__device__ __forceinline__ void lb_neg_body(int n, const float* __restrict__ g, float* __restrict__ d, const float* __restrict__ x,
                          float t, float* __restrict__ xt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -60,10 +60,38 @@ __global__ void k_lb_neg(int n, const float* __restrict__ g, float* __restrict__
   }
 }
 
-__global__ void k_lb_axpy(int n, const float* __restrict__ x, float t, const float* __restrict__ d,
+__device__ __forceinline__ void lb_axpy_body(int n, const float* __restrict__ x, float t, const float* __restrict__ d,
                           float* __restrict__ o) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = x[i] + t * d[i];  // p.add_(d, alpha=t): one multiply, one add (no contraction)
+}
+
+struct LbNegArgs {
+  UuoGridHdr h;
+  int n;
+  const float* g;
+  float* d;
+  const float* x;
+  float t;
+  float* xt;
+};
+__global__ void k_lb_neg(LbNegArgs a) { lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt); }
+__global__ void k_lb_neg_b(const LbNegArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(LbNegArgs, batch)
+  lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt);
+}
+struct LbAxpyArgs {
+  UuoGridHdr h;
+  int n;
+  const float* x;
+  float t;
+  const float* d;
+  float* o;
+};
+__global__ void k_lb_axpy(LbAxpyArgs a) { lb_axpy_body(a.n, a.x, a.t, a.d, a.o); }
+__global__ void k_lb_axpy_b(const LbAxpyArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(LbAxpyArgs, batch)
+  lb_axpy_body(a.n, a.x, a.t, a.d, a.o);
 }
 
 __global__ void k_lb_form(int n, const float* __restrict__ g, const float* __restrict__ gp,
@@ -159,7 +187,7 @@ __device__ __host__ __forceinline__ size_t lb_hist_off(int slot, int i, int capL
 // loads of a column block in flight together.  Per-lane fp64 accumulators, one wave reduction per row at the end.
 #define LB_DRS 16                        // row splits
 #define LB_DRW ((LB_ROWS + 4 * LB_DRS - 1) / (4 * LB_DRS))  // rows per wave (4)
-__global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int head, int count, int cand,
+__device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head, int count, int cand,
                                                   float* __restrict__ S, float* __restrict__ Y,
                                                   const float* __restrict__ g, const float* __restrict__ gp,
                                                   const float* __restrict__ d, float t, int ncb, int gcb,
@@ -269,6 +297,26 @@ __global__ __launch_bounds__(256) void k_lb_dots(int n, int cap, int capL, int h
       }
     }
   }
+}
+
+struct LbDotsArgs {
+  UuoGridHdr h;
+  int n, cap, capL, head, count, cand;
+  float* S;
+  float* Y;
+  const float* g;
+  const float* gp;
+  const float* d;
+  float t;
+  int ncb, gcb;
+  double* part;
+};
+__global__ __launch_bounds__(256) void k_lb_dots(LbDotsArgs a) {
+  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part);
+}
+__global__ __launch_bounds__(256) void k_lb_dots_b(const LbDotsArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(LbDotsArgs, batch)
+  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part);
 }
 
 // One block: reduce the dot partials, update the Gram matrices and the ring, then run the two-loop recursion of
@@ -851,7 +899,7 @@ __device__ __forceinline__ double quad_sum_d(double v) {  // sum over the 4 lane
   const double a = v + __shfl_xor(v, 1, 64);
   return a + __shfl_xor(a, 2, 64);
 }
-__global__ __launch_bounds__(512) void k_lb_small_inv(int nchunks, int cap, int hist, int cand,
+__device__ __forceinline__ void lb_small_inv_body(int nchunks, int cap, int hist, int cand,
                                                        const double* __restrict__ part, LbDev* __restrict__ st,
                                                        int stop) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
@@ -1049,8 +1097,23 @@ __global__ __launch_bounds__(512) void k_lb_small_inv(int nchunks, int cap, int 
   }
 }
 
+struct LbSmallArgs {
+  UuoGridHdr h;
+  int nchunks, cap, hist, cand;
+  const double* part;
+  LbDev* st;
+  int stop;
+};
+__global__ __launch_bounds__(512) void k_lb_small_inv(LbSmallArgs a) {
+  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop);
+}
+__global__ __launch_bounds__(512) void k_lb_small_inv_b(const LbSmallArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(LbSmallArgs, batch)
+  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop);
+}
+
 #define LB_DQ 4  // slot ranges per 256-column strip of k_lb_direction (one wave each)
-__global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction(int n, int cap, int capL, const float* __restrict__ S,
+__device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, const float* __restrict__ S,
                                                              const float* __restrict__ Y, const float* __restrict__ g,
                                                              LbDev* __restrict__ st, float* __restrict__ d,
                                                              const float* __restrict__ x, float t, float* __restrict__ xt) {
@@ -1158,6 +1221,27 @@ struct StageObjective : Objective {
   }
 };
 
+struct LbDirArgs {
+  UuoGridHdr h;
+  int n, cap, capL;
+  const float* S;
+  const float* Y;
+  const float* g;
+  LbDev* st;
+  float* d;
+  const float* x;
+  float t;
+  float* xt;
+};
+__global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction(LbDirArgs a) {
+  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt);
+}
+__global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction_b(const LbDirArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(LbDirArgs, batch)
+  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt);
+}
+
+
 // test objectives for the optimiser itself (tests/test_lbfgs.py): 0 = convex quadratic with a spread
 // spectrum, 1 = chained Rosenbrock.  loss/grad are computed by one block (n is small in the tests).
 __global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const float* __restrict__ x,
@@ -1232,7 +1316,7 @@ static int lbws_destroy(LbWs* w) {
   return 0;
 }
 
-static int lbws_create(int n, int hist, LbWs** out) {
+static int lbws_create(int n, int hist, LbWs** out, bool sync = true) {
   UUO_REQUIRE(hist >= 1 && hist <= LB_MAXH - 4, "lbfgs: history_size must be in [1,100]");
   LbWs* w = new LbWs();
   n = (n + LB_CW - 1) / LB_CW * LB_CW;  // whole column blocks: 16-byte loads of the work vectors stay in bounds
@@ -1260,13 +1344,34 @@ static int lbws_create(int n, int hist, LbWs** out) {
   if (e == hipSuccess) e = hipMemset(w->Y, 0, hist_floats * sizeof(float));
   if (e == hipSuccess) e = hipMemset(w->vecs, 0, (size_t)LB_NVEC * n * sizeof(float));
   // null-stream memsets are not ordered with the (non-blocking) stream the first solve runs on
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess && sync) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     lbws_destroy(w);
     uuo_set_error(std::string("lbfgs workspace: ") + hipGetErrorString(e));
     return -12;
   }
   *out = w;
+  return 0;
+}
+
+// issue now, or record for the lock-step batch that is stepping this problem (uuo_common.h)
+template <class A, class K>
+static inline void lb_dispatch(int op, hipStream_t s, dim3 grid, dim3 block, K kernel, A& a) {
+  a.h.gx = (int)grid.x;
+  a.h.gy = (int)grid.y;
+  if (uuo_record(op, (int)grid.x, (int)grid.y, a)) return;
+  hipLaunchKernelGGL(kernel, grid, block, 0, s, a);
+}
+struct LbCopyArgs {  // UUO_OP_COPY: device-to-device copy of n floats
+  UuoGridHdr h;
+  float* dst;
+  const float* src;
+  size_t bytes;
+};
+static inline int lb_copy(hipStream_t s, float* dst, const float* src, size_t bytes) {
+  LbCopyArgs c{{1, 1}, dst, src, bytes};
+  if (uuo_record(UUO_OP_COPY, 1, 1, c)) return 0;
+  UUO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 
@@ -1310,8 +1415,13 @@ struct LbHostOut {  // mirror of the tail of LbDev read back after every closure
   LbOut out;
 };
 
+// lock-step batches: while a batch steps this problem its launches are recorded (uuo_recorder) and `evaluate` hands control
+// back to the batch scheduler instead of polling; the scheduler resumes the solve when the evaluation has reported
+static thread_local void (*g_batch_yield)(void) = nullptr;
+
 static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
                      uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
+  const bool batched = uuo_recorder != nullptr;
   const int n = obj.n;
   UUO_REQUIRE(n > 0 && n <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
@@ -1366,6 +1476,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     }
     int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr, poll ? &rep : nullptr);
     if (rc) return rc;
+    if (batched) {  // the batch scheduler issues the recorded launches of all its problems and waits for their reports
+      UUO_REQUIRE(poll && g_batch_yield, "lbfgs: a lock-step batch needs the polled report path");
+      g_batch_yield();
+      return 0;
+    }
     if (poll) {
       // Bounded wait: the report word is polled; every ~1M polls the stream is queried (a failed or drained stream that
       // never reported is an error) and the wall clock is checked against eval_timeout_s -- a kernel that never finishes
@@ -1414,7 +1529,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     ++evals_total;
   };
 
-  UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
+  if (!batched) UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
   hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, w->st);
   int ig = pool_alloc();  // gradient at the current iterate
   int ipg = -1;           // gradient at the previous iterate
@@ -1445,23 +1560,26 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         t = lr;
       // ---------------------------------------------------------------- direction + first trial point
       if (n_iter == 1) {
-        hipLaunchKernelGGL(k_lb_neg, dim3(nb), dim3(256), 0, s, n, g, d, xcur, (float)t, xoth);
+        LbNegArgs na{{0, 0}, n, g, d, xcur, (float)t, xoth};
+        lb_dispatch(UUO_OP_NEG, s, dim3(nb), dim3(256), k_lb_neg, na);
       } else {
         const int cand = (head + count) % cap;
         const int nrows = 2 * (count + 1) + 1;
-        hipLaunchKernelGGL(k_lb_dots, dim3(nchunks, LB_DRS), dim3(256), 0, s, n, cap, w->cap, head, count, cand, w->S,
-                           w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part);
+        LbDotsArgs da{{0, 0}, n, cap, w->cap, head, count, cand, w->S, w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part};
+        lb_dispatch(UUO_OP_DOTS, s, dim3(nchunks, LB_DRS), dim3(256), k_lb_dots, da);
         static const int small_stop = UUO_ENV_INT("UUO_SMALL_STOP", 0);  // ablation only
         static const int small_ref = UUO_ENV_INT("UUO_SMALL_REF", 0);  // comparison only
         static const int small_block = UUO_ENV_INT("UUO_SMALL_BLOCK", 0);  // comparison only
-        if (small_ref)
+        if (small_ref && !uuo_recorder)
           hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        else if (small_block)
+        else if (small_block && !uuo_recorder)
           hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        else
-          hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
-        hipLaunchKernelGGL(k_lb_direction, dim3(2 * ncb), dim3(64 * LB_DQ), 0, s, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur,
-                           (float)t, xoth);
+        else {
+          LbSmallArgs sa{{0, 0}, nchunks, cap, hist, cand, w->part, w->st, small_stop};
+          lb_dispatch(UUO_OP_SMALL, s, dim3(1), dim3(512), k_lb_small_inv, sa);
+        }
+        LbDirArgs ra{{0, 0}, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur, (float)t, xoth};
+        lb_dispatch(UUO_OP_DIR, s, dim3(2 * ncb), dim3(64 * LB_DQ), k_lb_direction, ra);
       }
       UUO_HIP_CHECK(hipGetLastError());
       prev_loss = loss;
@@ -1512,7 +1630,8 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       auto trial = [&](LsPoint& pt) -> int {
         pt.buf = pool_alloc();
         UUO_REQUIRE(pt.buf >= 0, "lbfgs: gradient pool exhausted");
-        hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, xcur, (float)pt.t, d, xoth);
+        LbAxpyArgs xa{{0, 0}, n, xcur, (float)pt.t, d, xoth};
+        lb_dispatch(UUO_OP_AXPY, s, dim3(nb), dim3(256), k_lb_axpy, xa);
         int r = evaluate(xoth, vec(pt.buf), true);
         if (r) return r;
         t_at_xoth = pt.t;
@@ -1633,7 +1752,10 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       if (res.t == 0.0) {
         // line search returned the starting point (bracket low at t = 0): iterate unchanged
       } else {
-        if (t_at_xoth != res.t) hipLaunchKernelGGL(k_lb_axpy, dim3(nb), dim3(256), 0, s, n, xcur, (float)t, d, xoth);
+        if (t_at_xoth != res.t) {
+          LbAxpyArgs xa{{0, 0}, n, xcur, (float)t, d, xoth};
+          lb_dispatch(UUO_OP_AXPY_ACCEPT, s, dim3(nb), dim3(256), k_lb_axpy, xa);
+        }
         float* tmp = xcur;
         xcur = xoth;
         xoth = tmp;
@@ -1647,7 +1769,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           // accepted point is the starting point: prev gradient must still become a copy of g (y = 0 next time)
           ipg = (old_pg >= 0 && old_pg != old_g) ? old_pg : pool_alloc();
           pool_used[ipg] = true;
-          UUO_HIP_CHECK(hipMemcpyAsync(vec(ipg), vec(old_g), (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+          { const int rc_ = lb_copy(s, vec(ipg), vec(old_g), (size_t)n * sizeof(float)); if (rc_) return rc_; }
           ig = old_g;
         } else {
           ipg = old_g;
@@ -1680,12 +1802,16 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       }
     }
   }
-  if (xcur != d_x)
-    UUO_HIP_CHECK(hipMemcpyAsync(d_x, xcur, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  UUO_HIP_CHECK(hipEventRecord(w->ev1, s));
-  UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
+  if (xcur != d_x) {
+    const int rc_ = lb_copy(s, d_x, xcur, (size_t)n * sizeof(float));
+    if (rc_) return rc_;
+  }
   float ms = 0.f;
-  UUO_HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+  if (!batched) {
+    UUO_HIP_CHECK(hipEventRecord(w->ev1, s));
+    UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
+    UUO_HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+  }
   stats->n_iter = n_iter;
   stats->n_eval = current_evals;
   stats->final_loss = (float)loss;
@@ -1695,7 +1821,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
 }
 
 // ---------------------------------------------------------------------------------------------------- fit workspace
+static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bool sync);
 extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out) {
+  return fit_create_impl(model, F, M, out, true);
+}
+static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bool sync) {
   UUO_REQUIRE(model && out, "uuo_fit_create: null argument");
   UUO_REQUIRE(F > 0 && M > 0, "uuo_fit_create: F and M must be positive");
   uuo_fit* fit = new uuo_fit();
@@ -1729,7 +1859,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
     uuo_fit_destroy(fit);
     return -12;
   }
-  UUO_HIP_CHECK(hipDeviceSynchronize());  // the zero fills above ran on the null stream
+  if (sync) UUO_HIP_CHECK(hipDeviceSynchronize());  // the zero fills above ran on the null stream
   *out = fit;
   return 0;
 }
@@ -1737,7 +1867,7 @@ extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out)
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
   void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs,
-                  fit->pose_cache, fit->zeros16};
+                  fit->shared_pose_cache ? nullptr : fit->pose_cache, fit->zeros16};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);
@@ -1781,6 +1911,339 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   obj.n = uuo_problem_num_params(p);
   std::memset(stats, 0, sizeof(*stats));
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
+}
+
+// ---------------------------------------------------------------------------------------------------- lock-step batches
+// B independent L-BFGS problems of one stage and one (F, M) -- the candidate body parts of find_best_part_fits
+// (reference markers/markers_utils.py:416-610 solves them one after the other) or the yaw hypotheses of
+// multimodal_video_mocap (multimodal.py:462-574) -- stepped together: one ROUND = one closure evaluation of every live
+// problem, every kernel of the round launched once for all of them (grid z = problem).  Each problem runs the unchanged
+// lbfgs_run (same decisions, same arithmetic, same kernels' bodies: bit-identical to solving it alone) as a coroutine on
+// its own stack; where the single-problem driver would poll for its evaluation's report it yields to the scheduler, which
+// merges the launches the live problems recorded, stages their argument structs with one host-to-device copy, issues them
+// in the canonical order of uuo_common.h and waits for every report.  A problem that converged simply stops taking part.
+#include <ucontext.h>
+
+struct BatchCo {
+  ucontext_t ctx;
+  std::vector<unsigned char> stack;
+  UuoRecorder rec;
+  StageObjective obj;
+  LbWs* w = nullptr;
+  float* d_x = nullptr;
+  const uuo_lbfgs_options_t* opt = nullptr;
+  uuo_lbfgs_stats_t* stats = nullptr;
+  hipStream_t s = nullptr;
+  int rc = 0;
+  bool done = false, started = false, waiting = false;
+};
+
+struct uuo_batch {
+  uuo_model* model = nullptr;
+  int stage = 0, F = 0, M = 0, B = 0;
+  std::vector<uuo_fit*> fits;
+  std::vector<LbWs*> ws;
+  float* pose_cache = nullptr;  // part stage: the one pose-corrective blend all candidates share
+  unsigned char* h_blob = nullptr;  // pinned staging of one round's argument structs
+  unsigned char* d_blob = nullptr;
+  size_t blob_cap = 0;
+  int lb_n = 0, lb_hist = 0;
+};
+
+static thread_local ucontext_t g_sched_ctx;
+static thread_local BatchCo* g_cur_co = nullptr;
+
+static void batch_yield_impl() {
+  BatchCo* c = g_cur_co;
+  c->waiting = true;
+  swapcontext(&c->ctx, &g_sched_ctx);
+}
+
+static void batch_co_entry(unsigned lo, unsigned hi) {
+  BatchCo* c = reinterpret_cast<BatchCo*>(((unsigned long long)hi << 32) | (unsigned long long)lo);
+  c->rc = lbfgs_run(c->w, c->s, c->obj, c->d_x, c->opt, c->stats, nullptr, nullptr);
+  c->done = true;
+  c->waiting = false;
+  swapcontext(&c->ctx, &g_sched_ctx);
+}
+
+extern "C" int uuo_batch_destroy(uuo_batch_t* b) {
+  if (!b) return 0;
+  for (uuo_fit* f : b->fits) uuo_fit_destroy(f);  // also frees the fit's own L-BFGS workspace (fit->lbws)
+  if (b->pose_cache) (void)hipFree(b->pose_cache);
+  if (b->h_blob) (void)hipHostFree(b->h_blob);
+  if (b->d_blob) (void)hipFree(b->d_blob);
+  delete b;
+  return 0;
+}
+
+extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int B, uuo_batch_t** out) {
+  UUO_REQUIRE(model && out, "uuo_batch_create: null argument");
+  UUO_REQUIRE(stage >= 0 && stage <= 2 && F > 0 && M > 0 && B > 0 && B <= 4096, "uuo_batch_create: bad stage / sizes");
+  UUO_REQUIRE(model->nnz <= 4, "uuo_batch_create: needs the sparse skin-weight tables (<= 4 weights per vertex)");
+  uuo_batch* b = new uuo_batch();
+  b->model = model;
+  b->stage = stage;
+  b->F = F;
+  b->M = M;
+  b->B = B;
+  int rc = 0;
+  for (int i = 0; i < B && rc == 0; ++i) {
+    uuo_fit* f = nullptr;
+    rc = fit_create_impl(model, F, M, &f, false);
+    if (rc == 0) b->fits.push_back(f);
+  }
+  if (rc == 0 && stage == UUO_STAGE_PART) {
+    if (hipMalloc((void**)&b->pose_cache, (size_t)F * model->V * 3 * sizeof(float)) != hipSuccess) {
+      uuo_set_error("uuo_batch_create: pose cache allocation failed");
+      rc = -12;
+    } else {
+      for (uuo_fit* f : b->fits) {
+        f->pose_cache = b->pose_cache;
+        f->shared_pose_cache = true;
+      }
+    }
+  }
+  b->blob_cap = (size_t)B * 12 * UUO_OP_ARG_MAX + 4096;
+  if (rc == 0 && hipHostMalloc((void**)&b->h_blob, b->blob_cap, hipHostMallocDefault) != hipSuccess) rc = -12;
+  if (rc == 0 && hipMalloc((void**)&b->d_blob, b->blob_cap) != hipSuccess) rc = -12;
+  if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -5;  // the workspaces' zero fills ran on the null stream
+  if (rc != 0) {
+    if (rc == -12) uuo_set_error("uuo_batch_create: allocation failed");
+    uuo_batch_destroy(b);
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+// one round's recorded launches of all problems, merged by kind
+static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, int nb) {
+  // validate the per-problem order and count bytes
+  size_t off[UUO_OP_COUNT], cnt[UUO_OP_COUNT], width[UUO_OP_COUNT];
+  int gx[UUO_OP_COUNT], gy[UUO_OP_COUNT];
+  for (int k = 0; k < UUO_OP_COUNT; ++k) off[k] = cnt[k] = width[k] = 0, gx[k] = gy[k] = 0;
+  bool any = false;
+  for (int i = 0; i < nb; ++i) {
+    int last = -1;
+    for (const UuoOpRec& r : cos[i].rec.ops) {
+      UUO_REQUIRE(r.op >= last && (r.op > last || r.op == UUO_OP_COPY), "batch: a problem recorded its launches out of the canonical order");
+      last = r.op;
+      cnt[r.op] += 1;
+      UUO_REQUIRE(width[r.op] == 0 || width[r.op] == r.nbytes, "batch: argument structs of one kind differ in size");
+      width[r.op] = r.nbytes;
+      if (r.gx > gx[r.op]) gx[r.op] = r.gx;
+      if (r.gy > gy[r.op]) gy[r.op] = r.gy;
+      any = true;
+    }
+  }
+  if (!any) return 0;
+  size_t total = 0;
+  for (int k = 0; k < UUO_OP_COUNT; ++k) {
+    if (k == UUO_OP_COPY || k == UUO_OP_SKIN) continue;  // issued one by one from the host copies
+    off[k] = total;
+    total += (cnt[k] * width[k] + 255) / 256 * 256;
+  }
+  UUO_REQUIRE(total <= b->blob_cap, "batch: argument staging buffer too small");
+  size_t fill[UUO_OP_COUNT];
+  for (int k = 0; k < UUO_OP_COUNT; ++k) fill[k] = 0;
+  for (int i = 0; i < nb; ++i)
+    for (const UuoOpRec& r : cos[i].rec.ops) {
+      if (r.op == UUO_OP_COPY || r.op == UUO_OP_SKIN) continue;
+      std::memcpy(b->h_blob + off[r.op] + fill[r.op] * width[r.op], r.args, r.nbytes);
+      fill[r.op] += 1;
+    }
+  if (total) UUO_HIP_CHECK(hipMemcpyAsync(b->d_blob, b->h_blob, total, hipMemcpyHostToDevice, s));
+  for (int k = 0; k < UUO_OP_COUNT; ++k) {
+    if (cnt[k] == 0) continue;
+    if (k == UUO_OP_COPY) {
+      for (int i = 0; i < nb; ++i)
+        for (const UuoOpRec& r : cos[i].rec.ops)
+          if (r.op == UUO_OP_COPY) {
+            const LbCopyArgs* c = reinterpret_cast<const LbCopyArgs*>(r.args);
+            UUO_HIP_CHECK(hipMemcpyAsync(c->dst, c->src, c->bytes, hipMemcpyDeviceToDevice, s));
+          }
+      continue;
+    }
+    if (k == UUO_OP_SKIN) {
+      for (int i = 0; i < nb; ++i)
+        for (const UuoOpRec& r : cos[i].rec.ops)
+          if (r.op == UUO_OP_SKIN) {
+            const int rc = uuo_replay_skin_call(s, r.args);
+            if (rc) return rc;
+          }
+      continue;
+    }
+    const void* da = b->d_blob + off[k];
+    const int n_ = (int)cnt[k];
+    int rc = 1;
+    switch (k) {
+      case UUO_OP_AXPY_ACCEPT:
+      case UUO_OP_AXPY:
+        hipLaunchKernelGGL(k_lb_axpy_b, dim3(gx[k], gy[k], n_), dim3(256), 0, s, (const LbAxpyArgs*)da);
+        rc = 0;
+        break;
+      case UUO_OP_NEG:
+        hipLaunchKernelGGL(k_lb_neg_b, dim3(gx[k], gy[k], n_), dim3(256), 0, s, (const LbNegArgs*)da);
+        rc = 0;
+        break;
+      case UUO_OP_DOTS:
+        hipLaunchKernelGGL(k_lb_dots_b, dim3(gx[k], gy[k], n_), dim3(256), 0, s, (const LbDotsArgs*)da);
+        rc = 0;
+        break;
+      case UUO_OP_SMALL:
+        hipLaunchKernelGGL(k_lb_small_inv_b, dim3(gx[k], gy[k], n_), dim3(512), 0, s, (const LbSmallArgs*)da);
+        rc = 0;
+        break;
+      case UUO_OP_DIR:
+        hipLaunchKernelGGL(k_lb_direction_b, dim3(gx[k], gy[k], n_), dim3(64 * LB_DQ), 0, s, (const LbDirArgs*)da);
+        rc = 0;
+        break;
+      default:
+        rc = uuo_batched_launch_smpl(k, s, da, n_, gx[k], gy[k]);
+        if (rc == 1) rc = uuo_batched_launch_nn(k, s, da, n_, gx[k], gy[k]);
+        if (rc == 1) rc = uuo_batched_launch_closure(k, s, da, n_, gx[k], gy[k]);
+        UUO_REQUIRE(rc != 1, "batch: no batched kernel for a recorded launch kind");
+        break;
+    }
+    if (rc) return rc;
+    UUO_HIP_CHECK(hipGetLastError());
+  }
+  for (int i = 0; i < nb; ++i) cos[i].rec.ops.clear();
+  return 0;
+}
+
+extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t* problems, float* const* d_xs, int nb,
+                               const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats) {
+  UUO_REQUIRE(b && problems && d_xs && opt && stats, "uuo_batch_solve: null argument");
+  UUO_REQUIRE(nb >= 1 && nb <= b->B, "uuo_batch_solve: more problems than the batch was created for");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_batch_solve: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_batch_solve: batches do not nest");
+  hipStream_t s = (hipStream_t)stream;
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  int rc = 0;
+  for (int i = 0; i < nb; ++i) {
+    UUO_REQUIRE(problems[i].stage == b->stage, "uuo_batch_solve: every problem must be of the batch's stage");
+    rc = uuo_validate_problem(b->fits[i], &problems[i]);
+    if (rc) return rc;
+    UUO_REQUIRE(d_xs[i] != nullptr, "uuo_batch_solve: null parameter vector");
+  }
+  const int n_params = uuo_problem_num_params(&problems[0]);
+  // per-problem optimiser workspaces (kept with the fits; re-created when the history grows)
+  for (int i = 0; i < nb; ++i) {
+    LbWs* w = (LbWs*)b->fits[i]->lbws;
+    if (!w || w->cap < hist + 1 || w->n_cap < n_params) {
+      if (w) {
+        UUO_HIP_CHECK(hipStreamSynchronize(s));
+        lbws_destroy(w);
+      }
+      b->fits[i]->lbws = nullptr;
+      rc = lbws_create(n_params, hist, &w, false);
+      if (rc) return rc;
+      b->fits[i]->lbws = w;
+    }
+  }
+  UUO_HIP_CHECK(hipDeviceSynchronize());  // zero fills of new workspaces (null stream) before the first round
+  // marker masks (one small read-back each) and the shared pose cache, outside record mode
+  if (b->stage != UUO_STAGE_PART) {  // the part stage's chamfer term is unmasked (markers_utils.py:471-475)
+    for (int i = 0; i < nb; ++i) {
+      rc = uuo_ensure_mask(b->fits[i], s, &problems[i]);
+      if (rc) return rc;
+    }
+  }
+  if (b->stage == UUO_STAGE_PART && problems[0].pose_cache_id != 0) {
+    for (int i = 1; i < nb; ++i)
+      UUO_REQUIRE(problems[i].d_o_pose == problems[0].d_o_pose && problems[i].pose_cache_id != 0,
+                  "uuo_batch_solve: part-stage problems of one batch share the body pose (d_o_pose) and its cache");
+    b->fits[0]->pose_cache_id = 0;
+    rc = uuo_prepare_pose_cache(b->fits[0], s, &problems[0], d_xs[0]);
+    if (rc) return rc;
+    for (int i = 0; i < nb; ++i) b->fits[i]->pose_cache_id = problems[i].pose_cache_id;
+  }
+
+  std::vector<BatchCo> cos(nb);
+  const size_t stack_bytes = 256 * 1024;
+  for (int i = 0; i < nb; ++i) {
+    BatchCo& c = cos[i];
+    c.stack.resize(stack_bytes);
+    c.obj.fit = b->fits[i];
+    c.obj.p = &problems[i];
+    c.obj.fused_stats = true;
+    c.obj.n = n_params;
+    c.w = (LbWs*)b->fits[i]->lbws;
+    c.d_x = d_xs[i];
+    c.opt = opt;
+    c.stats = &stats[i];
+    c.s = s;
+    std::memset(&stats[i], 0, sizeof(stats[i]));
+    getcontext(&c.ctx);
+    c.ctx.uc_stack.ss_sp = c.stack.data();
+    c.ctx.uc_stack.ss_size = stack_bytes;
+    c.ctx.uc_link = &g_sched_ctx;
+    const unsigned long long pv = (unsigned long long)reinterpret_cast<uintptr_t>(&c);
+    makecontext(&c.ctx, (void (*)())batch_co_entry, 2, (unsigned)(pv & 0xFFFFFFFFull), (unsigned)(pv >> 32));
+  }
+  const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
+  g_batch_yield = batch_yield_impl;
+  int live = nb;
+  int result = 0;
+  while (live > 0 && result == 0) {
+    // step every live problem to its next evaluation (or to its end)
+    for (int i = 0; i < nb; ++i) {
+      BatchCo& c = cos[i];
+      if (c.done) continue;
+      c.waiting = false;
+      uuo_recorder = &c.rec;
+      g_cur_co = &c;
+      swapcontext(&g_sched_ctx, &c.ctx);
+      uuo_recorder = nullptr;
+      g_cur_co = nullptr;
+      if (c.done) {
+        --live;
+        if (c.rc && result == 0) result = c.rc;
+      }
+    }
+    if (result) break;
+    result = batch_flush(b, s, cos, nb);
+    if (result) break;
+    // wait for the reports of the problems that are in an evaluation
+    timespec t_start;
+    clock_gettime(CLOCK_MONOTONIC, &t_start);
+    for (int i = 0; i < nb && result == 0; ++i) {
+      BatchCo& c = cos[i];
+      if (c.done || !c.waiting) continue;
+      unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(c.w->h_out);
+      unsigned long spins = 0;
+      while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {
+          const hipError_t q = hipStreamQuery(s);
+          if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
+            uuo_set_error(std::string("batch: an evaluation did not report: ") + hipGetErrorString(q));
+            result = -5;
+            break;
+          }
+          timespec t_now;
+          clock_gettime(CLOCK_MONOTONIC, &t_now);
+          const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
+          if (waited > eval_timeout_s) {
+            uuo_set_error("batch: a round of evaluations did not finish within " + std::to_string((int)eval_timeout_s) + " s");
+            result = -62;
+            break;
+          }
+        }
+      }
+    }
+  }
+  g_batch_yield = nullptr;
+  uuo_recorder = nullptr;
+  if (result == 0) {
+    result = batch_flush(b, s, cos, nb);  // the final copies of problems that ended in the last round
+    if (result == 0) UUO_HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
+  }
+  return result;
 }
 
 // host copy of a device vector, ordered on `stream` and complete on return (the iter_fn adapter of the Python mirror
@@ -1844,7 +2307,7 @@ extern "C" int uuo_debug_time_small(int k, int iters, int stop, float* ms_out) {
     UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, Hdiag), &one, sizeof(double), hipMemcpyHostToDevice));
     UUO_HIP_CHECK(hipEventRecord(w->ev0, nullptr));
     if (stop >= 200)
-      hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 200);
+      { LbSmallArgs sa_{{1, 1}, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 200}; hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, sa_); }
     else if (stop >= 100)
       hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, stop - 100);
     else
@@ -1932,7 +2395,7 @@ extern "C" int uuo_debug_small_coeffs(int k, int use_ref, int seed, double* out)
       for (int r = 0; r < m; ++r) W[(size_t)r * LB_MAXH + c] = x[r];
     }
     UUO_HIP_CHECK(hipMemcpy((char*)w->st + offsetof(LbDev, W), W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
+    { LbSmallArgs sa_{{1, 1}, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0}; hipLaunchKernelGGL(k_lb_small_inv, dim3(1), dim3(512), 0, nullptr, sa_); }
   } else if (use_ref)
     hipLaunchKernelGGL(k_lb_small_ref, dim3(1), dim3(256), 0, nullptr, LB_MAXCHUNK, cap, hist, k - 1, w->part, w->st, 0);
   else

@@ -2,9 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/uuo_hip.h"
 
@@ -128,6 +130,7 @@ struct uuo_fit {
   void* lbws = nullptr;             // L-BFGS workspace (solver.hip), created on first solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float mask_sum = 0.f;  // host copy of sum(mask) (chamfer normaliser), refreshed by uuo_ensure_mask
+  bool shared_pose_cache = false;  // pose_cache belongs to a uuo_batch (not freed with the fit)
 };
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
@@ -156,6 +159,7 @@ int uuo_launch_finalize(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& 
 // closure internals shared with the solver (closure.hip)
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p);
 int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p);
+int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x);
 // Optional zero-copy report of a closure evaluation: the finalize kernel copies the 80-byte block that starts 8 bytes
 // before d_stats (the solver's {max|d| bits, pad, out[9]}) into `host` (pinned, device-visible) and then publishes
 // `seq` in host[10]; the solver polls that word instead of enqueueing a copy and synchronising the stream.
@@ -166,3 +170,67 @@ struct UuoEvalReport {
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
                           float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
                           const UuoEvalReport* report = nullptr);
+
+// ---- lock-step batches (uuo_batch_*: solver.hip) ------------------------------------------------------------------------
+// Every kernel of the solve path exists in two launch forms over ONE device body: k_X(XArgs) for a single problem and
+// k_X_b(const XArgs* batch) where blockIdx.z picks the problem (blocks outside a problem's own grid extent exit at once).
+// While a batch is being stepped, launches are not issued but RECORDED per problem (uuo_recorder != nullptr); the
+// scheduler then merges the records of all live problems by kind, in the canonical order below -- which is the order the
+// kinds occur in inside any one problem's round, so per-problem ordering is preserved by the in-order stream -- and
+// issues one launch per kind with the argument structs staged in device memory.
+enum {
+  UUO_OP_AXPY_ACCEPT = 0,  // x <- x + t d of the accepted step (end of an iteration)
+  UUO_OP_COPY,             // gradient hand-over copy (rare)
+  UUO_OP_DOTS,
+  UUO_OP_SMALL,
+  UUO_OP_DIR,
+  UUO_OP_NEG,
+  UUO_OP_AXPY,             // line-search trial point
+  UUO_OP_POSE_PREP,
+  UUO_OP_SKIN,             // k_skin / k_skin2: whole-GPU kernels, issued one problem after the other
+  UUO_OP_SKIN_CACHED,
+  UUO_OP_FILL,             // hipMemsetAsync
+  UUO_OP_NN,
+  UUO_OP_NN_FEWQ,
+  UUO_OP_NN_CULL,
+  UUO_OP_BWD,
+  UUO_OP_FIN,
+  UUO_OP_COUNT
+};
+#define UUO_OP_ARG_MAX 448
+struct UuoOpRec {
+  int op;
+  int gx, gy;
+  unsigned nbytes;
+  alignas(16) unsigned char args[UUO_OP_ARG_MAX];
+};
+struct UuoRecorder {
+  std::vector<UuoOpRec> ops;
+};
+extern thread_local UuoRecorder* uuo_recorder;
+template <class A>
+inline bool uuo_record(int op, int gx, int gy, const A& a) {
+  if (!uuo_recorder) return false;
+  static_assert(sizeof(A) <= UUO_OP_ARG_MAX, "argument struct too large for an op record");
+  UuoOpRec r;
+  r.op = op;
+  r.gx = gx;
+  r.gy = gy;
+  r.nbytes = (unsigned)sizeof(A);
+  std::memcpy(r.args, &a, sizeof(A));
+  uuo_recorder->ops.push_back(r);
+  return true;
+}
+// the argument struct of every batched kernel starts with its own grid extent
+struct UuoGridHdr {
+  int gx, gy;
+};
+#define UUO_BATCH_PICK(ArgsT, batch)                                      \
+  const ArgsT a = (batch)[blockIdx.z];                                    \
+  if ((int)blockIdx.x >= a.h.gx || (int)blockIdx.y >= a.h.gy) return;
+// batched launch of `count` records of one kind (d_args: count structs of that kind, contiguous in device memory);
+// each translation unit serves the kinds whose kernels it defines and returns 1 for the others
+int uuo_batched_launch_smpl(int op, hipStream_t s, const void* d_args, int count, int gx, int gy);
+int uuo_replay_skin_call(hipStream_t s, const void* h_args);
+int uuo_batched_launch_nn(int op, hipStream_t s, const void* d_args, int count, int gx, int gy);
+int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int count, int gx, int gy);

@@ -135,6 +135,49 @@ class _FitHandle:
             pass
 
 
+class _BatchHandle:
+    """Owner of one uuo_batch_t (B workspaces + the staging of a lock-step batch of independent solves)."""
+
+    def __init__(self, lib, ptr: c_void_p, device, shape, capacity: int):
+        self._lib, self.ptr, self._device, self.shape, self.capacity = lib, ptr, device, shape, capacity
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                with torch.cuda.device(self._device):
+                    self._lib.uuo_batch_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def solve_batch(problems, xs, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
+                tolerance_change: float = 1e-9, history_size: int = 100):
+    """uuo_batch_solve: the independent problems `problems` (same stage, F, M; e.g. the candidate body parts of
+    find_best_part_fits or the yaw hypotheses) solved in lock-step, one launch per kernel and round for all of them.
+    Each xs[i] is updated in place; returns one statistics dict per problem.  Results are bit-identical to
+    `problems[i].solve(xs[i], ...)` one after the other."""
+    assert len(problems) == len(xs) and len(problems) > 0
+    p0 = problems[0]
+    model = p0.model
+    for p, x in zip(problems, xs):
+        assert p.stage == p0.stage and p.F == p0.F and p.M == p0.M and p.model is model
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == p.n and x.is_contiguous()
+    nb = len(problems)
+    handle = model.batch(p0.stage, p0.F, p0.M, nb)
+    probs = (UuoProblem * nb)()
+    for i, p in enumerate(problems):
+        ctypes.memmove(ctypes.byref(probs[i]), ctypes.byref(p.problem), ctypes.sizeof(UuoProblem))
+    ptrs = (c_void_p * nb)(*[x.data_ptr() for x in xs])
+    opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad), float(tolerance_change), 0, 0)
+    stats = (UuoLbfgsStats * nb)()
+    with torch.cuda.device(model.device):
+        check(model.lib.uuo_batch_solve(handle.ptr, current_stream(model.device), probs, ptrs, nb, byref(opt), stats),
+              "uuo_batch_solve")
+    return [{"n_iter": st.n_iter, "n_eval": st.n_eval, "first_loss": st.first_loss, "final_loss": st.final_loss,
+             "stop_reason": STOP_REASONS[st.stop_reason], "device_ms": st.device_ms, "driver": "batch"} for st in stats]
+
+
 class DeviceModel:
     """Owns a uuo_model_t (device copies of the SMPL tables) and the per-(F, M) fit workspaces."""
 
@@ -154,6 +197,7 @@ class DeviceModel:
             check(self.lib.uuo_model_create(*[a.ctypes.data for a in arrs], self.V, byref(handle)), "uuo_model_create")
         self.handle = handle
         self._fits: "OrderedDict" = OrderedDict()   # (slot, F, M) -> _FitHandle, least recently used first
+        self._batches: Dict = {}                    # (group, stage) -> _BatchHandle
         self._fits_lock = threading.Lock()
 
     #: sequence shapes (F, M) whose workspaces stay cached per slot.  A dataset of sequences of many different lengths
@@ -182,6 +226,25 @@ class DeviceModel:
                 del self._fits[k]  # the handle frees the workspace once no problem references it any more
             return h
 
+    def batch(self, stage: int, F: int, M: int, count: int) -> "_BatchHandle":
+        """A lock-step batch (uuo_batch_t) able to step `count` problems of (stage, F, M) together; one per workspace group
+        and stage is kept (re-created when the shape changes or more problems are needed)."""
+        key = (workspace_group(), int(stage))
+        with self._fits_lock:
+            h = self._batches.get(key)
+            if h is not None and h.shape == (int(F), int(M)) and h.capacity >= count:
+                return h
+            if h is not None:
+                del self._batches[key]
+                h = None
+            cap = max(int(count), 4)
+            ptr = c_void_p()
+            with torch.cuda.device(self.device):
+                check(self.lib.uuo_batch_create(self.handle, int(stage), int(F), int(M), cap, byref(ptr)), "uuo_batch_create")
+            h = _BatchHandle(self.lib, ptr, self.device, (int(F), int(M)), cap)
+            self._batches[key] = h
+            return h
+
     def cached_workspaces(self) -> int:
         with self._fits_lock:
             return len(self._fits)
@@ -189,6 +252,7 @@ class DeviceModel:
     def close(self):
         with self._fits_lock:
             self._fits.clear()
+            self._batches.clear()
         if self.handle:
             self.lib.uuo_model_destroy(self.handle)
             self.handle = None

@@ -357,13 +357,55 @@ def find_best_part_fits(
                 stream.synchronize()
         return res
 
+    def score_candidate(x, prob, vertex_indices, stats):
+        """Ranking score of a solved candidate (reference :566-579): two-directional chamfer distance."""
+        z_angle, trans, betas_s = prob.unpack(x)
+        with torch.no_grad():
+            z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
+            verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
+                                   root_orient=z_root, trans=trans)["vertices"]
+            verts_sub = verts[:, vertex_indices].contiguous()
+            distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0]
+        return {"stats": stats, "distance": distance, "betas": betas_s.clone(), "root_orient": z_root.clone(),
+                "trans": trans.clone()}
+
+    def fit_subtrees_lockstep():
+        """All candidates in ONE lock-step batch (engine.solve_batch / uuo_batch_solve): they are independent problems of
+        one stage and size, so every round launches each kernel once for all of them instead of 202 x 8 launches from four
+        host threads.  Same decisions and arithmetic per candidate as the one-by-one solve (bit-identical)."""
+        from .engine import solve_batch
+
+        vis = [part_vertex_indices(st_) for st_ in subtrees]
+        probs = [PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vi, config) for vi in vis]
+        for p_ in probs[1:]:  # one body pose, one pose-blend cache for the whole batch
+            p_.problem.pose_cache_id = probs[0].problem.pose_cache_id
+        z0 = torch.zeros((1, 1, 1), device=device)
+        xs = [p_.pack(z0, trans0, o_betas) for p_ in probs]
+        out = []
+        chunk = int(os.environ.get("UUO_SUBTREE_BATCH", "256"))
+        for c0 in range(0, len(probs), chunk):
+            stats_l = solve_batch(probs[c0:c0 + chunk], xs[c0:c0 + chunk], max_iter=st["num_iters"], lr=1.0,
+                                  tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                  tolerance_change=config["optimizer"]["tolerance_change"])
+            for k, stt in enumerate(stats_l):
+                stt["n_subset"], stt["n_markers"] = int(vis[c0 + k].numel()), int(markers_subset.shape[1])
+                out.append(score_candidate(xs[c0 + k], probs[c0 + k], vis[c0 + k], stt))
+        dists = torch.stack([o["distance"] for o in out]).cpu().tolist()  # one read-back for all candidates
+        for o, dval in zip(out, dists):
+            o["distance"] = dval
+        return out
+
     if extra:
         fit_subtree = fit_subtree_general
 
     n_threads = min(len(subtrees), int(os.environ.get("UUO_SUBTREE_THREADS", "4")))
     if extra:
         n_threads = 1  # autograd graphs of concurrent candidates would share the engine's forward scratch
-    if n_threads > 1 and device.type == "cuda":
+    lockstep = (not extra and iter_fn is None and device.type == "cuda" and len(subtrees) > 1
+                and os.environ.get("UUO_SUBTREE_LOCKSTEP", "1") != "0")
+    if lockstep:
+        results = fit_subtrees_lockstep()
+    elif n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
         streams = worker_streams(device, n_threads, "subtree")
         for s_ in streams:
