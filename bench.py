@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
     ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation")
-    ap.add_argument("--inflight", type=int, default=1, help="sequences fitted concurrently per GPU (parallel.fit_many)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="sequences fitted concurrently per GPU (parallel.fit_many): independent sequences overlap on one "
+                         "device -- each on its own host thread, stream and workspaces -- which is how a dataset is run; "
+                         "1 = one sequence at a time (latency of a single fit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the timing loops of the roofline section (one warm-up fit): the command profiled into "

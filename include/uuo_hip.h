@@ -194,6 +194,12 @@ int uuo_batch_destroy(uuo_batch_t* batch);
 int uuo_batch_solve(uuo_batch_t* batch, void* stream, const uuo_problem_t* problems /* [nb] */,
                     float* const* d_xs /* [nb] device vectors, updated in place */, int nb,
                     const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats /* [nb] */);
+/* Ranking scores of part-stage candidates at d_xs (normally the vectors uuo_batch_solve has just solved; same problems, same
+ * batch): h_scores[i] = pytorch3d chamfer_distance(markers_subset, vertices[:, subset_i]) in BOTH directions (mean / mean,
+ * squared L2) -- what find_best_part_fits ranks its candidates by (markers/markers_utils.py:566-579, one SMPL forward and two
+ * K=1 searches per candidate there).  One batched forward + one score kernel for all candidates; synchronises `stream`. */
+int uuo_batch_part_scores(uuo_batch_t* batch, void* stream, const uuo_problem_t* problems, float* const* d_xs, int nb,
+                          float* h_scores /* [nb] host */);
 
 /* device -> host copy of n floats, ordered on `stream`, complete on return (for uuo_eval_callback_t users that only
  * hold the raw pointer, e.g. the iter_fn adapter). */

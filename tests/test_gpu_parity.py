@@ -1445,6 +1445,22 @@ def test_lockstep_batch_is_bit_identical_to_solving_one_by_one(smpl, dev):
 
     check(part_problems, lambda p, i: p.pack(torch.zeros(1, 1, 1, device=dev), trans, o_betas), max_iter=60, lr=1.0)
 
+    # ranking scores of the solved candidates: the batched kernel against the operator route (SMPL forward, two searches)
+    from uuo_mocap_amd.engine import part_scores_batch
+    from uuo_mocap_amd.losses import chamfer_distance
+
+    ps = part_problems()
+    xs = [p.pack(torch.zeros(1, 1, 1, device=dev), trans, o_betas) for p in ps]
+    solve_batch(ps, xs, max_iter=60, lr=1.0)
+    scores = part_scores_batch(ps, xs)
+    for p, x, sc, st_ in zip(ps, xs, scores, subtrees):
+        z, t_, b_ = p.unpack(x)
+        z_root = compute_root_orient_z(torch.repeat_interleave(z, repeats=F, dim=0)) @ root
+        verts = smpl(o_pose, b_.expand(F, 10), z_root, t_)["vertices"]
+        vidx = torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in st_])
+        ref = chamfer_distance(markers, verts[:, vidx].contiguous(), single_directional=False)[0].item()
+        np.testing.assert_allclose(sc, ref, rtol=2e-6)
+
     # chamfer stage: four yaw hypotheses
     def chamfer_problems():
         out = []

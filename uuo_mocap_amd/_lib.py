@@ -73,6 +73,8 @@ _SIGNATURES = {
     "uuo_batch_destroy": (c_int, [c_void_p]),
     "uuo_batch_solve": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), POINTER(c_void_p), c_int,
                                 POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats)]),
+    "uuo_batch_part_scores": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), POINTER(c_void_p), c_int,
+                                      POINTER(c_float)]),
 }
 # libuuo_hip_debug.so only (same sources built with -DUUO_DEBUG_HOOKS; loaded by tests/ and tools/, never by the
 # package): the optimiser self-test on analytic objectives (tests/test_gpu_parity.py::test_lbfgs_*), buffer read-backs,

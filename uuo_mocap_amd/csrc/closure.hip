@@ -988,6 +988,66 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
 
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return validate_problem(fit, p); }
 
+int uuo_closure_forward_at(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {
+  const StageLayout lay = stage_layout(p->stage, p->F);
+  const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
+  return closure_forward(fit, s, p, src);
+}
+
+// Ranking score of part-stage candidates (reference markers/markers_utils.py:575-579: pytorch3d chamfer_distance, both
+// directions, unweighted): per frame, the sum over the markers of the squared distance to the nearest subset vertex (read
+// from the search result of the forward just run) and the sum over the subset's vertices of the squared distance to the
+// nearest marker (distance arithmetic of the CPU loop: ((dx*dx)+(dy*dy))+(dz*dz), separately rounded).  One block per
+// (frame, candidate); fp64 sums in a fixed order.
+__global__ __launch_bounds__(256) void k_part_score_b(const PartScoreArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(PartScoreArgs, batch)
+  __shared__ float sm[64 * 3];
+  __shared__ double red[2][4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double sx = 0.0, sy = 0.0;
+  for (int m = tid; m < a.M; m += 256) sx += (double)__uint_as_float((unsigned)(a.nn[(size_t)f * a.M + m] >> 32));
+  // markers of the frame in tiles of 64; each thread keeps the running minimum of its vertices over the tiles
+  const float* vf = a.verts + (size_t)f * a.V * 3;
+  for (int c0 = 0; c0 < a.ns; c0 += 256) {
+    const int c = c0 + tid;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (c < a.ns) {
+      const float* pv = vf + (size_t)a.subset[c] * 3;
+      vx = pv[0]; vy = pv[1]; vz = pv[2];
+    }
+    float best = __builtin_huge_valf();
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+      const int mt = min(64, a.M - m0);
+      __syncthreads();
+      if (tid < mt * 3) sm[tid] = a.markers[((size_t)f * a.M + m0) * 3 + tid];
+      __syncthreads();
+      for (int m = 0; m < mt; ++m) {
+        const float dx = __fsub_rn(vx, sm[m * 3]), dy = __fsub_rn(vy, sm[m * 3 + 1]), dz = __fsub_rn(vz, sm[m * 3 + 2]);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        best = fminf(best, d);
+      }
+    }
+    if (c < a.ns) sy += (double)best;
+  }
+  sx = wave_sum_d(sx);
+  sy = wave_sum_d(sy);
+  if (lane == 0) {
+    red[0][wave] = sx;
+    red[1][wave] = sy;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.out[(size_t)f * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    a.out[(size_t)f * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+int uuo_launch_part_scores(hipStream_t s, const void* d_args, int count, int F) {
+  hipLaunchKernelGGL(k_part_score_b, dim3(F, 1, count), dim3(256), 0, s, (const PartScoreArgs*)d_args);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // Builds the pose-corrective blend cache of a part-stage problem now (normally the first evaluation does): a lock-step
 // batch shares ONE cache among its candidates (same body pose) and must have it before its first recorded round.
 int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {

@@ -1948,6 +1948,9 @@ struct uuo_batch {
   unsigned char* d_blob = nullptr;
   size_t blob_cap = 0;
   int lb_n = 0, lb_hist = 0;
+  double* d_scores = nullptr;  // uuo_batch_part_scores: [nb][F][2] per-frame sums
+  double* h_scores = nullptr;
+  size_t score_cap = 0;
 };
 
 static thread_local ucontext_t g_sched_ctx;
@@ -1973,6 +1976,8 @@ extern "C" int uuo_batch_destroy(uuo_batch_t* b) {
   if (b->pose_cache) (void)hipFree(b->pose_cache);
   if (b->h_blob) (void)hipHostFree(b->h_blob);
   if (b->d_blob) (void)hipFree(b->d_blob);
+  if (b->d_scores) (void)hipFree(b->d_scores);
+  if (b->h_scores) (void)hipHostFree(b->h_scores);
   delete b;
   return 0;
 }
@@ -2244,6 +2249,74 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
     (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
   }
   return result;
+}
+
+// Ranking scores of the part-stage candidates of a batch at their (solved) parameter vectors: one batched forward of all of
+// them (pose preparation, cached-blend skinning of each candidate's vertices, nearest-vertex search) and one score kernel.
+// h_scores[i] = chamfer(markers -> vertices) + chamfer(vertices -> markers), pytorch3d's two-directional mean / mean.
+extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_problem_t* problems, float* const* d_xs, int nb,
+                                     float* h_scores) {
+  UUO_REQUIRE(b && problems && d_xs && h_scores, "uuo_batch_part_scores: null argument");
+  UUO_REQUIRE(b->stage == UUO_STAGE_PART && nb >= 1 && nb <= b->B, "uuo_batch_part_scores: not a part-stage batch / too many problems");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_batch_part_scores: batches do not nest");
+  hipStream_t s = (hipStream_t)stream;
+  const int F = b->F;
+  std::vector<BatchCo> cos(nb);  // only their recorders are used
+  int rc = 0;
+  for (int i = 0; i < nb && rc == 0; ++i) {
+    rc = uuo_validate_problem(b->fits[i], &problems[i]);
+    if (rc) break;
+    UUO_REQUIRE(b->fits[i]->pose_cache_id == problems[i].pose_cache_id && problems[i].pose_cache_id != 0,
+                "uuo_batch_part_scores: call after uuo_batch_solve of the same problems (shared pose cache)");
+    uuo_recorder = &cos[i].rec;
+    rc = uuo_closure_forward_at(b->fits[i], s, &problems[i], d_xs[i]);
+    uuo_recorder = nullptr;
+  }
+  if (rc) return rc;
+  rc = batch_flush(b, s, cos, nb);
+  if (rc) return rc;
+  const size_t out_doubles = (size_t)nb * F * 2;
+  if (b->score_cap < out_doubles) {
+    if (b->d_scores) (void)hipFree(b->d_scores);
+    if (b->h_scores) (void)hipHostFree(b->h_scores);
+    b->d_scores = nullptr;
+    b->h_scores = nullptr;
+    UUO_HIP_CHECK(hipMalloc((void**)&b->d_scores, out_doubles * sizeof(double)));
+    UUO_HIP_CHECK(hipHostMalloc((void**)&b->h_scores, out_doubles * sizeof(double), hipHostMallocDefault));
+    b->score_cap = out_doubles;
+  }
+  UUO_REQUIRE((size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap, "uuo_batch_part_scores: staging buffer too small");
+  PartScoreArgs* ha = reinterpret_cast<PartScoreArgs*>(b->h_blob);
+  for (int i = 0; i < nb; ++i) {
+    PartScoreArgs a;
+    a.h.gx = F;
+    a.h.gy = 1;
+    a.F = F;
+    a.M = problems[i].M;
+    a.V = b->model->V;
+    a.ns = problems[i].n_subset;
+    a.markers = problems[i].d_markers;
+    a.verts = b->fits[i]->verts;
+    a.subset = problems[i].d_subset;
+    a.nn = b->fits[i]->nn;
+    a.out = b->d_scores + (size_t)i * F * 2;
+    ha[i] = a;
+  }
+  UUO_HIP_CHECK(hipMemcpyAsync(b->d_blob, b->h_blob, (size_t)nb * sizeof(PartScoreArgs), hipMemcpyHostToDevice, s));
+  rc = uuo_launch_part_scores(s, b->d_blob, nb, F);
+  if (rc) return rc;
+  UUO_HIP_CHECK(hipMemcpyAsync(b->h_scores, b->d_scores, out_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
+  UUO_HIP_CHECK(hipStreamSynchronize(s));
+  for (int i = 0; i < nb; ++i) {
+    double cx = 0.0, cy = 0.0;
+    const double* o = b->h_scores + (size_t)i * F * 2;
+    for (int f = 0; f < F; ++f) {
+      cx += o[2 * f] / (double)problems[i].M;
+      cy += o[2 * f + 1] / (double)problems[i].n_subset;
+    }
+    h_scores[i] = (float)(cx / (double)F + cy / (double)F);
+  }
+  return 0;
 }
 
 // host copy of a device vector, ordered on `stream` and complete on return (the iter_fn adapter of the Python mirror

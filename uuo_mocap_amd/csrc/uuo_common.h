@@ -47,6 +47,11 @@ void uuo_set_error(const std::string& msg);
     }                                 \
   } while (0)
 
+// the argument struct of every batched kernel (lock-step batches, below) starts with its own grid extent
+struct UuoGridHdr {
+  int gx, gy;
+};
+
 // Small per-model constant tables read by every frame kernel.
 struct UuoTree {
   int parent[UUO_NUM_JOINTS];
@@ -160,6 +165,19 @@ int uuo_launch_finalize(const uuo_fit* fit, hipStream_t s, const uuo_problem_t& 
 int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p);
 int uuo_ensure_mask(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p);
 int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x);
+// forward half of a stage closure at d_x (pose preparation, skinning, nearest-neighbour search): recorded when a batch records
+int uuo_closure_forward_at(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x);
+// two-directional chamfer sums of part-stage candidates after uuo_closure_forward_at (closure.hip)
+struct PartScoreArgs {
+  UuoGridHdr h;
+  int F, M, V, ns;
+  const float* markers;             // [F][M][3]
+  const float* verts;               // [F][V][3], valid at the subset's vertices
+  const int32_t* subset;            // [ns]
+  const unsigned long long* nn;     // [F][M] packed (squared distance bits << 32 | candidate)
+  double* out;                      // [F][2]: sum_m d2(marker -> nearest subset vertex), sum_c d2(subset vertex -> nearest marker)
+};
+int uuo_launch_part_scores(hipStream_t s, const void* d_args, int count, int F);
 // Optional zero-copy report of a closure evaluation: the finalize kernel copies the 80-byte block that starts 8 bytes
 // before d_stats (the solver's {max|d| bits, pad, out[9]}) into `host` (pinned, device-visible) and then publishes
 // `seq` in host[10]; the solver polls that word instead of enqueueing a copy and synchronising the stream.
@@ -221,10 +239,6 @@ inline bool uuo_record(int op, int gx, int gy, const A& a) {
   uuo_recorder->ops.push_back(r);
   return true;
 }
-// the argument struct of every batched kernel starts with its own grid extent
-struct UuoGridHdr {
-  int gx, gy;
-};
 #define UUO_BATCH_PICK(ArgsT, batch)                                      \
   const ArgsT a = (batch)[blockIdx.z];                                    \
   if ((int)blockIdx.x >= a.h.gx || (int)blockIdx.y >= a.h.gy) return;

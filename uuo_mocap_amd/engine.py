@@ -178,6 +178,25 @@ def solve_batch(problems, xs, max_iter: int, lr: float = 1.0, tolerance_grad: fl
              "stop_reason": STOP_REASONS[st.stop_reason], "device_ms": st.device_ms, "driver": "batch"} for st in stats]
 
 
+def part_scores_batch(problems, xs):
+    """uuo_batch_part_scores: two-directional chamfer distance between the markers and each candidate's vertices at
+    xs[i] -- the ranking score of find_best_part_fits -- for all candidates in one batched forward + one score kernel.
+    Call after solve_batch of the same problems (same batch, shared pose-blend cache).  Returns a list of floats."""
+    p0 = problems[0]
+    model = p0.model
+    nb = len(problems)
+    handle = model.batch(p0.stage, p0.F, p0.M, nb)
+    probs = (UuoProblem * nb)()
+    for i, p in enumerate(problems):
+        ctypes.memmove(ctypes.byref(probs[i]), ctypes.byref(p.problem), ctypes.sizeof(UuoProblem))
+    ptrs = (c_void_p * nb)(*[x.data_ptr() for x in xs])
+    scores = (c_float * nb)()
+    with torch.cuda.device(model.device):
+        check(model.lib.uuo_batch_part_scores(handle.ptr, current_stream(model.device), probs, ptrs, nb, scores),
+              "uuo_batch_part_scores")
+    return [float(v) for v in scores]
+
+
 class DeviceModel:
     """Owns a uuo_model_t (device copies of the SMPL tables) and the per-(F, M) fit workspaces."""
 

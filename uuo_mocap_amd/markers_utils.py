@@ -357,42 +357,32 @@ def find_best_part_fits(
                 stream.synchronize()
         return res
 
-    def score_candidate(x, prob, vertex_indices, stats):
-        """Ranking score of a solved candidate (reference :566-579): two-directional chamfer distance."""
-        z_angle, trans, betas_s = prob.unpack(x)
-        with torch.no_grad():
-            z_root = compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0)) @ root_orient
-            verts = smpl_inference(poses=pose_body, betas=torch.repeat_interleave(betas_s, dim=0, repeats=num_frames),
-                                   root_orient=z_root, trans=trans)["vertices"]
-            verts_sub = verts[:, vertex_indices].contiguous()
-            distance = chamfer_distance(markers_subset, verts_sub, single_directional=False)[0]
-        return {"stats": stats, "distance": distance, "betas": betas_s.clone(), "root_orient": z_root.clone(),
-                "trans": trans.clone()}
-
     def fit_subtrees_lockstep():
         """All candidates in ONE lock-step batch (engine.solve_batch / uuo_batch_solve): they are independent problems of
         one stage and size, so every round launches each kernel once for all of them instead of 202 x 8 launches from four
         host threads.  Same decisions and arithmetic per candidate as the one-by-one solve (bit-identical)."""
-        from .engine import solve_batch
+        from .engine import part_scores_batch, solve_batch
 
         vis = [part_vertex_indices(st_) for st_ in subtrees]
         probs = [PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vi, config) for vi in vis]
         for p_ in probs[1:]:  # one body pose, one pose-blend cache for the whole batch
             p_.problem.pose_cache_id = probs[0].problem.pose_cache_id
         z0 = torch.zeros((1, 1, 1), device=device)
-        xs = [p_.pack(z0, trans0, o_betas) for p_ in probs]
+        x_all = probs[0].pack(z0, trans0, o_betas).repeat(len(probs), 1)   # same start for every candidate (:418-421)
+        xs = [x_all[i] for i in range(len(probs))]
         out = []
         chunk = int(os.environ.get("UUO_SUBTREE_BATCH", "256"))
         for c0 in range(0, len(probs), chunk):
-            stats_l = solve_batch(probs[c0:c0 + chunk], xs[c0:c0 + chunk], max_iter=st["num_iters"], lr=1.0,
+            sl = slice(c0, c0 + chunk)
+            stats_l = solve_batch(probs[sl], xs[sl], max_iter=st["num_iters"], lr=1.0,
                                   tolerance_grad=config["optimizer"]["tolerance_grad"],
                                   tolerance_change=config["optimizer"]["tolerance_change"])
-            for k, stt in enumerate(stats_l):
+            # ranking score (reference :566-579): two-directional chamfer at the solved parameters, all candidates of the
+            # chunk in one batched forward + one score kernel (was one SMPL forward + two searches per candidate)
+            dists = part_scores_batch(probs[sl], xs[sl])
+            for k, (stt, dval) in enumerate(zip(stats_l, dists)):
                 stt["n_subset"], stt["n_markers"] = int(vis[c0 + k].numel()), int(markers_subset.shape[1])
-                out.append(score_candidate(xs[c0 + k], probs[c0 + k], vis[c0 + k], stt))
-        dists = torch.stack([o["distance"] for o in out]).cpu().tolist()  # one read-back for all candidates
-        for o, dval in zip(out, dists):
-            o["distance"] = dval
+                out.append({"stats": stt, "distance": dval, "x": xs[c0 + k], "prob": probs[c0 + k]})
         return out
 
     if extra:
@@ -432,16 +422,23 @@ def find_best_part_fits(
     best_distance = np.inf
     subtree_losses = []
     LAST_STATS["part"] = []
+    best_res = None
     for subtree, res in zip(subtrees, results):  # candidate order decides ties, exactly as the sequential reference
         LAST_STATS["part"].append(res["stats"])
         subtree_losses.append([subtree, res["distance"]])
         if res["distance"] < best_distance:
             best_distance = res["distance"]
-            best = {
-                "betas": res["betas"], "markers_subset": markers_subset.clone(), "root_orient": res["root_orient"],
-                "trans": res["trans"],
-                "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
-            }
+            best_res = res
+    if "betas" not in best_res:  # lock-step path: only the winner's parameters are unpacked
+        z_angle, trans_w, betas_w = best_res["prob"].unpack(best_res["x"])
+        best_res = dict(best_res, betas=betas_w.clone(), trans=trans_w.clone(),
+                        root_orient=(compute_root_orient_z(torch.repeat_interleave(z_angle, repeats=num_frames, dim=0))
+                                     @ root_orient).clone())
+    best = {
+        "betas": best_res["betas"], "markers_subset": markers_subset.clone(), "root_orient": best_res["root_orient"],
+        "trans": best_res["trans"],
+        "aabb": get_aabb_volume(get_aabb(markers_subset)) / get_aabb_volume(get_aabb(markers)),
+    }
 
     # The reference relabels the markers every time a candidate improves on the best so far (:586-597); only the last
     # such relabelling survives, i.e. the winner's: label of marker i = dominant joint of argmin_v mean_f |v - x_i| over

@@ -368,6 +368,64 @@ def multimodal_video_mocap(
                 stream.synchronize()
         return local
 
+    def fit_hypotheses_lockstep():
+        """All yaw hypotheses stage by stage: their chamfer solves are one lock-step batch (one launch per kernel and
+        round for all of them instead of one kernel stream per host thread), then the placements, then the marker solves as
+        another batch.  Every hypothesis ends exactly where fit_hypothesis takes it (same arithmetic, bit-identical)."""
+        hyps = []
+        for angle in root_orient_angles:
+            angle_t = torch.tensor([[[angle]]]).float().to(device)
+            z_root = compute_root_orient_z(torch.repeat_interleave(angle_t, repeats=root_orient.shape[0], dim=0)) @ \
+                root_orient.clone().detach()
+            hyps.append({"root_orient": z_root.clone().detach().requires_grad_(True),
+                         "trans": trans.clone().detach().requires_grad_(True),
+                         "pose_body": pose_body.clone().detach().requires_grad_(True),
+                         "betas": betas.clone().detach().requires_grad_(True)})
+        locals_ = [dict() for _ in hyps]
+        if run_chamfer:
+            for local, stt in zip(locals_, optimization.optim_chamfer_lockstep(markers, hyps, o_pose_body, o_betas,
+                                                                               smpl_inference, config)):
+                local["chamfer_stats"] = stt
+        for local, h in zip(locals_, hyps):
+            local["chamfer"] = _np_dict(trans=h["trans"], root_orient=normalize_rot(h["root_orient"]), betas=h["betas"][0],
+                                        pose_body=normalize_rot(h["pose_body"]))
+        if run_marker:
+            one_hots = [compute_nearest_points(
+                markers=markers, pose_body=h["pose_body"], betas=h["betas"], root_orient=h["root_orient"], trans=h["trans"],
+                smpl_inference=smpl_inference, marker_labels=marker_labels,
+                granularity=config["stages"]["segment"]["granularity"], img_mask=img_mask, device=device, config=config,
+                o_pose_body=o_pose_body, window_size=1,
+                use_velocity=config["stages"]["compute_locations"]["use_velocity"]) for h in hyps]
+            for h in hyps:
+                h["root_orient"] = h["root_orient"].clone().detach().requires_grad_(True)
+                h["pose_body"] = h["pose_body"].clone().detach().requires_grad_(True)
+            if all(optimization.is_one_hot_placement(oh) for oh in one_hots):
+                all_stats = optimization.optim_markers_lockstep(markers, hyps, [o_pose_body] * len(hyps), o_betas, one_hots,
+                                                                smpl_inference, config)
+            else:
+                all_stats = []
+                for h, oh, angle in zip(hyps, one_hots, root_orient_angles):
+                    optim_markers(markers=markers, pose_body=h["pose_body"], o_pose_body=o_pose_body, betas=h["betas"],
+                                  o_betas=o_betas, root_orient=h["root_orient"], trans=h["trans"],
+                                  barycentric_coords_one_hot=oh, img_mask=img_mask, smpl_inference=smpl_inference,
+                                  config=config, initial_angle=angle, repeat=0, verbose=verbose)
+                    all_stats.append(optimization.last_stats("marker"))
+            for local, stt in zip(locals_, all_stats):
+                local["marker_stats"] = stt
+        for local, h in zip(locals_, hyps):
+            if not run_chamfer and not run_marker:
+                local["marker"] = {k: v.copy() for k, v in local["chamfer"].items()}
+            else:
+                local["marker"] = _np_dict(trans=h["trans"], root_orient=normalize_rot(h["root_orient"]),
+                                           betas=h["betas"][0], pose_body=normalize_rot(h["pose_body"]))
+        return locals_
+
+    # lock-step batches need the fused device closures, no per-evaluation callbacks and the labels fixed during the loop
+    lockstep = (device.type == "cuda" and len(root_orient_angles) > 1 and (run_chamfer or run_marker)
+                and save_iter_fn is None and not verbose and not recompute_labels
+                and (not run_chamfer or optimization.lockstep_supported(config, "chamfer"))
+                and (not run_marker or optimization.lockstep_supported(config, "marker"))
+                and os.environ.get("UUO_HYPOTHESIS_LOCKSTEP", "0") == "1")
     n_threads = min(len(root_orient_angles), int(os.environ.get("UUO_HYPOTHESIS_THREADS", "4")))
     if not run_chamfer and not run_marker:
         n_threads = 1  # nothing to solve per hypothesis (hmr_full.yaml): worker threads would only add their start-up
@@ -375,7 +433,9 @@ def multimodal_video_mocap(
         # the reference's hypotheses run one after the other and each placement reads the labels the previous one
         # recomputed (only the "part" granularity looks at them): keep that order
         n_threads = 1
-    if n_threads > 1 and device.type == "cuda":
+    if lockstep:
+        results = fit_hypotheses_lockstep()
+    elif n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)
         streams = worker_streams(device, len(root_orient_angles), "hypothesis")
         for st_ in streams:

@@ -88,6 +88,74 @@ def optim_chamfer(
     return None
 
 
+def lockstep_supported(config: Dict, stage: str) -> bool:
+    """True when `stage` ("chamfer" / "marker") of this configuration runs on the fused device closure with the L-BFGS
+    driver, i.e. when independent solves of it can be stepped together (engine.solve_batch)."""
+    st = config["stages"][stage]
+    if str(config["optimizer"].get("type", "lbfgs")).lower() != "lbfgs":
+        return False
+    if stage == "chamfer":
+        return not (set(st["losses"]) - _CHAMFER_FUSED_LOSSES) and bool(st["yaw_lock"])
+    return not (set(st["losses"]) - {"marker", "reg_pose_body", "reg_betas"}) and not st.get("use_sdf")
+
+
+def optim_chamfer_lockstep(markers, hyps, o_pose_body, o_betas, smpl_inference, config):
+    """`optim_chamfer` for several independent hypotheses at once (the yaw hypotheses of multimodal_video_mocap,
+    reference multimodal.py:462-497): `hyps` is a list of dicts with the leaves `pose_body`, `betas`, `root_orient`,
+    `trans` of each.  One lock-step batch (engine.solve_batch) instead of one solve per host thread; each hypothesis ends
+    exactly where `optim_chamfer` would take it alone (bit-identical), with the same in-place updates.  Returns the
+    solver statistics per hypothesis."""
+    from .engine import solve_batch
+
+    probs, xs = [], []
+    for h in hyps:
+        prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, h["root_orient"], config)
+        z_angle = torch.zeros((h["root_orient"].shape[0], h["root_orient"].shape[1], 1), device=h["root_orient"].device)
+        probs.append(prob)
+        xs.append(prob.pack(h["trans"], z_angle, h["betas"], h["pose_body"]))
+    opt = config["optimizer"]
+    stats = solve_batch(probs, xs, max_iter=config["stages"]["chamfer"]["num_iters"], lr=0.1,
+                        tolerance_grad=opt["tolerance_grad"], tolerance_change=opt["tolerance_change"])
+    for h, prob, x in zip(hyps, probs, xs):
+        new_trans, new_z, new_betas, new_pose = prob.unpack(x)
+        with torch.no_grad():
+            h["trans"].copy_(new_trans)
+            h["betas"].copy_(new_betas)
+            h["pose_body"].copy_(new_pose)
+            h["root_orient"].requires_grad_(False)
+            h["root_orient"][:] = compute_root_orient_z(new_z) @ h["root_orient"]
+        h["root_orient"].requires_grad_(True)
+    return stats
+
+
+def optim_markers_lockstep(markers, hyps, o_pose_bodies, o_betas, one_hots, smpl_inference, config):
+    """`optim_markers` for several independent hypotheses at once (reference multimodal.py:549-565), one-hot placements
+    only; same contract as optim_chamfer_lockstep."""
+    from .engine import solve_batch
+
+    probs, xs = [], []
+    for h, o_pose, one_hot in zip(hyps, o_pose_bodies, one_hots):
+        prob = MarkerProblem(smpl_inference, markers, o_pose, o_betas, torch.argmax(one_hot, dim=-1), config)
+        probs.append(prob)
+        xs.append(prob.pack(h["pose_body"], h["betas"], h["root_orient"], h["trans"]))
+    opt = config["optimizer"]
+    stats = solve_batch(probs, xs, max_iter=config["stages"]["marker"]["num_iters"], lr=1.0,
+                        tolerance_grad=opt["tolerance_grad"], tolerance_change=opt["tolerance_change"])
+    for h, prob, x in zip(hyps, probs, xs):
+        new_pose, new_betas, new_root, new_trans = prob.unpack(x)
+        with torch.no_grad():
+            h["pose_body"].copy_(new_pose)
+            h["betas"].copy_(new_betas)
+            h["root_orient"].copy_(new_root)
+            h["trans"].copy_(new_trans)
+    return stats
+
+
+def is_one_hot_placement(one_hot: torch.Tensor) -> bool:
+    rows_nz = (one_hot != 0).sum(dim=1)
+    return bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all())
+
+
 def _solve(prob, x, config, stage: str, lr: float, verbose_tag: str, verbose: bool, point_cb):
     """L-BFGS (the reference's only driver) unless the config carries the EXTENSION key `optimizer.type: adam`
     (BASELINE's north star names Adam; the reference has no such option): then `optimizer.adam_steps` (default: the
