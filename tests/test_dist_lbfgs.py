@@ -1,0 +1,119 @@
+"""The sharded L-BFGS driver (uuo_mocap_amd/dist_lbfgs.py: shared-beta extension) on the CPU:
+(1) with one rank it is torch.optim.LBFGS(strong_wolfe) evaluation for evaluation; (2) with two gloo ranks, each holding
+its own block of the parameter vector plus a replicated shared tail, it reproduces the one-process solve of the joint
+problem and leaves the shared parameters bit-identical on both ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from uuo_mocap_amd.dist_lbfgs import DistReducer, LocalReducer, ShardedLBFGS  # noqa: E402
+
+N_LOCAL, N_SHARED = 40, 6
+
+
+def _block(rank):
+    """rank r's term: a well-scaled quadratic in its own block x_r, coupled to the shared tail s through
+    0.5 * c_r * sum_j (x_r[j] - s[j])^2 over the first N_SHARED entries, plus a smooth non-quadratic term."""
+    i = torch.arange(N_LOCAL, dtype=torch.float32)
+    a = 1.0 + 3.0 * i / (N_LOCAL - 1) + 0.5 * rank
+    b = 0.2 * torch.sin(0.37 * i + rank)
+    c = 0.7 + 0.2 * rank
+
+    def f(x_r, s):
+        q = 0.5 * (a * (x_r - b) ** 2).sum()
+        cpl = 0.5 * c * ((x_r[:N_SHARED] - s) ** 2).sum()
+        return q + cpl + 0.05 * torch.log1p(s ** 2).sum() / (1 + rank)
+
+    return f
+
+
+def _torch_reference(world, max_iter, lr):
+    fs = [_block(r) for r in range(world)]
+    x = torch.zeros(world * N_LOCAL + N_SHARED, requires_grad=True)
+    opt = torch.optim.LBFGS([x], max_iter=max_iter, tolerance_grad=1e-7, tolerance_change=1e-9, lr=lr,
+                            line_search_fn="strong_wolfe")
+    losses = []
+
+    def closure():
+        opt.zero_grad()
+        s = x[world * N_LOCAL:]
+        loss = sum(fs[r](x[r * N_LOCAL:(r + 1) * N_LOCAL], s) for r in range(world))
+        loss.backward()
+        losses.append(float(loss))
+        return loss
+
+    opt.step(closure)
+    return x.detach().clone(), losses, int(opt.state[opt._params[0]]["n_iter"])
+
+
+def _sharded_solve(rank, world, reducer, max_iter, lr):
+    f = _block(rank)
+    x = torch.zeros(N_LOCAL + N_SHARED)
+    losses = []
+
+    def evaluate(xl):
+        xl = xl.detach().clone().requires_grad_(True)
+        loss = f(xl[:N_LOCAL], xl[N_LOCAL:])
+        loss.backward()
+        losses.append(float(loss))
+        return float(loss), xl.grad
+
+    st = ShardedLBFGS(x, N_SHARED, evaluate, reducer=reducer, lr=lr, max_iter=max_iter).solve()
+    return x, st, losses
+
+
+@pytest.mark.parametrize("lr", [1.0, 0.3])
+def test_one_rank_is_torch_lbfgs(lr):
+    x_ref, losses_ref, n_iter_ref = _torch_reference(1, 40, lr)
+    x, st, losses = _sharded_solve(0, 1, LocalReducer(), 40, lr)
+    # evaluation for evaluation until the loss stops changing in fp32; in that plateau torch's fp32 directional
+    # derivatives and the driver's fp64 ones may disagree on the sign of a ~1e-9 quantity, so the very last line search
+    # can take a few evaluations more or fewer
+    assert st["n_iter"] == n_iter_ref and st["n_eval"] == len(losses)
+    assert abs(st["n_eval"] - len(losses_ref)) <= 6, (st["n_eval"], len(losses_ref))
+    head = min(len(losses), len(losses_ref))
+    np.testing.assert_allclose(losses[:head], losses_ref[:head], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(x.numpy(), x_ref.numpy(), atol=2e-5)
+
+
+def _rank_main(rank, world, port, max_iter, lr, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, st, losses = _sharded_solve(rank, world, DistReducer(), max_iter, lr)
+        torch.save({"x": x, "st": st, "n_local_evals": len(losses)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lr", [1.0])
+def test_two_gloo_ranks_reproduce_the_joint_solve(tmp_path, lr):
+    import torch.multiprocessing as mp
+
+    world, max_iter = 2, 40
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(world, port, max_iter, lr, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    x_ref, losses_ref, n_iter_ref = _torch_reference(world, max_iter, lr)
+    # lock-step: same decisions on every rank
+    assert res[0]["st"] == res[1]["st"]
+    assert res[0]["n_local_evals"] == res[1]["n_local_evals"] == res[0]["st"]["n_eval"]
+    # the replicated shared parameters never diverge
+    assert torch.equal(res[0]["x"][N_LOCAL:], res[1]["x"][N_LOCAL:])
+    # and the sharded solve is the joint solve
+    # (two partial sums added in fp64 are not the one-process fp32 dot product: at the fp32 plateau of the loss the last
+    # iteration or two may differ)
+    assert abs(res[0]["st"]["n_iter"] - n_iter_ref) <= 2 and abs(res[0]["st"]["n_eval"] - len(losses_ref)) <= 6
+    np.testing.assert_allclose(res[0]["st"]["final_loss"], min(losses_ref), rtol=1e-4, atol=1e-7)
+    joint = torch.cat([res[0]["x"][:N_LOCAL], res[1]["x"][:N_LOCAL], res[0]["x"][N_LOCAL:]])
+    np.testing.assert_allclose(joint.numpy(), x_ref.numpy(), atol=5e-5)

@@ -1,0 +1,141 @@
+"""Two ranks on the GPU box (gloo rendezvous, both on cuda:0: RCCL refuses two ranks on one device; the collectives of
+this path are < 1 KB host-side exchanges, so the backend does not change what is tested): the three ways the fit spreads
+over ranks with REAL fits -- sequences per rank, yaw hypotheses per rank, shared betas across ranks."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F, M, ITERS = 20, 12, 25
+
+
+def _setup():
+    from uuo_mocap_amd.body_model import synthetic_smpl
+    from uuo_mocap_amd.config import packaged_config
+    from uuo_mocap_amd.smpl import SmplInference
+
+    dev = torch.device("cuda:0")
+    tables = synthetic_smpl(0)
+    cfg = packaged_config("video_mocap")
+    for k in ("part", "chamfer", "marker"):
+        cfg["stages"][k]["num_iters"] = ITERS
+    return dev, tables, cfg, SmplInference(dev, tables=tables)
+
+
+def _fit(smpl, seq, cfg, dev):
+    import contextlib
+    import io
+
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                     save_stages=False, smpl_inference=smpl)
+    res = {k: np.asarray(out[k]) for k in ("trans", "pose_body", "betas", "root_orient")}
+    res["yaw_scores"] = np.asarray(last_run_stats()["yaw_scores"])
+    res["n_chamfer"] = len(last_run_stats()["chamfer"])
+    return res
+
+
+def _rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from uuo_mocap_amd import parallel
+        from uuo_mocap_amd.synthetic import make_sequence
+
+        dev, tables, cfg, smpl = _setup()
+        seqs = [make_sequence(tables, seed=40 + i, num_frames=F, num_markers=M) for i in range(4)]
+        out = {}
+        # (1) sequences per rank: real fits, gathered on rank 0
+        merged, elapsed = parallel.fit_sharded(list(range(4)), lambda sid: _fit(smpl, seqs[sid], cfg, dev), device=dev)
+        out["sharded"] = merged
+        out["sharded_elapsed"] = elapsed
+        # (2) yaw hypotheses per rank (8e.2): ONE sequence, every rank ends with the full, identical result
+        with parallel.shard_hypotheses():
+            out["hyp"] = _fit(smpl, seqs[0], cfg, dev)
+        # (3) shared betas (8e.3 / 8e.4, extension): rank r fits sequence r of the same subject, one shape vector
+        same_subject = [make_sequence(tables, seed=70 + r, num_frames=F, num_markers=M) for r in range(world)]
+        for sq in same_subject[1:]:
+            sq.img_smpl.betas = same_subject[0].img_smpl.betas.clone()
+        with parallel.shared_betas(device=dev) as red:
+            out["shared"] = _fit(smpl, same_subject[rank], cfg, dev)
+            out["shared_world"] = red.world
+        torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sequences_hypotheses_and_shared_betas(tmp_path):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+
+    # the single-process answers
+    from uuo_mocap_amd.synthetic import make_sequence
+
+    dev, tables, cfg, smpl = _setup()
+    seqs = [make_sequence(tables, seed=40 + i, num_frames=F, num_markers=M) for i in range(4)]
+    alone = [_fit(smpl, sq, cfg, dev) for sq in seqs]
+
+    # (1) every sequence was fitted by exactly one rank, rank 0 holds them all, each is the fit it is alone
+    assert res[1]["sharded"] is None and sorted(res[0]["sharded"].keys()) == [0, 1, 2, 3]
+    for sid in range(4):
+        for k in ("trans", "pose_body", "betas", "root_orient"):
+            assert np.array_equal(res[0]["sharded"][sid][k], alone[sid][k]), (sid, k)
+    assert res[0]["sharded_elapsed"] == res[1]["sharded_elapsed"]  # max over ranks, identical on both
+
+    # (2) hypotheses per rank: both ranks hold the whole result and it is the one-process fit, bit for bit
+    for r in range(world):
+        assert res[r]["hyp"]["n_chamfer"] == 4
+        np.testing.assert_array_equal(res[r]["hyp"]["yaw_scores"], alone[0]["yaw_scores"])
+        for k in ("trans", "pose_body", "betas", "root_orient"):
+            assert np.array_equal(res[r]["hyp"][k], alone[0][k]), (r, k)
+
+    # (3) shared betas: one shape vector, bit-identical on both ranks, and sensible fits
+    assert res[0]["shared_world"] == 2
+    assert np.array_equal(res[0]["shared"]["betas"][0], res[1]["shared"]["betas"][0])
+    assert not np.array_equal(res[0]["shared"]["trans"], res[1]["shared"]["trans"])
+    for r in range(world):
+        assert np.isfinite(res[r]["shared"]["pose_body"]).all()
+        assert res[r]["shared"]["yaw_scores"].min() < 5e-3   # the best hypothesis hugs the markers (m^2)
+
+
+def test_shared_betas_with_one_rank_matches_the_device_driver(tmp_path):
+    """The sharded driver with a single rank runs the same algorithm as uuo_lbfgs_solve on the same fused closure: the two
+    chamfer-stage solves follow each other closely (fp64 dot products in both, different summation orders)."""
+    from uuo_mocap_amd import parallel
+    from uuo_mocap_amd.engine import ChamferProblem
+    from uuo_mocap_amd.synthetic import make_sequence
+
+    dev, tables, cfg, smpl = _setup()
+    seq = make_sequence(tables, seed=81, num_frames=F, num_markers=M)
+    markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, cfg)
+    x0 = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas, o_pose)
+    xa, xb = x0.clone(), x0.clone()
+    sa = prob.solve(xa, max_iter=12, lr=0.1)
+    from uuo_mocap_amd.dist_lbfgs import LocalReducer
+
+    sb = prob.solve_shared(xb, LocalReducer(), max_iter=12, lr=0.1)
+    assert sa["n_iter"] == sb["n_iter"] == 12
+    assert sa["first_loss"] == pytest.approx(sb["first_loss"], rel=1e-6)
+    assert sb["final_loss"] == pytest.approx(sa["final_loss"], rel=2e-3)
+    assert abs(sa["n_eval"] - sb["n_eval"]) <= 2

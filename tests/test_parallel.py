@@ -2,6 +2,7 @@
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -56,3 +57,38 @@ def test_two_rank_sequence_sharding_gloo():
         torch.manual_seed(sid)
         assert results[sid]["betas"] == torch.randn(10).tolist()
     assert elapsed > 0
+
+
+def _hyp_rank(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from uuo_mocap_amd import parallel
+
+        with parallel.shard_hypotheses() as shard:
+            assert parallel.hypothesis_shard() is shard and shard.world == world
+            mine = shard.mine(4)
+            local = {i: {"angle": i, "by": rank, "payload": np.full(3, float(i))} for i in mine}
+            everything = shard.exchange(local, 4)
+        assert parallel.hypothesis_shard() is None
+        torch.save({"mine": mine, "all": everything}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hypothesis_shard_exchange_two_gloo_ranks(tmp_path):
+    """rank r owns hypotheses r, r + world, ...; after one all_gather_object every rank holds all of them
+    in hypothesis order."""
+    import torch
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + 1
+    mp.spawn(_hyp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    assert res[0]["mine"] == [0, 2] and res[1]["mine"] == [1, 3]
+    for r in range(2):
+        assert [h["angle"] for h in res[r]["all"]] == [0, 1, 2, 3]
+        assert [h["by"] for h in res[r]["all"]] == [0, 1, 0, 1]

@@ -1,0 +1,319 @@
+"""L-BFGS (strong Wolfe) on a parameter vector that is SHARDED over the ranks of a process group.
+
+EXTENSION, not reference behaviour: the reference fits every sequence on its own (one ``multimodal_video_mocap`` call per
+sequence with its own betas, reference test/test.py:57-112).  BASELINE.json's ``configs[3]`` / north star ask
+for "sequences sharded across the GPUs of one node with RCCL over xGMI for the shared-beta reduction only": several sequences
+of ONE subject fitted together with a single shape vector.  That is one joint L-BFGS problem over
+
+    x = [ x_0 | x_1 | ... | x_{R-1} | shared ]        (x_r: the pose / translation / yaw parameters of rank r's sequence)
+
+with loss sum_r loss_r(x_r, shared).  Rank r stores only ``[x_r | shared]``; ``shared`` is replicated and kept bit-identical
+on every rank.  The algorithm is torch.optim.LBFGS(line_search_fn="strong_wolfe") (torch 2.10: history push iff y.s > 1e-10,
+H_diag = y.s / y.y, first step min(1, 1/|g|_1) lr, bracket / zoom with the insufficient-progress rule, max_ls = max_eval -
+evals, termination tests in torch's order) -- the same mirror as the device driver (csrc/solver.hip), evaluated the same way:
+in COEFFICIENT SPACE from Gram matrices of the (s, y) history, so an iteration needs a fixed, small number of collectives
+instead of 2 x history dependent dot products:
+
+* per closure evaluation ONE ``all_gather`` of ``[loss, g.d, |g|_1, g.g, max|g|, grad(shared)...]`` (<= 16 + n_shared doubles);
+* per iteration ONE ``all_gather`` of the new Gram row / column (``4 k + 4`` doubles) and one of ``max|d|``.
+
+Messages are < 1 KB: latency-bound, the 7 x 153 GB/s xGMI links of an MI355X node are irrelevant here.  Every
+rank reduces the gathered partials in rank order in fp64, so all ranks take bit-identical decisions and stay in lock-step
+without any further synchronisation.  The collective sits behind ``Reducer`` so that the same driver runs on one process
+(``LocalReducer``), on gloo (CPU tests) and on RCCL.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+class LocalReducer:
+    """world_size 1: the partials are the totals."""
+
+    world = 1
+    rank = 0
+
+    def gather(self, values: Sequence[float]) -> np.ndarray:
+        return np.asarray(values, dtype=np.float64)[None, :]
+
+
+class DistReducer:
+    """Partials of every rank through ONE all_gather on a torch.distributed process group ("nccl" = RCCL on ROCm, "gloo" in
+    the CPU tests); each rank then reduces the [world, n] table itself, in rank order."""
+
+    def __init__(self, group=None, device: Optional[torch.device] = None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
+
+    def gather(self, values: Sequence[float]) -> np.ndarray:
+        local = torch.tensor(list(values), dtype=torch.float64, device=self.device)
+        out = torch.empty(self.world * local.numel(), dtype=torch.float64, device=self.device)  # flat: gloo wants 1-D
+        self.dist.all_gather_into_tensor(out, local, group=self.group)
+        return out.cpu().numpy().reshape(self.world, local.numel())
+
+
+def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):
+    """torch/optim/lbfgs.py:12-38 on Python floats."""
+    if bounds is not None:
+        xmin_bound, xmax_bound = bounds
+    else:
+        xmin_bound, xmax_bound = (x1, x2) if x1 <= x2 else (x2, x1)
+    d1 = g1 + g2 - 3 * (f1 - f2) / (x1 - x2)
+    d2_square = d1 ** 2 - g1 * g2
+    if d2_square >= 0:
+        d2 = math.sqrt(d2_square)
+        if x1 <= x2:
+            min_pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2))
+        else:
+            min_pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2))
+        return min(max(min_pos, xmin_bound), xmax_bound)
+    return (xmin_bound + xmax_bound) / 2.0
+
+
+class ShardedLBFGS:
+    """One ``.solve()`` = one ``torch.optim.LBFGS(...).step(closure)`` on the joint problem.
+
+    x_local     [n_local + n_shared] float32 tensor of this rank: its own parameters followed by the shared ones
+    n_shared    number of trailing entries that are shared (replicated, identical on every rank)
+    evaluate    callable(x_local) -> (loss_r: float, grad_r: tensor like x_local): this rank's loss term and its gradient
+                (the shared entries' gradient is the LOCAL contribution; the driver sums it over the ranks)
+    """
+
+    def __init__(self, x_local: torch.Tensor, n_shared: int, evaluate: Callable, reducer=None, lr: float = 1.0,
+                 max_iter: int = 20, max_eval: Optional[int] = None, tolerance_grad: float = 1e-7,
+                 tolerance_change: float = 1e-9, history_size: int = 100):
+        assert x_local.dim() == 1 and 0 <= n_shared <= x_local.numel()
+        self.x = x_local
+        self.n = x_local.numel()
+        self.ns = int(n_shared)
+        self.evaluate = evaluate
+        self.red = reducer if reducer is not None else LocalReducer()
+        self.lr, self.max_iter = float(lr), int(max_iter)
+        self.max_eval = int(max_eval) if max_eval is not None else self.max_iter * 5 // 4
+        self.tol_grad, self.tol_change, self.hist = float(tolerance_grad), float(tolerance_change), int(history_size)
+        # every entry is counted once in the joint vector: the shared tail belongs to rank 0's partial sums
+        self.w = torch.ones(self.n, dtype=torch.float64, device=x_local.device)
+        if self.ns and self.red.rank != 0:
+            self.w[self.n - self.ns:] = 0.0
+
+    # ---- reductions -------------------------------------------------------------------------------------------------
+    def _dot(self, a: torch.Tensor, b: torch.Tensor) -> float:
+        return float(torch.dot(a.double() * self.w, b.double()))
+
+    def _eval(self, x: torch.Tensor, d: Optional[torch.Tensor]) -> Tuple[float, torch.Tensor, float, float, float, float]:
+        """closure at x: joint loss, joint gradient (shared entries summed over the ranks), g.d, |g|_1, g.g, max|g|.
+        The shared gradient must be known before the statistics, so an evaluation is two gathers when n_shared > 0 (the
+        first carries the loss and the local shared gradients, the second the statistics of the completed gradient)."""
+        loss_r, g = self.evaluate(x)
+        g = g.detach().to(torch.float32).clone()
+        if self.ns:
+            tab = self.red.gather([float(loss_r)] + g[self.n - self.ns:].double().cpu().tolist())
+            loss = float(tab[:, 0].sum())
+            shared = np.zeros(self.ns)
+            for r in range(tab.shape[0]):  # rank order, fp64: identical on every rank
+                shared = shared + tab[r, 1:]
+            g[self.n - self.ns:] = torch.from_numpy(shared.astype(np.float32)).to(g.device)
+            stats = [self._dot(g, d) if d is not None else 0.0, float((g.double().abs() * self.w).sum()),
+                     self._dot(g, g), float((g.abs().double() * self.w).max()) if self.n else 0.0]
+            tab = self.red.gather(stats)
+        else:
+            stats = [float(loss_r), self._dot(g, d) if d is not None else 0.0, float((g.double().abs() * self.w).sum()),
+                     self._dot(g, g), float(g.abs().max()) if self.n else 0.0]
+            tab = self.red.gather(stats)
+            loss = float(tab[:, 0].sum())
+            tab = tab[:, 1:]
+        gtd, g1, gg = (float(tab[:, 0].sum()), float(tab[:, 1].sum()), float(tab[:, 2].sum()))
+        gmax = float(tab[:, 3].max())
+        # losses are fp32 quantities in the reference (float(closure())): keep the joint loss at that precision
+        return float(np.float32(loss)), g, gtd, g1, gg, gmax
+
+    # ---- the solve ---------------------------------------------------------------------------------------------------
+    def solve(self) -> Dict:
+        x, n, hist = self.x, self.n, self.hist
+        dev = x.device
+        S = torch.zeros((hist, n), dtype=torch.float32, device=dev)
+        Y = torch.zeros((hist, n), dtype=torch.float32, device=dev)
+        slots: List[int] = []            # ring: physical rows of the pairs in the window, oldest first
+        SY = np.zeros((hist, hist))      # s_i . y_j by physical row
+        YY = np.zeros((hist, hist))
+        H_diag = 1.0
+        loss, g, _, g1, gg, gmax = self._eval(x, None)
+        first_loss = loss
+        n_eval, n_iter, reason = 1, 0, "max_iter"
+        if gmax <= self.tol_grad:
+            return {"n_iter": 0, "n_eval": 1, "first_loss": loss, "final_loss": loss,
+                    "stop_reason": "initial_tolerance_grad"}
+        d = None
+        t = 0.0
+        g_prev = None
+        while n_iter < self.max_iter:
+            n_iter += 1
+            if n_iter == 1:
+                d = g.neg()
+                gtd = -gg
+            else:
+                y = g - g_prev
+                s = d * t
+                # one gather: the new pair against the window and itself, and the new gradient against the window
+                rows = list(slots)
+                Sw = S[rows] if rows else S[:0]
+                Yw = Y[rows] if rows else Y[:0]
+                yw, sw, gw = y.double() * self.w, s.double() * self.w, g.double() * self.w
+                part = torch.cat([Sw.double() @ yw, Yw.double() @ yw, Yw.double() @ sw, Sw.double() @ gw, Yw.double() @ gw,
+                                  torch.stack([torch.dot(s.double(), yw), torch.dot(y.double(), yw),
+                                               torch.dot(s.double(), gw), torch.dot(y.double(), gw)])])
+                tot = self.red.gather(part.cpu().tolist())
+                tot = tot.sum(axis=0)   # rank order, fp64: identical on every rank
+                k0 = len(rows)
+                S_y, Y_y, Y_s, S_g, Y_g = (tot[0:k0], tot[k0:2 * k0], tot[2 * k0:3 * k0], tot[3 * k0:4 * k0],
+                                           tot[4 * k0:5 * k0])
+                ys, yy, sg_new, yg_new = tot[5 * k0:5 * k0 + 4]
+                if ys > 1e-10:
+                    if len(slots) == hist:
+                        row = slots.pop(0)
+                        S_y, Y_y, Y_s, S_g, Y_g = S_y[1:], Y_y[1:], Y_s[1:], S_g[1:], Y_g[1:]
+                        rows = rows[1:]
+                    else:
+                        row = len(slots)
+                    S[row] = s
+                    Y[row] = y
+                    for i, ri in enumerate(rows):
+                        SY[ri, row] = S_y[i]      # s_i . y_new
+                        SY[row, ri] = Y_s[i]      # s_new . y_i
+                        YY[ri, row] = YY[row, ri] = Y_y[i]
+                    SY[row, row] = ys
+                    YY[row, row] = yy
+                    slots.append(row)
+                    H_diag = ys / yy
+                    S_g = np.append(S_g, sg_new)
+                    Y_g = np.append(Y_g, yg_new)
+                k = len(slots)
+                idx = np.array(slots, dtype=np.int64)
+                U = SY[np.ix_(idx, idx)]
+                Yw_ = YY[np.ix_(idx, idx)]
+                al = np.zeros(k)
+                for i in range(k - 1, -1, -1):   # loop 1 of the two-loop recursion in coefficient space
+                    al[i] = (-S_g[i] - np.dot(al[i + 1:], U[i, i + 1:])) / U[i, i]
+                cg = -H_diag
+                cy = -H_diag * al
+                wv = Yw_ @ cy
+                cs = np.zeros(k)
+                for i in range(k):               # loop 2
+                    be = (cg * Y_g[i] + wv[i] + np.dot(cs[:i], U[:i, i])) / U[i, i]
+                    cs[i] = al[i] - be
+                d = (cg * g.double() + torch.from_numpy(cy).to(dev) @ Y[idx.tolist()].double()
+                     + torch.from_numpy(cs).to(dev) @ S[idx.tolist()].double()).to(torch.float32)
+                gtd = float(cg * gg + np.dot(cy, Y_g) + np.dot(cs, S_g))
+            g_prev = g.clone()
+            prev_loss = loss
+            t = min(1.0, 1.0 / g1) * self.lr if n_iter == 1 else self.lr
+            if gtd > -self.tol_change:
+                reason = "directional_derivative"
+                break
+            d_norm = float(self.red.gather([float((d.abs().double() * self.w).max())]).max())
+            # ---- strong Wolfe (torch/optim/lbfgs.py:40-209); the line search's own tolerance_change is torch's default
+            x0 = x.clone()
+            max_ls = self.max_eval - n_eval
+            c1, c2 = 1e-4, 0.9
+
+            def trial(tt):
+                x.copy_(x0 + tt * d)
+                return self._eval(x, d)
+
+            f_new, g_new, gtd_new, g1_new, gg_new, gmax_new = trial(t)
+            ls_evals = 1
+            t_prev, f_prev, gp_, gtd_prev = 0.0, loss, (g, g1, gg, gmax), gtd
+            done, ls_iter = False, 0
+            bracket = None
+            while ls_iter < max_ls:
+                if f_new > (loss + c1 * t * gtd) or (ls_iter > 1 and f_new >= f_prev):
+                    bracket = [t_prev, t]
+                    bracket_f = [f_prev, f_new]
+                    bracket_g = [gp_, (g_new, g1_new, gg_new, gmax_new)]
+                    bracket_gtd = [gtd_prev, gtd_new]
+                    break
+                if abs(gtd_new) <= -c2 * gtd:
+                    bracket = [t]
+                    bracket_f = [f_new]
+                    bracket_g = [(g_new, g1_new, gg_new, gmax_new)]
+                    done = True
+                    break
+                if gtd_new >= 0:
+                    bracket = [t_prev, t]
+                    bracket_f = [f_prev, f_new]
+                    bracket_g = [gp_, (g_new, g1_new, gg_new, gmax_new)]
+                    bracket_gtd = [gtd_prev, gtd_new]
+                    break
+                min_step = t + 0.01 * (t - t_prev)
+                max_step = t * 10
+                tmp = t
+                t = _cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(min_step, max_step))
+                t_prev, f_prev, gp_, gtd_prev = tmp, f_new, (g_new, g1_new, gg_new, gmax_new), gtd_new
+                f_new, g_new, gtd_new, g1_new, gg_new, gmax_new = trial(t)
+                ls_evals += 1
+                ls_iter += 1
+            if ls_iter == max_ls:
+                bracket = [0.0, t]
+                bracket_f = [loss, f_new]
+                bracket_g = [(g, g1, gg, gmax), (g_new, g1_new, gg_new, gmax_new)]
+            insuf = False
+            low_pos, high_pos = (0, 1) if bracket_f[0] <= bracket_f[-1] else (1, 0)
+            while not done and ls_iter < max_ls:
+                if abs(bracket[1] - bracket[0]) * d_norm < 1e-9:
+                    break
+                t = _cubic_interpolate(bracket[0], bracket_f[0], bracket_gtd[0], bracket[1], bracket_f[1], bracket_gtd[1])
+                eps = 0.1 * (max(bracket) - min(bracket))
+                if min(max(bracket) - t, t - min(bracket)) < eps:
+                    if insuf or t >= max(bracket) or t <= min(bracket):
+                        t = max(bracket) - eps if abs(t - max(bracket)) < abs(t - min(bracket)) else min(bracket) + eps
+                        insuf = False
+                    else:
+                        insuf = True
+                else:
+                    insuf = False
+                f_new, g_new, gtd_new, g1_new, gg_new, gmax_new = trial(t)
+                ls_evals += 1
+                ls_iter += 1
+                if f_new > (loss + c1 * t * gtd) or f_new >= bracket_f[low_pos]:
+                    bracket[high_pos], bracket_f[high_pos] = t, f_new
+                    bracket_g[high_pos], bracket_gtd[high_pos] = (g_new, g1_new, gg_new, gmax_new), gtd_new
+                    low_pos, high_pos = (0, 1) if bracket_f[0] <= bracket_f[1] else (1, 0)
+                else:
+                    if abs(gtd_new) <= -c2 * gtd:
+                        done = True
+                    elif gtd_new * (bracket[high_pos] - bracket[low_pos]) >= 0:
+                        bracket[high_pos], bracket_f[high_pos] = bracket[low_pos], bracket_f[low_pos]
+                        bracket_g[high_pos], bracket_gtd[high_pos] = bracket_g[low_pos], bracket_gtd[low_pos]
+                    bracket[low_pos], bracket_f[low_pos] = t, f_new
+                    bracket_g[low_pos], bracket_gtd[low_pos] = (g_new, g1_new, gg_new, gmax_new), gtd_new
+            lp = 0 if len(bracket) == 1 else low_pos
+            t = bracket[lp]
+            loss = bracket_f[lp]
+            g, g1, gg, gmax = bracket_g[lp]
+            x.copy_(x0 + t * d)
+            n_eval += ls_evals
+            if n_iter == self.max_iter:
+                reason = "max_iter"
+                break
+            if n_eval >= self.max_eval:
+                reason = "max_eval"
+                break
+            if gmax <= self.tol_grad:
+                reason = "tolerance_grad"
+                break
+            if d_norm * abs(t) <= self.tol_change:
+                reason = "tolerance_change(step)"
+                break
+            if abs(loss - prev_loss) < self.tol_change:
+                reason = "tolerance_change(loss)"
+                break
+        return {"n_iter": n_iter, "n_eval": n_eval, "first_loss": first_loss, "final_loss": loss, "stop_reason": reason}

@@ -458,6 +458,34 @@ class _StageProblem:
                 "final_loss": stats.final_loss, "stop_reason": STOP_REASONS[stats.stop_reason],
                 "device_ms": stats.device_ms}
 
+    def solve_shared(self, x: torch.Tensor, reducer, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
+                     tolerance_change: float = 1e-9, history_size: int = 100) -> Dict:
+        """EXTENSION (BASELINE configs[3], not reference behaviour): this stage's problem on every rank of `reducer`'s
+        process group solved as ONE joint L-BFGS problem whose shape vector (the 10 betas) is shared by all ranks' sequences
+        -- dist_lbfgs.ShardedLBFGS drives the fused HIP closure of each rank; per evaluation the ranks exchange
+        [loss, d loss / d betas (10), g.d, |g|_1, g.g, max|g|], per iteration the new Gram row of the history (< 1 KB).
+        x is updated in place; betas end bit-identical on every rank."""
+        from .dist_lbfgs import ShardedLBFGS
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        F = self.F
+        off = {UUO_STAGE_CHAMFER: 4 * F, UUO_STAGE_MARKER: 207 * F, UUO_STAGE_PART: 3 * F + 1}[self.stage]
+        idx = torch.arange(self.n, device=self.device)
+        perm = torch.cat([idx[:off], idx[off + 10:], idx[off:off + 10]])  # own parameters first, the shared betas last
+        xs = x[perm].clone()
+        full = torch.empty_like(x)
+
+        def evaluate(xl):
+            full[perm] = xl
+            loss, grad, _ = self.evaluate(full, want_nn=False)
+            return loss, grad[perm]
+
+        st = ShardedLBFGS(xs, 10, evaluate, reducer=reducer, lr=lr, max_iter=max_iter, tolerance_grad=tolerance_grad,
+                          tolerance_change=tolerance_change, history_size=history_size).solve()
+        x[perm] = xs
+        st.update(device_ms=0.0, driver="sharded-lbfgs(world=%d)" % reducer.world)
+        return st
+
     def solve_adam(self, x: torch.Tensor, num_steps: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
                    callback: Optional[Callable[[int, float], None]] = None) -> Dict:
         """EXTENSION, not reference behaviour (the reference only drives its closures with L-BFGS; BASELINE's north star

@@ -433,7 +433,36 @@ def multimodal_video_mocap(
         # the reference's hypotheses run one after the other and each placement reads the labels the previous one
         # recomputed (only the "part" granularity looks at them): keep that order
         n_threads = 1
-    if lockstep:
+    from .parallel import hypothesis_shard, shared_betas_reducer
+
+    hyp_shard = hypothesis_shard()
+    if shared_betas_reducer() is not None:
+        # shared betas across ranks (extension): every solve is a collective, so all ranks must issue them in one order
+        lockstep, n_threads = False, 1
+        if hyp_shard is not None:
+            raise NotImplementedError("shared betas and hypothesis sharding are two different uses of the ranks")
+    if hyp_shard is not None and hyp_shard.world > 1:
+        # this rank fits hypotheses rank, rank + world, ...; one all_gather_object brings every rank all results
+        if recompute_labels:
+            raise NotImplementedError("recompute_marker_labels chains the hypotheses (reference :529-539); not shardable")
+        mine = hyp_shard.mine(len(root_orient_angles))
+        local = {}
+        if len(mine) > 1 and device.type == "cuda":
+            main_stream = torch.cuda.current_stream(device)
+            streams = worker_streams(device, len(mine), "hypothesis")
+            for st_ in streams:
+                st_.wait_stream(main_stream)
+            pool = worker_pool(len(mine), "hypothesis")
+            futures = [pool.submit(fit_hypothesis, k, root_orient_angles[i], streams[k]) for k, i in enumerate(mine)]
+            for i, f in zip(mine, futures):
+                local[i] = f.result()
+            for st_ in streams:
+                main_stream.wait_stream(st_)
+        else:
+            for i in mine:
+                local[i] = fit_hypothesis(0, root_orient_angles[i], None, marker_labels)
+        results = hyp_shard.exchange(local, len(root_orient_angles))
+    elif lockstep:
         results = fit_hypotheses_lockstep()
     elif n_threads > 1 and device.type == "cuda":
         main_stream = torch.cuda.current_stream(device)

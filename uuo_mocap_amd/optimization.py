@@ -162,6 +162,14 @@ def _solve(prob, x, config, stage: str, lr: float, verbose_tag: str, verbose: bo
     stage's num_iters) Adam steps of `optimizer.adam_lr` (default: the stage's L-BFGS lr / 100) on the same fused closure."""
     opt = config["optimizer"]
     kind = str(opt.get("type", "lbfgs")).lower()
+    from .parallel import shared_betas_reducer
+
+    shared = shared_betas_reducer()
+    if shared is not None:  # EXTENSION: one joint problem over the ranks, shared betas (parallel.shared_betas)
+        if kind != "lbfgs" or point_cb is not None:
+            raise NotImplementedError("shared betas: L-BFGS driver without per-evaluation callbacks only")
+        return prob.solve_shared(x, shared, max_iter=config["stages"][stage]["num_iters"], lr=lr,
+                                 tolerance_grad=opt["tolerance_grad"], tolerance_change=opt["tolerance_change"])
     if kind == "lbfgs":
         return prob.solve(x, max_iter=config["stages"][stage]["num_iters"], lr=lr, tolerance_grad=opt["tolerance_grad"],
                           tolerance_change=opt["tolerance_change"], callback=_printer(verbose_tag, verbose),

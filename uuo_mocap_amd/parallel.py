@@ -106,3 +106,86 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None) 
 
     with ThreadPoolExecutor(max_workers=inflight) as pool:
         return list(pool.map(run, items))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Beyond "one sequence per rank": the two other decompositions of SURVEY.md 8e.  Both are switched on for the calling thread
+# with a context manager, so the operator surface (multimodal_video_mocap, optim_chamfer, optim_markers) stays the reference's.
+# ---------------------------------------------------------------------------------------------------------------------
+import contextlib
+import threading
+
+_ctx = threading.local()
+
+
+def shared_betas_reducer():
+    """The reducer of the active `shared_betas(...)` context of this thread, or None."""
+    return getattr(_ctx, "shared", None)
+
+
+@contextlib.contextmanager
+def shared_betas(group=None, device=None, reducer=None):
+    """EXTENSION (BASELINE configs[3]; not reference behaviour -- the reference fits every sequence with its own betas,
+    SURVEY.md F12): inside this context every chamfer / marker stage solve is ONE joint L-BFGS problem over the ranks of
+    `group`, the sequences of the ranks (same subject) sharing a single shape vector.  All ranks must run the same stages in
+    the same order (they do: the iteration counts follow from all-reduced scalars only); the yaw hypotheses therefore run
+    one after the other instead of on concurrent threads.  Without an initialised process group the context is the
+    one-rank case of the same driver."""
+    from .dist_lbfgs import DistReducer, LocalReducer
+
+    if reducer is None:
+        reducer = DistReducer(group, device) if _dist() is not None else LocalReducer()
+    prev = getattr(_ctx, "shared", None)
+    _ctx.shared = reducer
+    try:
+        yield reducer
+    finally:
+        _ctx.shared = prev
+
+
+class HypothesisShard:
+    """the yaw hypotheses of ONE sequence (reference multimodal.py:462-574: independent solves, best one
+    picked by 4 scalars, :576-599) spread over the ranks of a process group -- rank r fits hypotheses r, r + world, ...;
+    the per-hypothesis results (the parameters of each stage as host arrays, ~263 KB each at F = 300, and the solver
+    statistics) are exchanged with one all_gather_object; every rank then holds all of them and continues identically."""
+
+    def __init__(self, group=None, rank: int = None, world: int = None):
+        dist = _dist()
+        self.group = group
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist is not None else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if dist is not None else 1)
+
+    def mine(self, count: int) -> List[int]:
+        return list(range(self.rank, count, self.world))
+
+    def exchange(self, local: Dict[int, Dict], count: int) -> List[Dict]:
+        dist = _dist()
+        if dist is None or self.world == 1:
+            parts = [local]
+        else:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, local, group=self.group)
+        merged: Dict[int, Dict] = {}
+        for part in parts:
+            merged.update(part)
+        missing = [i for i in range(count) if i not in merged]
+        if missing:
+            raise RuntimeError("hypotheses %s were fitted by no rank" % missing)
+        return [merged[i] for i in range(count)]
+
+
+def hypothesis_shard():
+    return getattr(_ctx, "hyp", None)
+
+
+@contextlib.contextmanager
+def shard_hypotheses(group=None, shard: HypothesisShard = None):
+    """Inside this context multimodal_video_mocap fits only this rank's share of the yaw hypotheses and exchanges the
+    results (HypothesisShard): one sequence uses up to `num_root_orient_angles` GPUs.  Every rank returns the full,
+    identical output dictionary."""
+    prev = getattr(_ctx, "hyp", None)
+    _ctx.hyp = shard if shard is not None else HypothesisShard(group)
+    try:
+        yield _ctx.hyp
+    finally:
+        _ctx.hyp = prev
