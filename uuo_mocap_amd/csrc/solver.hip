@@ -1948,6 +1948,8 @@ struct uuo_batch {
   unsigned char* d_blob = nullptr;
   size_t blob_cap = 0;
   int lb_n = 0, lb_hist = 0;
+  size_t blob_used = 0;        // bytes of the blob the last flush staged
+  bool blob_pending = false;   // that flush's host-to-device copy may not have executed yet (no sync point passed since)
   double* d_scores = nullptr;  // uuo_batch_part_scores: [nb][F][2] per-frame sums
   double* h_scores = nullptr;
   size_t score_cap = 0;
@@ -2050,6 +2052,14 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
     total += (cnt[k] * width[k] + 255) / 256 * 256;
   }
   UUO_REQUIRE(total <= b->blob_cap, "batch: argument staging buffer too small");
+  // A flush overwrites the pinned blob from its start, so the previous flush's (asynchronous) host-to-device copy must
+  // have executed.  Inside a solve that is implied -- every round waits for its evaluations' reports, which follow the copy
+  // on the stream -- and the flag is cleared there; a flush that follows another one with no such wait synchronises first.
+  if (b->blob_pending && total > 0) UUO_HIP_CHECK(hipStreamSynchronize(s));
+  if (total > 0) {
+    b->blob_pending = true;
+    b->blob_used = total;
+  }
   size_t fill[UUO_OP_COUNT];
   for (int k = 0; k < UUO_OP_COUNT; ++k) fill[k] = 0;
   for (int i = 0; i < nb; ++i)
@@ -2212,11 +2222,13 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
     result = batch_flush(b, s, cos, nb);
     if (result) break;
     // wait for the reports of the problems that are in an evaluation
+    bool waited_any = false;
     timespec t_start;
     clock_gettime(CLOCK_MONOTONIC, &t_start);
     for (int i = 0; i < nb && result == 0; ++i) {
       BatchCo& c = cos[i];
       if (c.done || !c.waiting) continue;
+      waited_any = true;
       unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(c.w->h_out);
       unsigned long spins = 0;
       while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
@@ -2239,12 +2251,16 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
         }
       }
     }
+    if (waited_any && result == 0) b->blob_pending = false;  // a report arrived: everything enqueued before it has run
   }
   g_batch_yield = nullptr;
   uuo_recorder = nullptr;
   if (result == 0) {
     result = batch_flush(b, s, cos, nb);  // the final copies of problems that ended in the last round
-    if (result == 0) UUO_HIP_CHECK(hipStreamSynchronize(s));
+    if (result == 0) {
+      UUO_HIP_CHECK(hipStreamSynchronize(s));
+      b->blob_pending = false;
+    }
   } else {
     (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
   }
@@ -2285,8 +2301,11 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
     UUO_HIP_CHECK(hipHostMalloc((void**)&b->h_scores, out_doubles * sizeof(double), hipHostMallocDefault));
     b->score_cap = out_doubles;
   }
-  UUO_REQUIRE((size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap, "uuo_batch_part_scores: staging buffer too small");
-  PartScoreArgs* ha = reinterpret_cast<PartScoreArgs*>(b->h_blob);
+  // The forward's argument structs were staged in the first b->blob_used bytes of the pinned blob and their host-to-device
+  // copy may not have executed yet (it is asynchronous): the score kernel's structs go BEHIND them, never over them.
+  const size_t score_off = (b->blob_used + 255) / 256 * 256;
+  UUO_REQUIRE(score_off + (size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap, "uuo_batch_part_scores: staging buffer too small");
+  PartScoreArgs* ha = reinterpret_cast<PartScoreArgs*>(b->h_blob + score_off);
   for (int i = 0; i < nb; ++i) {
     PartScoreArgs a;
     a.h.gx = F;
@@ -2302,11 +2321,13 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
     a.out = b->d_scores + (size_t)i * F * 2;
     ha[i] = a;
   }
-  UUO_HIP_CHECK(hipMemcpyAsync(b->d_blob, b->h_blob, (size_t)nb * sizeof(PartScoreArgs), hipMemcpyHostToDevice, s));
-  rc = uuo_launch_part_scores(s, b->d_blob, nb, F);
+  UUO_HIP_CHECK(hipMemcpyAsync(b->d_blob + score_off, b->h_blob + score_off, (size_t)nb * sizeof(PartScoreArgs),
+                               hipMemcpyHostToDevice, s));
+  rc = uuo_launch_part_scores(s, b->d_blob + score_off, nb, F);
   if (rc) return rc;
   UUO_HIP_CHECK(hipMemcpyAsync(b->h_scores, b->d_scores, out_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
   UUO_HIP_CHECK(hipStreamSynchronize(s));
+  b->blob_pending = false;
   for (int i = 0; i < nb; ++i) {
     double cx = 0.0, cy = 0.0;
     const double* o = b->h_scores + (size_t)i * F * 2;

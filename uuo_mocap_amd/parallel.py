@@ -12,6 +12,15 @@ import torch
 
 
 def world_info():
+    """(rank, world size, local rank): from the initialised default process group when there is one, else from the
+    launcher's environment (torchrun)."""
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", str(dist.get_rank())))
+    except Exception:
+        pass
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
