@@ -63,14 +63,32 @@ def parse():
                          "profiles/r1_roofline_kernel_stats.csv")
     ap.add_argument("--cpu-evals", type=int, default=20, help="closure evaluations per stage type timed on the CPU")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the hmr_full / hmr_part / mht_rotation legs")
+    ap.add_argument("--mode", default="sequences", choices=["sequences", "hypotheses", "shared_betas"],
+                    help="how N ranks share the work (SURVEY.md 8e): sequences = independent sequences per rank, no data-path "
+                         "collective (default; weak scaling); hypotheses = every step is ONE sequence whose yaw hypotheses "
+                         "are spread over the ranks (strong scaling, useful up to num_root_orient_angles ranks); "
+                         "shared_betas = one sequence per rank, one shape vector for all of them (extension: joint L-BFGS, "
+                         "one small all_gather per evaluation)")
     return ap.parse_args()
 
 
+MODE = "sequences"
+
+
 def fit_once(smpl, seq, cfg, dev):
+    import contextlib
+
+    from uuo_mocap_amd import parallel
     from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
 
-    out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
-                                 save_stages=False, smpl_inference=smpl)
+    ctx = contextlib.nullcontext()
+    if MODE == "hypotheses":
+        ctx = parallel.shard_hypotheses()
+    elif MODE == "shared_betas":
+        ctx = parallel.shared_betas(device=dev)
+    with ctx:
+        out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                     save_stages=False, smpl_inference=smpl)
     return out, copy.deepcopy(dict(last_run_stats()))
 
 
@@ -237,7 +255,11 @@ def packaged_cfg_full():
 
 
 def main():
+    global MODE
     args = parse()
+    MODE = args.mode
+    if MODE != "sequences":
+        args.inflight = 1  # both modes issue collectives from the fitting thread: one sequence at a time per rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -271,7 +293,8 @@ def main():
     limb = args.config == "hmr_part"
     # distinct seeds for every warm-up and timed sequence of every rank (the solves stop on tolerances, so time depends on
     # the data: a timed step must not repeat a warm-up step)
-    seqs = [make_sequence(tables, seed=rank * n_seq + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb)
+    seed_base = 0 if MODE == "hypotheses" else rank * n_seq   # hypotheses mode: all ranks work on the SAME sequences
+    seqs = [make_sequence(tables, seed=seed_base + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb)
             for i in range(n_seq)]
 
     if args.roofline_only:
@@ -329,7 +352,7 @@ def main():
     if rank == 0:
         n_eval = eval_counts(all_stats[-1])
         total_evals = sum(sum(eval_counts(s).values()) for s in all_stats)
-        frames = world * args.steps * F
+        frames = (1 if MODE == "hypotheses" else world) * args.steps * F
         value = frames / elapsed
         roofline = measure_roofline(smpl, seqs[-1], dev, F)
         # whole-fit arithmetic rate: SURVEY 8d's algorithmic FLOPs of every closure evaluation the timed fits executed
@@ -347,12 +370,13 @@ def main():
         result = {
             "metric": "mocap frames/sec fitted (300-frame seq, 50 markers)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if MODE == "hypotheses" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.yaml full fit, F=%d frames x M=%d markers, synthetic SMPL-shaped model, one "
                                    "sequence per step per GPU" % (args.config, F, M if not limb else 10),
                        "frames": F, "markers": M, "sequences_per_gpu": args.steps,
-                       "sequences_in_flight": args.inflight},
+                       "sequences_in_flight": args.inflight, "rank_mode": MODE},
             "closure_evals_per_step": total_evals / max(args.steps, 1), "closure_evals_last_step": n_eval,
             "frame_evals_per_s": world * total_evals * F / elapsed if world == 1 else None,
             "fit_quality": {"mean": q_mean, "worst": q_worst, "steps": len(quality) * world,

@@ -1478,3 +1478,70 @@ def test_lockstep_batch_is_bit_identical_to_solving_one_by_one(smpl, dev):
         return [MarkerProblem(smpl, markers, o_pose, o_betas, (gt_vids + 7 * k) % 6890, cfg) for k in range(3)]
 
     check(marker_problems, lambda p, i: p.pack(o_pose, o_betas, root, trans + 0.01 * i), max_iter=30, lr=1.0)
+
+
+@pytest.mark.gpu
+def test_batch_runner_on_a_reference_style_dataset_tree(smpl, dev, tmp_path):
+    """The runner pointed at a CMU-Kitchen style tree (BASELINE configs[1]'s inputs): `<dataset>/mocap/<subject>/<seq>.c3d`
+    (millimetres, an invalid point), `comparisons/4d_humans/<subject>/<seq>.<camera>/results/demo_<seq>.pkl` (joblib,
+    4D-Humans per-frame layout, two frames without a detection) and `videos/<subject>/<seq>.<camera>.avi` (30 Hz in its
+    RIFF headers) -- read by uuo_mocap_amd.ingest, fitted, written in the reference's output layout."""
+    import struct
+
+    import joblib
+
+    from uuo_mocap_amd import ingest, runner
+    from uuo_mocap_amd.config import CONFIG_DIR
+
+    F, M = 14, 10
+    seq = make_sequence(smpl.tables, seed=77, num_frames=F, num_markers=M, dropout=0.0)
+    root = tmp_path / "data"
+    ds, subj, name, cam = "cmu_kitchen_pilot", "s1", "brownies_00000150", runner.CAMERAS["cmu_kitchen_pilot"]
+    (root / ds / "mocap" / subj).mkdir(parents=True)
+    pts = seq.markers.get_points().astype(np.float64) * 1000.0
+    pts[3, 2] = np.nan
+    ingest.write_c3d(str(root / ds / "mocap" / subj / (name + ".c3d")), pts, rate=30.0, units="mm")
+    corr = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], np.float32)
+    data = {}
+    for f in range(F):
+        if f in (5, 6):
+            data["f%04d" % f] = {"tracked_ids": [], "smpl": [], "3d_joints": [], "camera_bbox": [], "center": [],
+                                 "scale": [], "size": [], "2d_joints": []}
+            continue
+        j3d = np.zeros((45, 3), np.float32)
+        j3d[8] = seq.img_smpl.trans[f].numpy()
+        data["f%04d" % f] = {
+            "tracked_ids": [1],
+            "smpl": [{"global_orient": (corr.T @ seq.img_smpl.root_orient[f, 0].numpy())[None],
+                      "body_pose": seq.img_smpl.pose_body[f].numpy(), "betas": seq.img_smpl.betas[f].numpy()}],
+            "3d_joints": [j3d], "camera_bbox": [np.zeros(3, np.float32)], "center": [np.zeros(2, np.float32)],
+            "scale": [1.0], "size": [np.array([480.0, 640.0], np.float32)], "2d_joints": [np.zeros(90, np.float32)]}
+    res_dir = root / ds / "comparisons" / "4d_humans" / subj / (name + "." + cam) / "results"
+    res_dir.mkdir(parents=True)
+    joblib.dump(data, str(res_dir / ("demo_" + name + ".pkl")))
+
+    def chunk(tag, payload):
+        return tag + struct.pack("<I", len(payload)) + payload
+
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII", 0, 0, 0, 0, 1, 30, 0, F, 0, 0, 0) + b"\x00" * 8
+    body = b"AVI " + chunk(b"LIST", b"hdrl" + chunk(b"LIST", b"strl" + chunk(b"strh", strh)))
+    (root / ds / "videos" / subj).mkdir(parents=True)
+    (root / ds / "videos" / subj / (name + "." + cam + ".avi")).write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("parent: %s\nname: unit\nstages:\n  part:\n    num_iters: 8\n  chamfer:\n    num_iters: 8\n"
+                   "  marker:\n    num_iters: 8\n" % os.path.join(CONFIG_DIR, "video_mocap.yaml"))
+    args = runner.build_parser().parse_args(["--config", str(cfg), "--dataset", ds, "--input_dir", str(root), "--gpu", "0",
+                                             "--print_options"])
+    loaded = runner.load_sequence(str(root / ds / "mocap" / subj / name), ds, str(root))
+    img, mk = loaded
+    assert img.img_mask.tolist() == [f not in (5, 6) for f in range(F)] and img.freq == 30.0
+    np.testing.assert_allclose(img.root_orient[0].numpy(), seq.img_smpl.root_orient[0].numpy(), atol=1e-6)
+    assert mk.get_points().shape == (F, M, 3) and (mk.get_points()[3, 2] == 0).all() and mk.get_frequency() == 30
+    np.testing.assert_allclose(mk.get_points()[0], seq.markers.get_points()[0], atol=1e-6)
+    assert runner.run(args) == 1
+    out = np.load(root / ds / "results" / "unit" / subj / (name + "_stageii.npz"))
+    assert out["poses"].shape == (F, 72) and out["mocap_markers"].shape == (F, M, 3) and float(out["mocap_frame_rate"]) == 30.0
+    # a sequence without its 4D-Humans result is skipped like in the reference
+    ingest.write_c3d(str(root / ds / "mocap" / subj / "orphan.c3d"), pts, rate=30.0, units="mm")
+    assert runner.run(args) == 0

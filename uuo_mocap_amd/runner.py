@@ -6,10 +6,11 @@ Same command line (argument names, `--print_options` default), same directory co
 same output files: `betas[10], trans[F,3], poses[F,72] (axis-angle, root first), mocap_frame_rate,
 mocap_markers[F,M,3], gender="neutral"` plus one `_stageii.<stage>.npz` per saved stage (test.py:115-143).
 
-What it does not reproduce are the dataset readers (`.c3d` through ezc3d, the 4D-Humans `.pkl`, the video frame rate
-through OpenCV: SURVEY 8f rank 3).  A sequence is read from `<sequence>.npz` holding
+Inputs: the reference's own triple -- `<sequence>.c3d` (uuo_mocap_amd.ingest.Markers: a self-contained C3D point reader
+in place of ezc3d), the 4D-Humans `demo_<sequence>.pkl` (ingest.ImgSmpl: gap filling by lerp / slerp, img_mask) and the
+`.avi`'s frame rate (RIFF headers in place of OpenCV) -- or a `<sequence>.npz` bundle holding
 `markers[F,M,3], mocap_frame_rate, pose_body[F,23,3,3], root_orient[F,1,3,3], betas[F,10], img_mask[F], video_frame_rate`
-(`write_sequence_npz` writes one); a `.c3d` without such a bundle raises NotImplementedError.
+(`write_sequence_npz` writes one).
 
 One process per GPU: with `torchrun` (WORLD_SIZE > 1) the sequences are sharded round-robin over the ranks
 (`parallel.shard_indices`), no collective on the data path; `--inflight N` overlaps N sequences per GPU."""
@@ -49,6 +50,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--parts_list", nargs="+", default=[])
     parser.add_argument("--print_options", type=str, nargs="*", default=["loss", "progress"])
     parser.add_argument("--inflight", type=int, default=1, help="sequences fitted concurrently per GPU (not in the reference)")
+    parser.add_argument("--video_fps", type=float, default=None,
+                        help="video frame rate when the .avi is absent or not an AVI container (not in the reference: it asks OpenCV)")
     return parser
 
 
@@ -63,13 +66,38 @@ def write_sequence_npz(path: str, markers: np.ndarray, mocap_frame_rate: float, 
              video_frame_rate=float(mocap_frame_rate if video_frame_rate is None else video_frame_rate))
 
 
-def load_sequence(filename_base: str):
-    """-> (img_smpl, markers) with the attributes multimodal_video_mocap reads (reference test.py:88-101)."""
+def load_dataset_sequence(filename_base: str, dataset: str, input_dir: str, video_fps: Optional[float] = None):
+    """The reference's own inputs (test.py:76-102): `<sequence>.c3d` markers, the 4D-Humans result
+    `<input_dir>/<dataset>/comparisons/4d_humans/<subject>/<sequence>[.<camera>]/results/demo_<sequence>.pkl` (joblib) and the
+    frame rate of `<input_dir>/<dataset>/videos/<subject>/<sequence>[.<camera>].avi` (or `video_fps`).  Returns None when
+    the HMR result is missing (the reference prints "Skipping" and moves on, test.py:91-93)."""
+    from . import ingest
+
+    subject = os.path.basename(os.path.dirname(filename_base))
+    name = os.path.basename(filename_base)
+    camera = CAMERAS.get(dataset)
+    video_name = name if camera is None else name + "." + camera
+    pkl = os.path.join(input_dir, dataset, "comparisons", "4d_humans", subject, video_name, "results", "demo_" + name + ".pkl")
+    if not os.path.isfile(pkl):
+        print("Skipping", pkl)
+        return None
+    if video_fps is None:
+        video_fps = ingest.video_frame_rate(os.path.join(input_dir, dataset, "videos", subject, video_name + ".avi"))
+    img_smpl = ingest.load_hmr_pkl(pkl, video_fps)
+    markers = ingest.Markers(filename_base + ".c3d")
+    points = ingest.cleanup_markers(np.nan_to_num(markers.get_points(), nan=0.0))  # test.py:98-101
+    markers.set_points(points)
+    return img_smpl, markers
+
+
+def load_sequence(filename_base: str, dataset: Optional[str] = None, input_dir: Optional[str] = None,
+                  video_fps: Optional[float] = None):
+    """-> (img_smpl, markers) with the attributes multimodal_video_mocap reads (reference test.py:88-101): from the
+    `<sequence>.npz` bundle if there is one, else from the reference's `.c3d` / 4D-Humans `.pkl` / `.avi` triple."""
     npz = filename_base + ".npz"
     if not os.path.isfile(npz):
-        if os.path.isfile(filename_base + ".c3d"):
-            raise NotImplementedError("reading %s.c3d needs the ezc3d / 4D-Humans / OpenCV readers, which are not part "
-                                      "of the accelerated path (SURVEY 8f rank 3); provide %s" % (filename_base, npz))
+        if os.path.isfile(filename_base + ".c3d") and dataset is not None and input_dir is not None:
+            return load_dataset_sequence(filename_base, dataset, input_dir, video_fps)
         raise FileNotFoundError(npz)
     d = np.load(npz)
     points = np.nan_to_num(np.asarray(d["markers"], np.float32), nan=0.0)  # test.py:98-99
@@ -186,12 +214,15 @@ def run(args, fit_fn: Optional[Callable] = None) -> int:
 
         def one(job):
             base, out = job
-            img_smpl, markers = load_sequence(base)
+            loaded = load_sequence(base, args.dataset, args.input_dir, getattr(args, "video_fps", None))
+            if loaded is None:
+                return None
+            img_smpl, markers = loaded
             result = fit_fn(img_smpl, markers)
             save_outputs(out, result)
             return out
 
-        written += len(fit_many(mine, one, inflight=args.inflight, device=device))
+        written += sum(1 for r in fit_many(mine, one, inflight=args.inflight, device=device) if r is not None)
     return written
 
 
