@@ -120,3 +120,57 @@ class SmplInferenceRef(nn.Module):
 
     def get_lbs_weights(self):
         return self.smpl.lbs_weights
+
+
+def batch_rodrigues(rot_vecs: torch.Tensor, epsilon: float = 1e-8) -> torch.Tensor:
+    """smplx.lbs.batch_rodrigues (published algorithm)."""
+    batch_size = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos = torch.unsqueeze(torch.cos(angle), dim=1)
+    sin = torch.unsqueeze(torch.sin(angle), dim=1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((batch_size, 1), dtype=rot_vecs.dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view((batch_size, 3, 3))
+    ident = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(dim=0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+class SmplInferenceGenderRef(nn.Module):
+    """Restates reference utils/smpl.py:56-131 (SmplInferenceGender) over two SMPLRef models."""
+
+    def __init__(self, tables_male, tables_female):
+        super().__init__()
+        self.smpls = {"male": SMPLRef(tables_male), "female": SMPLRef(tables_female)}
+
+    def forward(self, poses, betas, root_orient, trans, gender_one_hot, pose2rot: bool = True,
+                compute_part_labels: bool = False):
+        if betas.shape[1] != 10:
+            raise ValueError("Betas array must have 10 beta values")
+        if len(gender_one_hot.shape) != 2:
+            raise ValueError("Gender one-hot vector must have 2 dimensions")
+        batch_size, num_frames, _ = trans.shape
+        poses_rs = torch.reshape(poses, (-1, poses.shape[-1]))
+        root_rs = torch.reshape(root_orient, (-1, root_orient.shape[-1]))
+        trans_rs = torch.reshape(trans, (-1, trans.shape[-1]))
+        betas_rs = torch.repeat_interleave(torch.unsqueeze(betas, dim=0), dim=0, repeats=num_frames)
+        betas_rs = torch.reshape(betas_rs, (-1, betas.shape[-1]))
+        g = torch.repeat_interleave(torch.unsqueeze(gender_one_hot, dim=1), dim=1, repeats=num_frames)
+        g = torch.reshape(g, (-1, gender_one_hot.shape[-1], 1))
+        out = {}
+        for gender in ["male", "female"]:
+            if pose2rot:  # what smplx.SMPL.forward does with axis-angle input before lbs
+                body = batch_rodrigues(poses_rs.reshape(-1, 3)).reshape(-1, 23, 3, 3)
+                glob = batch_rodrigues(root_rs.reshape(-1, 3)).reshape(-1, 1, 3, 3)
+            else:
+                body = poses.reshape(-1, 23, 3, 3)
+                glob = root_orient.reshape(-1, 1, 3, 3)
+            out[gender] = self.smpls[gender](body_pose=body, betas=betas_rs, global_orient=glob, transl=trans_rs)
+        joints = out["male"].joints[:, :24] * g[:, [0], :] + out["female"].joints[:, :24] * g[:, [1], :]
+        vertices = out["male"].vertices * g[:, [0], :] + out["female"].vertices * g[:, [1], :]
+        output = {"joints": torch.reshape(joints, (batch_size, num_frames, 24, 3)),
+                  "vertices": torch.reshape(vertices, (batch_size, num_frames, 6890, 3))}
+        if compute_part_labels:
+            lab = self.smpls["male"].lbs_weights * g[[0], [0], :] + self.smpls["female"].lbs_weights * g[[0], [1], :]
+            output["vertex_part_labels"] = torch.repeat_interleave(torch.unsqueeze(lab, 0), repeats=batch_size, dim=0)
+        return output

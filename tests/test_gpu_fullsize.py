@@ -301,7 +301,9 @@ def test_workspaces_are_evicted_and_memory_returns(tables, dev):
     from uuo_mocap_amd.engine import _FitHandle
 
     assert _FitHandle.live - live_start == s2.device_model.cached_workspaces(), "evicted workspaces must be destroyed"
-    assert used[4] <= used[2] + (320 << 20), used
+    # what stays allocated scales with the CURRENT sequence length (workspaces and the part stage's batch are F-proportional),
+    # not with the number of lengths seen: F grew 1.5x from the third to the fifth sequence
+    assert used[4] <= 1.5 * 1.3 * used[2], used
     s2.device_model.close()
     del s2
     assert _FitHandle.live == live_start

@@ -1545,3 +1545,46 @@ def test_batch_runner_on_a_reference_style_dataset_tree(smpl, dev, tmp_path):
     # a sequence without its 4D-Humans result is skipped like in the reference
     ingest.write_c3d(str(root / ds / "mocap" / subj / "orphan.c3d"), pts, rate=30.0, units="mm")
     assert runner.run(args) == 0
+
+
+@pytest.mark.gpu
+def test_gendered_blended_smpl_matches_oracle(dev):
+    """SmplInferenceGender (reference utils/smpl.py:56-131; BASELINE configs[4] "mixed male/female SMPL"): a male and a
+    female model blended by gender_one_hot, axis-angle and rotation-matrix inputs, N = 2 sequences (which exposes the
+    reference's frame-major betas repeat), soft genders, part labels; differentiable through the HIP forward."""
+    from oracle.smpl_ref import SmplInferenceGenderRef
+    from uuo_mocap_amd.body_model import synthetic_smpl
+    from uuo_mocap_amd.smpl import SmplInferenceGender
+
+    male, female = synthetic_smpl(1), synthetic_smpl(2)
+    assert male.checksum() != female.checksum()
+    ours = SmplInferenceGender(dev, tables=(male, female))
+    ref = SmplInferenceGenderRef(male, female)
+    g = torch.Generator().manual_seed(9)
+    N, F = 2, 5
+    poses = 0.4 * torch.randn(N, F, 69, generator=g)
+    root = 0.8 * torch.randn(N, F, 3, generator=g)
+    poses[0, 0] = 0.0   # zero rotation: the +1e-8 guard of batch_rodrigues
+    betas = torch.randn(N, 10, generator=g)
+    trans = torch.randn(N, F, 3, generator=g)
+    gender = torch.tensor([[1.0, 0.0], [0.3, 0.7]])
+    r = ref(poses, betas, root, trans, gender, pose2rot=True, compute_part_labels=True)
+    o = ours(poses.to(dev), betas.to(dev), root.to(dev), trans.to(dev), gender.to(dev), pose2rot=True, compute_part_labels=True)
+    assert o["vertices"].shape == (N, F, 6890, 3) and o["joints"].shape == (N, F, 24, 3)
+    np.testing.assert_allclose(o["vertices"].cpu().numpy(), r["vertices"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(o["joints"].cpu().numpy(), r["joints"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(o["vertex_part_labels"].cpu().numpy(), r["vertex_part_labels"].numpy(), atol=1e-6)
+    # rotation-matrix inputs (pose2rot False)
+    pm = p3d_ref.rotation_6d_to_matrix(torch.randn(N, F, 23, 6, generator=g))
+    rm = p3d_ref.rotation_6d_to_matrix(torch.randn(N, F, 6, generator=g))
+    r2 = ref(pm, betas, rm, trans, gender, pose2rot=False)
+    o2 = ours(pm.to(dev), betas.to(dev), rm.to(dev), trans.to(dev), gender.to(dev), pose2rot=False)
+    np.testing.assert_allclose(o2["vertices"].cpu().numpy(), r2["vertices"].numpy(), atol=1e-4)
+    # gradients flow to the shape through both models
+    b = betas.to(dev).requires_grad_(True)
+    (ours(pm.to(dev), b, rm.to(dev), trans.to(dev), gender.to(dev), pose2rot=False)["vertices"] ** 2).sum().backward()
+    bb = betas.clone().requires_grad_(True)
+    (ref(pm, bb, rm, trans, gender, pose2rot=False)["vertices"] ** 2).sum().backward()
+    np.testing.assert_allclose(b.grad.cpu().numpy(), bb.grad.numpy(), rtol=2e-3, atol=1e-2)
+    with pytest.raises(ValueError, match="10 beta"):
+        ours(pm.to(dev), torch.zeros(N, 9, device=dev), rm.to(dev), trans.to(dev), gender.to(dev), pose2rot=False)

@@ -1,1 +1,1 @@
-from uuo_mocap_amd.smpl import SmplInference  # noqa: F401
+from uuo_mocap_amd.smpl import SmplInference, SmplInferenceGender  # noqa: F401

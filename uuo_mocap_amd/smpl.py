@@ -72,3 +72,63 @@ class SmplInference(nn.Module):
 
     def get_lbs_weights(self):
         return self.smpl.lbs_weights
+
+
+def batch_rodrigues(rot_vecs: torch.Tensor) -> torch.Tensor:
+    """smplx.lbs.batch_rodrigues (what smplx applies to axis-angle inputs when pose2rot=True): [N,3] -> [N,3,3] with
+    angle = |r + 1e-8|, R = I + sin(angle) K + (1 - cos(angle)) K^2."""
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos = torch.unsqueeze(torch.cos(angle), dim=1)
+    sin = torch.unsqueeze(torch.sin(angle), dim=1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros_like(rx)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(-1, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device).unsqueeze(dim=0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+class SmplInferenceGender(nn.Module):
+    """reference src/video_mocap/utils/smpl.py:56-131: a male and a female SMPL evaluated on the same parameters and
+    blended by `gender_one_hot` [N,2] (soft genders allowed: the blend is linear in the two outputs).  Used by the
+    reference's dataset / synthetic-marker tooling, not by the fit itself; BASELINE configs[4] names
+    "mixed male/female SMPL".  Both models live on the GPU (two uuo_model_t table sets); every forward is the HIP path
+    of SmplInference, differentiable the same way.  `tables` = (male, female) SmplTables; by default the licensed
+    ./body_models/smpl/SMPL_{MALE,FEMALE}.pkl, else two synthetic SMPL-shaped models."""
+
+    def __init__(self, device=torch.device("cpu"), tables=None):
+        super().__init__()
+        self.body_model_path = "./body_models/"
+        self.device = torch.device(device)
+        if tables is None:
+            tables = (load_model(self.body_model_path, "male"), load_model(self.body_model_path, "female"))
+        self.smpls = {"male": SmplInference(self.device, "male", tables=tables[0]),
+                      "female": SmplInference(self.device, "female", tables=tables[1])}
+
+    def forward(self, poses, betas, root_orient, trans, gender_one_hot, pose2rot: bool = True,
+                compute_part_labels: bool = False) -> Dict:
+        if betas.shape[1] != 10:
+            raise ValueError("Betas array must have 10 beta values")
+        if len(gender_one_hot.shape) != 2:
+            raise ValueError("Gender one-hot vector must have 2 dimensions")
+        batch_size, num_frames, _ = trans.shape
+        if pose2rot:  # axis-angle [N,F,69] / [N,F,3]
+            pose_m = batch_rodrigues(poses.reshape(-1, 3)).reshape(-1, 23, 3, 3)
+            root_m = batch_rodrigues(root_orient.reshape(-1, 3)).reshape(-1, 1, 3, 3)
+        else:         # rotation matrices [N,F,23,3,3] / [N,F,3,3]
+            pose_m = poses.reshape(-1, 23, 3, 3)
+            root_m = root_orient.reshape(-1, 1, 3, 3)
+        trans_rs = trans.reshape(-1, 3)
+        # the reference repeats betas FRAME-major ([F,N,10] flattened) although poses are sequence-major ([N,F,...]):
+        # rows agree only for N = 1; reproduced as written (smpl.py:100-101)
+        betas_rs = torch.repeat_interleave(torch.unsqueeze(betas, dim=0), dim=0, repeats=num_frames).reshape(-1, betas.shape[-1])
+        g = torch.repeat_interleave(torch.unsqueeze(gender_one_hot, dim=1), dim=1, repeats=num_frames).reshape(-1, 2, 1)
+        out = {k: m(pose_m, betas_rs, root_m, trans_rs) for k, m in self.smpls.items()}
+        joints = out["male"]["joints"][:, :24] * g[:, [0], :] + out["female"]["joints"][:, :24] * g[:, [1], :]
+        vertices = out["male"]["vertices"] * g[:, [0], :] + out["female"]["vertices"] * g[:, [1], :]
+        output = {"joints": joints.reshape(batch_size, num_frames, 24, 3),
+                  "vertices": vertices.reshape(batch_size, num_frames, -1, 3)}
+        if compute_part_labels:
+            labels = self.smpls["male"].smpl.lbs_weights * g[[0], [0], :] + self.smpls["female"].smpl.lbs_weights * g[[0], [1], :]
+            output["vertex_part_labels"] = torch.repeat_interleave(torch.unsqueeze(labels, 0), repeats=batch_size, dim=0)
+        return output
