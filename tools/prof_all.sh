@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/p_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_bench -- python3 $R/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-other-configs > $R/gpurun_out/p_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_closure -- python3 $R/tools/profile_closure.py --solve-iters 300 > $R/gpurun_out/p_closure.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_pmc1 -- python3 $R/tools/profile_closure.py --evals 10 > $R/gpurun_out/p_pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_pmc2 -- python3 $R/tools/profile_closure.py --evals 10 > $R/gpurun_out/p_pmc2.log 2>&1

@@ -20,7 +20,12 @@ ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--markers", type=int, default=50)
 ap.add_argument("--evals", type=int, default=50)
 ap.add_argument("--solve-iters", type=int, default=0)
+ap.add_argument("--lib", default=None, help="alternative build of the library (kernel tuning experiments)")
 args = ap.parse_args()
+if args.lib:
+    from uuo_mocap_amd import _lib as _l
+
+    _l.LIB_PATH = os.path.abspath(args.lib)
 
 dev = torch.device("cuda:0")
 tables = synthetic_smpl(0)
