@@ -258,7 +258,7 @@ def test_end_to_end_config0_against_the_reference_fit(smpl, oracle_smpl, golden,
         record_property("config0_" + k, v)
     print("config0: bodies %.2e m apart; error vs ground truth ref %.2e ours %.2e m; final marker loss ref %.3e ours %.3e"
           % (between, err_ref, err_our, ref_final, our_final))
-    assert between < 2e-2, between                 # two converged fits of the same inputs
+    assert between < 2e-3, between                 # two converged fits of the same inputs (observed: 0.14 mm)
     assert err_our < max(1.25 * err_ref, err_ref + 2e-3), (err_our, err_ref)   # no worse than the reference's own fit
     assert our_final < max(2.0 * ref_final, 5e-5), (our_final, ref_final)
 
