@@ -217,6 +217,53 @@ def test_chamfer_closure_matches_oracle_and_golden(smpl, oracle_smpl, golden, de
     assert flips == 0, "%d of %d assignments differ (near-ties from the MFMA vertex path)" % (flips, i_ref.size)
 
 
+@pytest.mark.parametrize("F,M,parts", [(37, 10, (16, 18, 20)), (300, 16, (0, 1, 2, 4, 5)), (9, 1, (15,))])
+def test_fused_part_forward_is_bit_identical_to_skinning_then_searching(smpl, dev, F, M, parts):
+    """k_part_fwd (vertices of the candidate in registers, nearest-vertex search in the same kernel) against the
+    two-kernel path it replaces in closure evaluations (k_skin_cached writes the vertices, k_nn_fewq searches them):
+    loss, gradient and assignment of the same part-stage closure, bit for bit, at two points of one problem."""
+    import ctypes
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd.engine import PartProblem, _ptr, current_stream
+
+    dbg = _lib.load_debug()
+    seq = make_sequence(smpl.tables, seed=5, num_frames=F, num_markers=M)
+    cfg = packaged_config("hmr_part")
+    markers = _t(np.nan_to_num(seq.markers.get_points()), dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    vertex_labels = torch.argmax(torch.as_tensor(smpl.tables.lbs_weights), dim=-1)
+    vidx = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in parts]).to(dev)
+    prob = PartProblem(smpl, markers, seq.img_smpl.pose_body.to(dev), o_betas, seq.img_smpl.root_orient.to(dev), vidx, cfg)
+    gen = torch.Generator().manual_seed(F)
+    for k in range(2):
+        x = prob.pack(torch.full((1, 1, 1), 0.3 - 0.7 * k, device=dev),
+                      torch.median(markers, dim=1)[0] + 0.02 * torch.randn(F, 3, generator=gen).to(dev),
+                      o_betas + 0.3 * torch.randn(1, 10, generator=gen).to(dev))
+        got = []
+        for unfused in ("0", "1"):
+            os.environ["UUO_PART_UNFUSED"] = unfused
+            try:
+                loss = torch.empty(1, device=dev)
+                grad = torch.empty(prob.n, device=dev)
+                nn = torch.full((F, M), -1, dtype=torch.int32, device=dev)
+                rc = dbg.uuo_closure_eval(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), _ptr(loss),
+                                          _ptr(grad), _ptr(nn))
+                assert rc == 0, dbg.uuo_last_error()
+                torch.cuda.synchronize()
+                got.append((loss.cpu().numpy(), grad.cpu().numpy(), nn.cpu().numpy()))
+            finally:
+                os.environ.pop("UUO_PART_UNFUSED", None)
+        assert np.isfinite(got[0][0]).all() and got[0][2].min() >= 0 and got[0][2].max() < vidx.numel()
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a, b)
+        # and the product library (no knob: always the fused kernel) agrees with both
+        loss_p, grad_p, nn_p = prob.evaluate(x)
+        assert np.float32(loss_p) == got[0][0][0] and np.array_equal(grad_p.cpu().numpy(), got[0][1])
+        assert np.array_equal(nn_p.cpu().numpy(), got[0][2])
+
+
 def test_marker_closure_matches_oracle_and_golden(smpl, oracle_smpl, golden, dev):
     from uuo_mocap_amd.engine import MarkerProblem
 

@@ -906,7 +906,7 @@ static int validate_problem(const uuo_fit* fit, const uuo_problem_t* p) {
   if (p->stage != UUO_STAGE_MARKER) UUO_REQUIRE(p->d_root != nullptr, "closure: fixed root orientation required");
   if (p->stage == UUO_STAGE_MARKER) UUO_REQUIRE(p->d_assign != nullptr, "closure: marker stage needs d_assign");
   if (p->stage == UUO_STAGE_PART)
-    UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0, "closure: part stage needs a vertex subset");
+    UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0 && p->n_subset <= fit->model->V, "closure: part stage needs a vertex subset");
   return 0;
 }
 
@@ -947,7 +947,9 @@ static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay,
 }
 
 // forward half shared by uuo_closure_eval and uuo_time_closure
-static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src) {
+// `need_verts`: the caller reads fit->verts afterwards (candidate scores); a closure evaluation does not (the backward
+// kernel re-skins the winners), which lets the part stage keep its vertices in registers (k_part_fwd)
+static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src, bool need_verts) {
   if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
   const uuo_model* m = fit->model;
   int rc = 0;
@@ -970,6 +972,14 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
     if (rc) return rc;
     fit->pose_cache_id = p->pose_cache_id;
   }
+  const int unfused = UUO_ENV_INT("UUO_PART_UNFUSED", 0);  // debug flavour only: the two-kernel path, for comparison
+  const bool fused = cached && !need_verts && !unfused && p->M >= 1 && p->M <= 16;
+  if (fused) {
+    rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames, p->d_subset, p->n_subset, fit->part_sb);
+    if (rc) return rc;
+    return uuo_launch_part_fwd(m, s, p->F, p->M, fit->pose_cache, fit->part_sb, fit->A, src.trans, p->d_subset, p->n_subset,
+                               p->d_markers, fit->nn);
+  }
   rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
   if (rc) return rc;
   if (cached) {
@@ -991,7 +1001,7 @@ int uuo_validate_problem(const uuo_fit* fit, const uuo_problem_t* p) { return va
 int uuo_closure_forward_at(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {
   const StageLayout lay = stage_layout(p->stage, p->F);
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
-  return closure_forward(fit, s, p, src);
+  return closure_forward(fit, s, p, src, true);
 }
 
 // Ranking score of part-stage candidates (reference markers/markers_utils.py:575-579: pytorch3d chamfer_distance, both
@@ -1080,7 +1090,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const int F = p->F, M = p->M;
   const StageLayout lay = stage_layout(p->stage, F);
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
-  rc = closure_forward(fit, s, p, src);
+  rc = closure_forward(fit, s, p, src, false);
   if (rc) return rc;
   if (d_nn_idx && p->stage != UUO_STAGE_MARKER) {
     rc = uuo_launch_nn_unpack(s, F * M, fit->nn, nullptr, d_nn_idx);
@@ -1178,7 +1188,7 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   if (rc) return rc;
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
   // warm-up
-  rc = dominant_only ? closure_forward(fit, s, p, src) : uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr, nullptr, nullptr);
+  rc = dominant_only ? closure_forward(fit, s, p, src, false) : uuo_closure_eval_impl(fit, s, p, d_x, loss, grad, nullptr, nullptr, nullptr);
   if (rc) return rc;
   if (dominant_only) {
     // the dominant kernel alone, one event pair per launch on the launch stream: the average is the kernel's own

@@ -151,6 +151,177 @@ __global__ __launch_bounds__(256) void k_nn_fewq_b(const NnArgs* __restrict__ ba
   nn_fewq_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out);
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Part stage (constant body pose, P1 <= 16 markers per frame): skinning of the candidate's vertices fused with the
+// nearest-vertex search.  The vertex positions only exist in registers:
+//   v = T_f(v) (C[f][v] + SB[v]) + trans_f,   T_f(v) = sum_n w_n A_f[j_n]        (skin_cached_body's arithmetic)
+// with C the cached template + pose-corrective blend of the frame; S[v] . beta, the joints and the weights of the vertex
+// come packed in subset order from k_pose_prep's tail (coalesced loads instead of three gathers per vertex); each
+// lane keeps the (distance, candidate) minimum of every marker over its vertices, the wave merges them into the packed
+// keys k_nn_fewq would write (same order, same tie rule).  The backward kernel re-skins the winners itself, so nothing but the P1 keys
+// per frame is written: 12 B of C per vertex and frame instead of 12 B read + 12 B written + 12 B read again.
+// One wave per (candidate, frame) - the kernel is bound by instruction issue, and the per-frame work that does not scale
+// with the vertices (staging, 2 * P1 cross-lane minima) is paid once per wave; consecutive blocks of an XCD walk the candidates of ONE frame, so the frame's slice
+// of C (82 KB, shared by all candidates of a lock-step batch) is fetched into that XCD's L2 once.
+// ----------------------------------------------------------------------------------------------------
+struct PartFwdArgs {
+  UuoGridHdr h;  // gx = F
+  int F, V, ns, P1;
+  const int32_t* subset;
+  const float* C;
+  const float* SB;  // [ns][8]: shape offset | packed joints | weights (k_pose_prep's tail)
+  const float* A;
+  const float* trans;
+  const float* x;
+  unsigned long long* out;
+};
+// minimum over the wave's 64 lanes, uniform result: 4 DPP steps inside each row of 16 lanes, then the 4 row results
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
+  v = min(v, dpp_u32<0x140>(v));  // row_mirror: every lane of a row holds the row's minimum
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+#define PFW_U 4  // candidates per lane in flight (their loads are issued together)
+#define PFW_T 64  // one wave per (candidate, frame): one set of cross-lane minima per frame, no block-level merge
+// QB = the markers per frame (the running minima live in 2 * QB registers; one instantiation per count, no per-marker branch)
+template <int QB>
+__device__ __forceinline__ void part_fwd_body(const PartFwdArgs& a, int f) {
+  __shared__ __align__(16) float sA[UUO_NUM_JOINTS * 12];
+  const int tid = threadIdx.x;
+  constexpr int P1 = QB;
+  // the lane's first candidates: their vertex ids are on their way while the skinning matrices are staged
+  int cc[PFW_U], vv[PFW_U];
+#pragma unroll
+  for (int u = 0; u < PFW_U; ++u) {
+    cc[u] = tid + PFW_T * u;
+    vv[u] = cc[u] < a.ns ? a.subset[cc[u]] : -1;
+  }
+  {
+    const float4* Af = reinterpret_cast<const float4*>(a.A + (size_t)f * UUO_NUM_JOINTS * 12);
+    for (int i = tid; i < UUO_NUM_JOINTS * 3; i += PFW_T) reinterpret_cast<float4*>(sA)[i] = Af[i];
+  }
+  // the frame's markers and translation are block-uniform: they live in SGPRs
+  float sq[QB * 3], sTr[3];
+  const float* xq = a.x + (size_t)f * P1 * 3;
+#pragma unroll
+  for (int i = 0; i < QB * 3; ++i)
+    sq[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xq[i])));
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    sTr[i] = a.trans ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.trans[(size_t)f * 3 + i]))) : 0.f;
+  // the distance bits of a (non-negative) squared distance order as unsigned exactly as the packed key does; a lane sees
+  // its candidates in ascending order, so strict '<' keeps the first index on ties, as the packed comparison would
+  unsigned bd[QB], bi[QB];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) bd[q] = bi[q] = 0xFFFFFFFFu;
+  const float* Cf = a.C + (size_t)f * a.V * 3;
+  const float4* SB4 = reinterpret_cast<const float4*>(a.SB);
+  __syncthreads();
+  for (int c0 = tid; c0 < a.ns; c0 += PFW_T * PFW_U) {
+    bool ok[PFW_U];
+    float p[PFW_U][3];
+    unsigned pj[PFW_U];
+    float4 ww[PFW_U];
+#pragma unroll
+    for (int u = 0; u < PFW_U; ++u) {
+      ok[u] = (unsigned)vv[u] < (unsigned)a.V;  // (-1 past the end of the subset)
+      const unsigned v = ok[u] ? (unsigned)vv[u] : 0u, c = ok[u] ? (unsigned)cc[u] : 0u;
+      const float* pc = Cf + v * 3u;
+      const float4 k0 = SB4[c * 2u];
+      ww[u] = SB4[c * 2u + 1u];
+      p[u][0] = pc[0] + k0.x;
+      p[u][1] = pc[1] + k0.y;
+      p[u][2] = pc[2] + k0.z;
+      pj[u] = __float_as_uint(k0.w);
+    }
+    int cn[PFW_U], vn[PFW_U];  // the next round's vertex ids
+#pragma unroll
+    for (int u = 0; u < PFW_U; ++u) {
+      cn[u] = cc[u] + PFW_T * PFW_U;
+      vn[u] = cn[u] < a.ns ? a.subset[cn[u]] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < PFW_U; ++u) {
+      const float wv[4] = {ww[u].x, ww[u].y, ww[u].z, ww[u].w};
+      float T[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        // byte n of pj = 3 * joint: the row's float4 index (an unused slot is joint 0 with weight 0: adds exact zeros)
+        const float4* pa = reinterpret_cast<const float4*>(sA) + ((pj[u] >> (8 * n)) & 0xFFu);
+        const float4 r0 = pa[0], r1 = pa[1], r2 = pa[2];
+        const float ar[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(wv[n], ar[e], T[e]);
+      }
+      const float px = p[u][0], py = p[u][1], pz = p[u][2];
+      const float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3] + sTr[0];
+      const float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7] + sTr[1];
+      const float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11] + sTr[2];
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const unsigned d = __float_as_uint(sqdist(sq[q * 3], sq[q * 3 + 1], sq[q * 3 + 2], ox, oy, oz));
+        const bool better = ok[u] && d < bd[q];
+        bd[q] = better ? d : bd[q];
+        bi[q] = better ? (unsigned)cc[u] : bi[q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PFW_U; ++u) {
+      cc[u] = cn[u];
+      vv[u] = vn[u];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    const unsigned dmin = wave_min_u32(bd[q]);
+    const unsigned imin = wave_min_u32(bd[q] == dmin ? bi[q] : 0xFFFFFFFFu);
+    if (tid == 0) a.out[(size_t)f * P1 + q] = ((unsigned long long)dmin << 32) | (unsigned long long)imin;
+  }
+}
+// block id -> (candidate, frame): the 8 XCDs take blocks round-robin; block b of XCD (b & 7) works on frame
+// 8 * ((b >> 3) / count) + (b & 7) of candidate (b >> 3) % count
+template <int QB>
+__global__ __launch_bounds__(PFW_T) void k_part_fwd(PartFwdArgs a) {
+  const int f = (int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7);
+  if (f >= a.F) return;
+  part_fwd_body<QB>(a, f);
+}
+template <int QB>
+__global__ __launch_bounds__(PFW_T) void k_part_fwd_b(const PartFwdArgs* __restrict__ batch, int count) {
+  const int r = (int)(blockIdx.x >> 3);
+  const PartFwdArgs a = batch[r % count];
+  const int f = (r / count) * 8 + (int)(blockIdx.x & 7);
+  if (f >= a.F) return;
+  part_fwd_body<QB>(a, f);
+}
+
+int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
+                        const float* trans, const int32_t* subset, int n_subset, const float* markers,
+                        unsigned long long* packed) {
+  UUO_REQUIRE(m->nnz <= 4 && P1 >= 1 && P1 <= NNQ_MAX && subset && n_subset > 0 && F > 0, "uuo_launch_part_fwd: bad arguments");
+  PartFwdArgs a{{F, P1}, F, m->V, n_subset, P1, subset, cache, sb, A, trans, markers, packed};
+  if (uuo_record(UUO_OP_PART_FWD, F, P1, a)) return 0;  // P1 rides in the record's gy
+  const dim3 grid(8 * ((F + 7) / 8));
+  switch (P1) {
+#define PFW_CASE(Q) case Q: hipLaunchKernelGGL(k_part_fwd<Q>, grid, dim3(PFW_T), 0, s, a); break;
+    PFW_CASE(1) PFW_CASE(2) PFW_CASE(3) PFW_CASE(4) PFW_CASE(5) PFW_CASE(6) PFW_CASE(7) PFW_CASE(8)
+    PFW_CASE(9) PFW_CASE(10) PFW_CASE(11) PFW_CASE(12) PFW_CASE(13) PFW_CASE(14) PFW_CASE(15) PFW_CASE(16)
+#undef PFW_CASE
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 static int fill_keys(hipStream_t s, unsigned long long* packed, size_t count) {
   FillArgs f{{(int)((count + 255) / 256), 1}, packed, (int)count};
   if (uuo_record(UUO_OP_FILL, f.h.gx, 1, f)) return 0;
@@ -379,6 +550,16 @@ int uuo_batched_launch_nn(int op, hipStream_t s, const void* d_args, int count, 
     hipLaunchKernelGGL(k_nn_fewq_b, dim3(gx, gy, count), dim3(256), 0, s, (const NnArgs*)d_args);
   } else if (op == UUO_OP_NN_CULL) {
     hipLaunchKernelGGL(k_nn_cull_b, dim3(gx, gy, count), dim3(CULL_T), 0, s, (const NnCullArgs*)d_args);
+  } else if (op == UUO_OP_PART_FWD) {  // gx = frames of the longest problem, gy = markers per frame (one value per batch)
+    const dim3 grid(8 * ((gx + 7) / 8) * count);
+    const PartFwdArgs* pa = (const PartFwdArgs*)d_args;
+    switch (gy) {
+#define PFW_CASE(Q) case Q: hipLaunchKernelGGL(k_part_fwd_b<Q>, grid, dim3(PFW_T), 0, s, pa, count); break;
+      PFW_CASE(1) PFW_CASE(2) PFW_CASE(3) PFW_CASE(4) PFW_CASE(5) PFW_CASE(6) PFW_CASE(7) PFW_CASE(8)
+      PFW_CASE(9) PFW_CASE(10) PFW_CASE(11) PFW_CASE(12) PFW_CASE(13) PFW_CASE(14) PFW_CASE(15) PFW_CASE(16)
+#undef PFW_CASE
+      default: UUO_REQUIRE(false, "batched k_part_fwd: markers per frame out of range");
+    }
   } else {
     return 1;
   }

@@ -12,7 +12,11 @@
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoTree* __restrict__ tree, int F,
                                                float* __restrict__ pfaT, float* __restrict__ A,
-                                               float* __restrict__ jposed, float* __restrict__ frames) {
+                                               float* __restrict__ jposed, float* __restrict__ frames,
+                                               const float* __restrict__ ST = nullptr, const int* __restrict__ Wi = nullptr,
+                                               const float* __restrict__ Ww = nullptr, int V = 0,
+                                               const int32_t* __restrict__ subset = nullptr, int ns = 0,
+                                               float* __restrict__ sb_out = nullptr) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   const int f = blockIdx.x;
@@ -45,6 +49,41 @@ __device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoT
         jposed[((size_t)f * UUO_NUM_JOINTS + l) * 3 + c] = L.Gt[l][c] + (src.trans ? src.trans[(size_t)f * 3 + c] : 0.f);
     }
   }
+  if (sb_out) {
+    // part stage: per vertex of the candidate, what k_part_fwd needs at every frame, packed in subset order so that its
+    // loads are coalesced: [S[v] . beta (3 floats, one beta for all frames; accumulation order of skin_cached_body) |
+    // the 4 skinning joints, 3 * joint per byte] [the 4 skin weights].  A slice of the subset per frame block.
+    const int per = (ns + F - 1) / F, c0 = f * per;
+    for (int i = l; i < per; i += 64) {
+      const int c = c0 + i;
+      if (c >= ns) break;
+      const int v = subset[c];
+      float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)v < (unsigned)V) {
+        float sb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp)
+#pragma unroll
+          for (int k = 0; k < 10; ++k) sb[comp] = fmaf(ST[(size_t)v * 30 + comp * 10 + k], src.betas[k], sb[comp]);
+        const int4 wi = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
+        o1 = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
+        // byte n = 3 * joint n (the float4 index of its skinning matrix); an unused slot becomes joint 0 with weight 0,
+        // which adds exact zeros to the blend
+        const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
+        float wv[4] = {o1.x, o1.y, o1.z, o1.w};
+        unsigned pj = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (wj[n] < 0) wv[n] = 0.f;
+          else pj |= (unsigned)(wj[n] * 3) << (8 * n);
+        }
+        o1 = make_float4(wv[0], wv[1], wv[2], wv[3]);
+        o0 = make_float4(sb[0], sb[1], sb[2], __uint_as_float(pj));
+      }
+      reinterpret_cast<float4*>(sb_out)[(size_t)c * 2] = o0;
+      reinterpret_cast<float4*>(sb_out)[(size_t)c * 2 + 1] = o1;
+    }
+  }
 }
 
 struct PosePrepArgs {
@@ -56,18 +95,25 @@ struct PosePrepArgs {
   float* A;
   float* jposed;
   float* frames;
+  const float* ST;        // part stage (k_part_fwd follows): shape blend and skin weight tables, the candidate's vertices,
+  const int* Wi;          // their count and the [ns][8] buffer that takes their per-vertex constants; null / 0 otherwise
+  const float* Ww;
+  int V;
+  const int32_t* subset;
+  int ns;
+  float* sb_out;
 };
 __global__ __launch_bounds__(64) void k_pose_prep(PosePrepArgs a) {
-  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames);
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out);
 }
 __global__ __launch_bounds__(64) void k_pose_prep_b(const PosePrepArgs* __restrict__ batch) {
   UUO_BATCH_PICK(PosePrepArgs, batch)
-  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames);
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out);
 }
 
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
-                         float* jposed, float* frames) {
-  PosePrepArgs a{{F, 1}, src, m->tree, F, pfaT, A, jposed, frames};
+                         float* jposed, float* frames, const int32_t* sb_subset, int sb_ns, float* sb_out) {
+  PosePrepArgs a{{F, 1}, src, m->tree, F, pfaT, A, jposed, frames, sb_out ? m->ST : nullptr, m->Wi, m->Ww, m->V, sb_subset, sb_ns, sb_out};
   if (uuo_record(UUO_OP_POSE_PREP, F, 1, a)) return 0;
   hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());

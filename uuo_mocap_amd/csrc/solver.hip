@@ -1844,6 +1844,7 @@ static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bo
   A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
   A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
+  A((void**)&fit->part_sb, (size_t)model->V * 8 * sizeof(float));
   A((void**)&fit->bbox, (size_t)F * ((model->V + 15) / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));
@@ -1866,7 +1867,7 @@ static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bo
 
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
-  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs,
+  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->part_sb, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs,
                   fit->shared_pose_cache ? nullptr : fit->pose_cache, fit->zeros16};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1949,7 +1950,7 @@ struct uuo_batch {
   size_t blob_cap = 0;
   int lb_n = 0, lb_hist = 0;
   size_t blob_used = 0;        // bytes of the blob the last flush staged
-  bool blob_pending = false;   // that flush's host-to-device copy may not have executed yet (no sync point passed since)
+  bool blob_pending[2] = {false, false};  // per blob half: that flush's host-to-device copy may not have executed yet
   double* d_scores = nullptr;  // uuo_batch_part_scores: [nb][F][2] per-frame sums
   double* h_scores = nullptr;
   size_t score_cap = 0;
@@ -2011,7 +2012,7 @@ extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int
       }
     }
   }
-  b->blob_cap = (size_t)B * 12 * UUO_OP_ARG_MAX + 4096;
+  b->blob_cap = 2 * ((size_t)B * 12 * UUO_OP_ARG_MAX + 4096);  // two halves: one per stepping group
   if (rc == 0 && hipHostMalloc((void**)&b->h_blob, b->blob_cap, hipHostMallocDefault) != hipSuccess) rc = -12;
   if (rc == 0 && hipMalloc((void**)&b->d_blob, b->blob_cap) != hipSuccess) rc = -12;
   if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -5;  // the workspaces' zero fills ran on the null stream
@@ -2025,13 +2026,14 @@ extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int
 }
 
 // one round's recorded launches of all problems, merged by kind
-static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, int nb) {
+// `i0 .. i1` = the problems of one stepping group, `region` = which half of the staging blob the group owns
+static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, int i0, int i1, int region) {
   // validate the per-problem order and count bytes
   size_t off[UUO_OP_COUNT], cnt[UUO_OP_COUNT], width[UUO_OP_COUNT];
   int gx[UUO_OP_COUNT], gy[UUO_OP_COUNT];
   for (int k = 0; k < UUO_OP_COUNT; ++k) off[k] = cnt[k] = width[k] = 0, gx[k] = gy[k] = 0;
   bool any = false;
-  for (int i = 0; i < nb; ++i) {
+  for (int i = i0; i < i1; ++i) {
     int last = -1;
     for (const UuoOpRec& r : cos[i].rec.ops) {
       UUO_REQUIRE(r.op >= last && (r.op > last || r.op == UUO_OP_COPY), "batch: a problem recorded its launches out of the canonical order");
@@ -2051,28 +2053,34 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
     off[k] = total;
     total += (cnt[k] * width[k] + 255) / 256 * 256;
   }
-  UUO_REQUIRE(total <= b->blob_cap, "batch: argument staging buffer too small");
+  const size_t region_cap = b->blob_cap / 2, region_off = (size_t)region * region_cap;
+  unsigned char* h_blob = b->h_blob + region_off;
+  unsigned char* d_blob = b->d_blob + region_off;
+  UUO_REQUIRE(total <= region_cap, "batch: argument staging buffer too small");
   // A flush overwrites the pinned blob from its start, so the previous flush's (asynchronous) host-to-device copy must
   // have executed.  Inside a solve that is implied -- every round waits for its evaluations' reports, which follow the copy
   // on the stream -- and the flag is cleared there; a flush that follows another one with no such wait synchronises first.
-  if (b->blob_pending && total > 0) UUO_HIP_CHECK(hipStreamSynchronize(s));
+  if (b->blob_pending[region] && total > 0) {
+    UUO_HIP_CHECK(hipStreamSynchronize(s));
+    b->blob_pending[0] = b->blob_pending[1] = false;
+  }
   if (total > 0) {
-    b->blob_pending = true;
+    b->blob_pending[region] = true;
     b->blob_used = total;
   }
   size_t fill[UUO_OP_COUNT];
   for (int k = 0; k < UUO_OP_COUNT; ++k) fill[k] = 0;
-  for (int i = 0; i < nb; ++i)
+  for (int i = i0; i < i1; ++i)
     for (const UuoOpRec& r : cos[i].rec.ops) {
       if (r.op == UUO_OP_COPY || r.op == UUO_OP_SKIN) continue;
-      std::memcpy(b->h_blob + off[r.op] + fill[r.op] * width[r.op], r.args, r.nbytes);
+      std::memcpy(h_blob + off[r.op] + fill[r.op] * width[r.op], r.args, r.nbytes);
       fill[r.op] += 1;
     }
-  if (total) UUO_HIP_CHECK(hipMemcpyAsync(b->d_blob, b->h_blob, total, hipMemcpyHostToDevice, s));
+  if (total) UUO_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, total, hipMemcpyHostToDevice, s));
   for (int k = 0; k < UUO_OP_COUNT; ++k) {
     if (cnt[k] == 0) continue;
     if (k == UUO_OP_COPY) {
-      for (int i = 0; i < nb; ++i)
+      for (int i = i0; i < i1; ++i)
         for (const UuoOpRec& r : cos[i].rec.ops)
           if (r.op == UUO_OP_COPY) {
             const LbCopyArgs* c = reinterpret_cast<const LbCopyArgs*>(r.args);
@@ -2081,7 +2089,7 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
       continue;
     }
     if (k == UUO_OP_SKIN) {
-      for (int i = 0; i < nb; ++i)
+      for (int i = i0; i < i1; ++i)
         for (const UuoOpRec& r : cos[i].rec.ops)
           if (r.op == UUO_OP_SKIN) {
             const int rc = uuo_replay_skin_call(s, r.args);
@@ -2089,7 +2097,7 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
           }
       continue;
     }
-    const void* da = b->d_blob + off[k];
+    const void* da = d_blob + off[k];
     const int n_ = (int)cnt[k];
     int rc = 1;
     switch (k) {
@@ -2124,7 +2132,7 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
     if (rc) return rc;
     UUO_HIP_CHECK(hipGetLastError());
   }
-  for (int i = 0; i < nb; ++i) cos[i].rec.ops.clear();
+  for (int i = i0; i < i1; ++i) cos[i].rec.ops.clear();
   return 0;
 }
 
@@ -2200,11 +2208,14 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
   }
   const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
   g_batch_yield = batch_yield_impl;
-  int live = nb;
   int result = 0;
-  while (live > 0 && result == 0) {
-    // step every live problem to its next evaluation (or to its end)
-    for (int i = 0; i < nb; ++i) {
+  // Two stepping groups (halves of the batch) take turns on the one stream: while the kernels of one group's round run,
+  // the host steps the other group's coroutines and stages their launches, so the ~1 ms of host work per round of a
+  // 200-problem batch hides behind ~1.5 ms of kernels instead of adding to it.  Each group owns half of the staging blob.
+  const int ngroups = nb >= 8 ? 2 : 1;
+  const int gbeg[2] = {0, ngroups == 2 ? nb / 2 : nb}, gend[2] = {ngroups == 2 ? nb / 2 : nb, nb};
+  auto step_group = [&](int g) -> int {  // every live problem of the group to its next evaluation (or to its end)
+    for (int i = gbeg[g]; i < gend[g]; ++i) {
       BatchCo& c = cos[i];
       if (c.done) continue;
       c.waiting = false;
@@ -2213,19 +2224,15 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       swapcontext(&g_sched_ctx, &c.ctx);
       uuo_recorder = nullptr;
       g_cur_co = nullptr;
-      if (c.done) {
-        --live;
-        if (c.rc && result == 0) result = c.rc;
-      }
+      if (c.done && c.rc) return c.rc;
     }
-    if (result) break;
-    result = batch_flush(b, s, cos, nb);
-    if (result) break;
-    // wait for the reports of the problems that are in an evaluation
+    return batch_flush(b, s, cos, gbeg[g], gend[g], g);
+  };
+  auto wait_group = [&](int g) -> int {  // the reports of the group's problems that are in an evaluation
     bool waited_any = false;
     timespec t_start;
     clock_gettime(CLOCK_MONOTONIC, &t_start);
-    for (int i = 0; i < nb && result == 0; ++i) {
+    for (int i = gbeg[g]; i < gend[g]; ++i) {
       BatchCo& c = cos[i];
       if (c.done || !c.waiting) continue;
       waited_any = true;
@@ -2237,30 +2244,40 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
           const hipError_t q = hipStreamQuery(s);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
             uuo_set_error(std::string("batch: an evaluation did not report: ") + hipGetErrorString(q));
-            result = -5;
-            break;
+            return -5;
           }
           timespec t_now;
           clock_gettime(CLOCK_MONOTONIC, &t_now);
           const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
           if (waited > eval_timeout_s) {
             uuo_set_error("batch: a round of evaluations did not finish within " + std::to_string((int)eval_timeout_s) + " s");
-            result = -62;
-            break;
+            return -62;
           }
         }
       }
     }
-    if (waited_any && result == 0) b->blob_pending = false;  // a report arrived: everything enqueued before it has run
+    // a report of this group arrived: its flush's copy (enqueued before the kernels that reported) has executed
+    if (waited_any) b->blob_pending[g] = false;
+    return 0;
+  };
+  auto group_live = [&](int g) {
+    for (int i = gbeg[g]; i < gend[g]; ++i)
+      if (!cos[i].done) return true;
+    return false;
+  };
+  for (int g = 0; g < ngroups && result == 0; ++g) result = step_group(g);
+  while (result == 0 && (group_live(0) || (ngroups == 2 && group_live(1)))) {
+    for (int g = 0; g < ngroups && result == 0; ++g) {
+      if (!group_live(g)) continue;
+      result = wait_group(g);
+      if (result == 0) result = step_group(g);
+    }
   }
   g_batch_yield = nullptr;
   uuo_recorder = nullptr;
   if (result == 0) {
-    result = batch_flush(b, s, cos, nb);  // the final copies of problems that ended in the last round
-    if (result == 0) {
-      UUO_HIP_CHECK(hipStreamSynchronize(s));
-      b->blob_pending = false;
-    }
+    UUO_HIP_CHECK(hipStreamSynchronize(s));  // (problems that ended in the last round flushed their final copies there)
+    b->blob_pending[0] = b->blob_pending[1] = false;
   } else {
     (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
   }
@@ -2289,7 +2306,7 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
     uuo_recorder = nullptr;
   }
   if (rc) return rc;
-  rc = batch_flush(b, s, cos, nb);
+  rc = batch_flush(b, s, cos, 0, nb, 0);
   if (rc) return rc;
   const size_t out_doubles = (size_t)nb * F * 2;
   if (b->score_cap < out_doubles) {
@@ -2304,7 +2321,7 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
   // The forward's argument structs were staged in the first b->blob_used bytes of the pinned blob and their host-to-device
   // copy may not have executed yet (it is asynchronous): the score kernel's structs go BEHIND them, never over them.
   const size_t score_off = (b->blob_used + 255) / 256 * 256;
-  UUO_REQUIRE(score_off + (size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap, "uuo_batch_part_scores: staging buffer too small");
+  UUO_REQUIRE(score_off + (size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap / 2, "uuo_batch_part_scores: staging buffer too small");
   PartScoreArgs* ha = reinterpret_cast<PartScoreArgs*>(b->h_blob + score_off);
   for (int i = 0; i < nb; ++i) {
     PartScoreArgs a;
@@ -2327,7 +2344,7 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
   if (rc) return rc;
   UUO_HIP_CHECK(hipMemcpyAsync(b->h_scores, b->d_scores, out_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
   UUO_HIP_CHECK(hipStreamSynchronize(s));
-  b->blob_pending = false;
+  b->blob_pending[0] = b->blob_pending[1] = false;
   for (int i = 0; i < nb; ++i) {
     double cx = 0.0, cy = 0.0;
     const double* o = b->h_scores + (size_t)i * F * 2;

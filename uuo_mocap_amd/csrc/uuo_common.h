@@ -48,6 +48,21 @@ void uuo_set_error(const std::string& msg);
   } while (0)
 
 // the argument struct of every batched kernel (lock-step batches, below) starts with its own grid extent
+// A pointer read from an argument struct that itself lives in device memory (the lock-step kernels' `batch[...]`) would be
+// a generic pointer to the compiler: its loads become flat_load, which count on the LDS counter as well and so serialise
+// with the kernel's LDS traffic.  Everything this library hands to a kernel is global memory (device or pinned host), so
+// the pointer members of the argument structs say so in their type when compiled for the device (same size and layout
+// on the host, where they are plain pointers); uuo_p() gives the generic pointer where a callee wants one - after
+// inlining the compiler still knows where it came from and keeps the global_load.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define UUO_GLOBAL __attribute__((address_space(1)))
+#else
+#define UUO_GLOBAL
+#endif
+template <typename T>
+__host__ __device__ __forceinline__ T* uuo_p(UUO_GLOBAL T* p) {
+  return (T*)p;
+}
 struct UuoGridHdr {
   int gx, gy;
 };
@@ -120,6 +135,7 @@ struct uuo_fit {
   float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
   float* bbox = nullptr;            // [F][ceil(V/16)][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
+  float* part_sb = nullptr;         // [V][8] per-vertex constants of a part-stage candidate (k_pose_prep -> k_part_fwd)
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
@@ -140,7 +156,11 @@ struct uuo_fit {
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
-                         float* joints_posed, float* frames = nullptr);
+                         float* joints_posed, float* frames = nullptr, const int32_t* sb_subset = nullptr, int sb_ns = 0,
+                         float* sb_out = nullptr);
+int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
+                        const float* trans, const int32_t* subset, int n_subset, const float* markers,
+                        unsigned long long* packed);
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox);
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
@@ -207,6 +227,7 @@ enum {
   UUO_OP_POSE_PREP,
   UUO_OP_SKIN,             // k_skin / k_skin2: whole-GPU kernels, issued one problem after the other
   UUO_OP_SKIN_CACHED,
+  UUO_OP_PART_FWD,         // k_part_fwd: skinning of a candidate's vertices fused with the nearest-vertex search
   UUO_OP_FILL,             // hipMemsetAsync
   UUO_OP_NN,
   UUO_OP_NN_FEWQ,
