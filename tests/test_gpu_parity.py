@@ -258,6 +258,19 @@ def test_fused_part_forward_is_bit_identical_to_skinning_then_searching(smpl, de
         assert np.isfinite(got[0][0]).all() and got[0][2].min() >= 0 and got[0][2].max() < vidx.numel()
         for a, b in zip(got[0], got[1]):
             assert np.array_equal(a, b)
+        # the part-stage backward kernel (vertex from the cached blend, no pose-feature path) against the general one
+        os.environ["UUO_PART_GENERAL_BWD"] = "1"
+        try:
+            loss = torch.empty(1, device=dev)
+            grad = torch.empty(prob.n, device=dev)
+            rc = dbg.uuo_closure_eval(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), _ptr(loss),
+                                      _ptr(grad), None)
+            assert rc == 0, dbg.uuo_last_error()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("UUO_PART_GENERAL_BWD", None)
+        assert loss.cpu().numpy()[0] == got[0][0][0]
+        assert _rel_err(got[0][1], grad.cpu().numpy()) < 2e-6
         # and the product library (no knob: always the fused kernel) agrees with both
         loss_p, grad_p, nn_p = prob.evaluate(x)
         assert np.float32(loss_p) == got[0][0][0] and np.array_equal(grad_p.cpu().numpy(), got[0][1])

@@ -13,43 +13,44 @@
 struct BwdArgs {
   UuoGridHdr h;  // grid extent of this problem (lock-step batches: uuo_common.h)
   // model
-  const float* PT;
-  const float* ST;
-  const float* vt;
-  const float* Wd;
-  const int* Wi;
-  const float* Ww;
-  const UuoTree* tree;
+  uuo_gptr<const float> PT;
+  uuo_gptr<const float> ST;
+  uuo_gptr<const float> vt;
+  uuo_gptr<const float> Wd;
+  uuo_gptr<const int> Wi;
+  uuo_gptr<const float> Ww;
+  uuo_gptr<const UuoTree> tree;
   int V;
   // frame inputs
   UuoPoseSrc src;
   int stage, F, M;
   int stop;  // ablation only
-  const float* markers;
-  const float* mask;
-  const unsigned long long* nn;
-  const int* assign;
-  const int* subset;
-  const float* raw_pose;  // optimised raw body rotations (chamfer, marker) or null
-  const float* o_pose;    // prior target
-  const float* raw_root;  // marker stage: optimised raw root
+  uuo_gptr<const float> markers;
+  uuo_gptr<const float> mask;
+  uuo_gptr<const unsigned long long> nn;
+  uuo_gptr<const int> assign;
+  uuo_gptr<const int> subset;
+  uuo_gptr<const float> raw_pose;  // optimised raw body rotations (chamfer, marker) or null
+  uuo_gptr<const float> o_pose;    // prior target
+  uuo_gptr<const float> raw_root;  // marker stage: optimised raw root
   float cg;               // 2*w_data / normaliser
   float cpose;            // 2*w_pose / (F*207)
   float d0;
   // outputs
-  float* g_pose;
-  float* g_root;
-  float* g_z;
-  float* g_trans;
-  const float* dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
+  uuo_gptr<float> g_pose;
+  uuo_gptr<float> g_root;
+  uuo_gptr<float> g_z;
+  uuo_gptr<float> g_trans;
+  uuo_gptr<const float> dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
   int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat vector (-1 = absent)
-  const float* frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
+  uuo_gptr<const float> frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
+  uuo_gptr<const float> C;       // part stage (k_bwd_part): the cached template + pose-corrective blend [F][V][3]
   // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
   // (+ the 21 vertex-picked joints) with dL/dv given, instead of markers with a residual
-  const float* up_verts;   // [F][V][3] or null
-  const float* up_joints;  // [F][45][3] or null
-  float* g_betas_frame;    // [F][10]
-  float* frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
+  uuo_gptr<const float> up_verts;   // [F][V][3] or null
+  uuo_gptr<const float> up_joints;  // [F][45][3] or null
+  uuo_gptr<float> g_betas_frame;    // [F][10]
+  uuo_gptr<float> frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
                       //              16 g.d, 17 sum|g|, 18 g.g, 19 max|g| over this frame's gradient entries
 };
 
@@ -77,14 +78,18 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
                   // fits at 3 waves per SIMD: 300 blocks then run in two rounds on 256 CUs, 24.8 -> 38.5 us.  8 waves need
                   // <= 128 VGPRs for two blocks per CU and spill: 43 -> 73 us.)
 #define BWD_SLOTS (BWD_NW * 4)  // (wave, 16-lane group) pairs: items in flight per block
-template <bool SPARSE>
+// PART (with SPARSE): the part stage with its cached pose blend.  The body pose is a constant there, so nothing of the
+// pose-feature path exists - no posedirs gather (2.5 KB per item), no feature gradient, no body-rotation epilogue - and
+// the posed-template vertex is read from the cache k_part_fwd searched: v_posed = C[f][v] + S[v] . beta.
+template <bool SPARSE, bool PART = false>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
+  static_assert(SPARSE || !PART, "the part-stage variant is built on the sparse item loop");
   __builtin_amdgcn_s_setprio(2);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
   __shared__ float spf[UUO_KB];
   __shared__ float w_dA[BWD_SLOTS][UUO_NUM_JOINTS * 12];  // private accumulators: one per (wave, 16-lane group)
-  __shared__ float w_dpf[BWD_SLOTS][UUO_KB];
+  __shared__ float w_dpf[PART ? 1 : BWD_SLOTS][PART ? 256 : UUO_KB];  // (the shape-gradient tail borrows 240 entries from row 0)
   __shared__ float w_red[BWD_SLOTS][16];
   __shared__ float sdA[UUO_NUM_JOINTS * 12];
   __shared__ float sdpf[UUO_KB];
@@ -118,7 +123,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     frame_forward(a.src, a.tree, f, L);
   }
   if (tid < UUO_NUM_JOINTS) frame_skin_matrix(L, tid, sA + tid * 12);
-  if (tid < UUO_KB) {
+  if (!PART && tid < UUO_KB) {
     float v = 0.f;
     if (tid < UUO_NUM_POSE_FEATS) {
       const int j = 1 + tid / 9, e = tid % 9;
@@ -174,7 +179,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     const int slot = wave * 4 + gq;  // 0..15
     float fk[13];
 #pragma unroll
-    for (int t = 0; t < 13; ++t) fk[t] = spf[sl + 16 * t];
+    for (int t = 0; t < 13; ++t) fk[t] = PART ? 0.f : spf[sl + 16 * t];
     const float beta_s = (sl < 10) ? L.beta[sl] : 0.f;
     float acc_pf[13];
 #pragma unroll
@@ -228,14 +233,21 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
         const float* px = a.markers + ((size_t)f * M + mm) * 3;
         q.x0 = px[0]; q.x1 = px[1]; q.x2 = px[2];
       }
-      const float* pt = a.PT + (size_t)vi * 3 * UUO_KB + sl;
+      if constexpr (PART) {  // template + pose-corrective offsets of this frame, from the cache
+        const float* pc = a.C + ((size_t)f * a.V + vi) * 3;
+        q.vt0 = pc[0];
+        q.vt1 = pc[1];
+        q.vt2 = pc[2];
+      } else {
+        const float* pt = a.PT + (size_t)vi * 3 * UUO_KB + sl;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int t = 0; t < 13; ++t) q.p[c][t] = pt[c * UUO_KB + 16 * t];
-      q.vt0 = a.vt[(size_t)vi * 3];
-      q.vt1 = a.vt[(size_t)vi * 3 + 1];
-      q.vt2 = a.vt[(size_t)vi * 3 + 2];
+          for (int t = 0; t < 13; ++t) q.p[c][t] = pt[c * UUO_KB + 16 * t];
+        q.vt0 = a.vt[(size_t)vi * 3];
+        q.vt1 = a.vt[(size_t)vi * 3 + 1];
+        q.vt2 = a.vt[(size_t)vi * 3 + 2];
+      }
       const float* ps = a.ST + (size_t)vi * 30 + (sl < 10 ? sl : 0);
       q.st0 = (sl < 10) ? ps[0] : 0.f;
       q.st1 = (sl < 10) ? ps[10] : 0.f;
@@ -256,7 +268,11 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       fetch16(slot + BWD_SLOTS * r, cur);
       const float wgt = cur.wgt, d2 = cur.d2;
       float vp[3];
-      {
+      if constexpr (PART) {
+        vp[0] = cur.vt0 + row_sum(cur.st0 * beta_s);
+        vp[1] = cur.vt1 + row_sum(cur.st1 * beta_s);
+        vp[2] = cur.vt2 + row_sum(cur.st2 * beta_s);
+      } else {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < 13; ++t) {
@@ -305,9 +321,11 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       float dvp[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
+      if constexpr (!PART) {
 #pragma unroll
-      for (int t = 0; t < 13; ++t)
-        acc_pf[t] += fmaf(cur.p[2][t], dvp[2], fmaf(cur.p[1][t], dvp[1], cur.p[0][t] * dvp[0]));
+        for (int t = 0; t < 13; ++t)
+          acc_pf[t] += fmaf(cur.p[2][t], dvp[2], fmaf(cur.p[1][t], dvp[1], cur.p[0][t] * dvp[0]));
+      }
       acc_db16 += fmaf(cur.st2, dvp[2], fmaf(cur.st1, dvp[1], cur.st0 * dvp[0]));  // sub-lanes 0..9: d beta (direct path)
       if (sl < 12) {
         const int rr_ = sl >> 2, cc_ = sl & 3;
@@ -320,8 +338,10 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       acc_dt16 += (sl == 0) ? g[0] : ((sl == 1) ? g[1] : g[2]);  // sub-lanes 0..2
       acc_loss16 += loss_item;                                     // sub-lane 0 is the one that is stored
     }
+    if constexpr (!PART) {
 #pragma unroll
-    for (int t = 0; t < 13; ++t) w_dpf[slot][sl + 16 * t] = acc_pf[t];
+      for (int t = 0; t < 13; ++t) w_dpf[slot][sl + 16 * t] = acc_pf[t];
+    }
     if (sl == 0) w_red[slot][0] = acc_loss16;
     if (sl < 3) w_red[slot][1 + sl] = acc_dt16;
     if (sl < 10) w_red[slot][4 + sl] = acc_db16;
@@ -486,11 +506,13 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   // ---- block reduction over the accumulation slots (fixed order -> deterministic)
   __syncthreads();
   BWD_STAMP(3);
-  if (tid < UUO_KB) {
-    float acc = w_dpf[0][tid];
+  if constexpr (!PART) {
+    if (tid < UUO_KB) {
+      float acc = w_dpf[0][tid];
 #pragma unroll
-    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dpf[w][tid];
-    sdpf[tid] = acc;
+      for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dpf[w][tid];
+      sdpf[tid] = acc;
+    }
   }
   for (int i = tid; i < UUO_NUM_JOINTS * 12; i += BWD_NW * 64) {
     float acc = w_dA[0][i];
@@ -519,7 +541,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   const int j = tid;
   // this thread's rotation inputs for the epilogue: issued here so their round trip overlaps the sweep
   float raw_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, po_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (j >= 1 && j < UUO_NUM_JOINTS && a.g_pose) {
+  if (!PART && j >= 1 && j < UUO_NUM_JOINTS && a.g_pose) {
     const float* pr = a.raw_pose + ((size_t)f * 23 + (j - 1)) * 9;
 #pragma unroll
     for (int e = 0; e < 9; ++e) raw_pre[e] = pr[e];
@@ -618,7 +640,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   // body rotations
   if (j >= 1 && j < UUO_NUM_JOINTS) {
     float psq = 0.f;
-    if (a.g_pose) {
+    if (!PART && a.g_pose) {
       float dR[9], raw[9], gout[9];
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
@@ -748,6 +770,12 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
   UUO_BATCH_PICK(BwdArgs, batch)
   bwd_body<true>(a);
 }
+// part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part(BwdArgs a) { bwd_body<true, true>(a); }
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(BwdArgs, batch)
+  bwd_body<true, true>(a);
+}
 
 // ----------------------------------------------------------------------------------------------------
 // K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
@@ -756,19 +784,19 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
 struct FinArgs {
   UuoGridHdr h;
   int stage, F;
-  const float* frame_part;
-  const float* betas;
-  const float* o_betas;
+  uuo_gptr<const float> frame_part;
+  uuo_gptr<const float> betas;
+  uuo_gptr<const float> o_betas;
   double closs;   // data-term coefficient on the summed per-frame values
   double cpose;   // w_pose / (F*207)
   double cbetas;  // w_betas / 10
-  float* g_betas;
-  float* g_z;  // part stage
-  float* loss;
-  const float* dir_betas;  // optional direction entries of the shared parameters
-  const float* dir_z;
-  double* stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
-  unsigned long long* rep_host;  // optional zero-copy report (UuoEvalReport)
+  uuo_gptr<float> g_betas;
+  uuo_gptr<float> g_z;  // part stage
+  uuo_gptr<float> loss;
+  uuo_gptr<const float> dir_betas;  // optional direction entries of the shared parameters
+  uuo_gptr<const float> dir_z;
+  uuo_gptr<double> stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
+  uuo_gptr<unsigned long long> rep_host;  // optional zero-copy report (UuoEvalReport)
   unsigned long long rep_seq;
 };
 
@@ -834,7 +862,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       if (a.rep_host) {
         // the solver's read-back block {max|d| bits, pad, out[9]} starts one word before stats; words 1..5 are
         // the values just written, the rest was left by the direction kernels of this iteration
-        const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats) - 1;
+        const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats.get()) - 1;
 #pragma unroll
         for (int i = 0; i < 10; ++i) a.rep_host[i] = blk[i];
         __threadfence_system();
@@ -854,6 +882,8 @@ __global__ __launch_bounds__(1024) void k_finalize_b(const FinArgs* __restrict__
 int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int count, int gx, int gy) {
   if (op == UUO_OP_BWD) {
     hipLaunchKernelGGL(k_bwd_sparse_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
+  } else if (op == UUO_OP_BWD_PART) {
+    hipLaunchKernelGGL(k_bwd_part_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
   } else if (op == UUO_OP_FIN) {
     hipLaunchKernelGGL(k_finalize_b, dim3(gx, gy, count), dim3(1024), 0, s, (const FinArgs*)d_args);
   } else {
@@ -1132,7 +1162,11 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
   a.h.gx = F;
   a.h.gy = 1;
-  if (m->nnz <= 4) {
+  const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
+  if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && m->nnz <= 4 && !part_general) {
+    a.C = fit->pose_cache;
+    if (!uuo_record(UUO_OP_BWD_PART, F, 1, a)) hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  } else if (m->nnz <= 4) {
     if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else {
     UUO_REQUIRE(!uuo_recorder, "lock-step batches need the sparse skin-weight tables (<= 4 weights per vertex)");

@@ -68,11 +68,11 @@ __device__ __forceinline__ void nn_body(const float* __restrict__ x, const float
 
 struct NnArgs {
   UuoGridHdr h;  // batched form: gy = query groups x splits
-  const float* x;
-  const float* y;
-  const int* ysub;
+  uuo_gptr<const float> x;
+  uuo_gptr<const float> y;
+  uuo_gptr<const int> ysub;
   int P1, P2, nc, S;
-  unsigned long long* out;
+  uuo_gptr<unsigned long long> out;
 };
 __global__ __launch_bounds__(64) void k_nn(NnArgs a) {
   nn_body(a.x, a.y, a.ysub, a.P1, a.P2, a.nc, a.S, a.out, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_nn_b(const NnArgs* __restrict__ batch) {
 }
 struct FillArgs {  // UUO_OP_FILL: all-ones fill of the packed (distance, index) keys before a split search
   UuoGridHdr h;
-  unsigned long long* p;
+  uuo_gptr<unsigned long long> p;
   int count;
 };
 __global__ void k_fill_keys_b(const FillArgs* __restrict__ batch) {
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void k_nn_fewq_b(const NnArgs* __restrict__ ba
 struct PartFwdArgs {
   UuoGridHdr h;  // gx = F
   int F, V, ns, P1;
-  const int32_t* subset;
-  const float* C;
-  const float* SB;  // [ns][8]: shape offset | packed joints | weights (k_pose_prep's tail)
-  const float* A;
-  const float* trans;
-  const float* x;
-  unsigned long long* out;
+  uuo_gptr<const int32_t> subset;
+  uuo_gptr<const float> C;
+  uuo_gptr<const float> SB;  // [ns][8]: shape offset | packed joints | weights (k_pose_prep's tail)
+  uuo_gptr<const float> A;
+  uuo_gptr<const float> trans;
+  uuo_gptr<const float> x;
+  uuo_gptr<unsigned long long> out;
 };
 // minimum over the wave's 64 lanes, uniform result: 4 DPP steps inside each row of 16 lanes, then the 4 row results
 template <int CTRL>
@@ -189,6 +189,10 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
   return min(min(r0, r1), min(r2, r3));
 }
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pfw_uniform(float v) {  // a wave-uniform value, kept in a scalar register
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 #define PFW_U 4  // candidates per lane in flight (their loads are issued together)
 #define PFW_T 64  // one wave per (candidate, frame): one set of cross-lane minima per frame, no block-level merge
 // QB = the markers per frame (the running minima live in 2 * QB registers; one instantiation per count, no per-marker branch)
@@ -198,42 +202,49 @@ __device__ __forceinline__ void part_fwd_body(const PartFwdArgs& a, int f) {
   const int tid = threadIdx.x;
   constexpr int P1 = QB;
   // the lane's first candidates: their vertex ids are on their way while the skinning matrices are staged
+  // (past the end of the subset a lane repeats the last candidate: the same (distance, index) pair again changes no
+  // minimum, and the loop needs no validity mask)
+  const int last = a.ns - 1;
   int cc[PFW_U], vv[PFW_U];
 #pragma unroll
   for (int u = 0; u < PFW_U; ++u) {
-    cc[u] = tid + PFW_T * u;
-    vv[u] = cc[u] < a.ns ? a.subset[cc[u]] : -1;
+    cc[u] = min(tid + PFW_T * u, last);
+    vv[u] = a.subset[cc[u]];
   }
   {
     const float4* Af = reinterpret_cast<const float4*>(a.A + (size_t)f * UUO_NUM_JOINTS * 12);
     for (int i = tid; i < UUO_NUM_JOINTS * 3; i += PFW_T) reinterpret_cast<float4*>(sA)[i] = Af[i];
   }
-  // the frame's markers and translation are block-uniform: they live in SGPRs
-  float sq[QB * 3], sTr[3];
+  // the frame's markers and translation are block-uniform: they live in SGPRs, the markers as pairs (the distance
+  // arithmetic runs two markers per instruction on the packed-fp32 pipe: same IEEE operations, element by element)
+  constexpr int QP = (QB + 1) / 2;  // an odd count repeats its last marker in the spare half
+  pf2 qx[QP], qy[QP], qz[QP];
+  float sTr[3];
   const float* xq = a.x + (size_t)f * P1 * 3;
 #pragma unroll
-  for (int i = 0; i < QB * 3; ++i)
-    sq[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xq[i])));
+  for (int k = 0; k < QP; ++k) {
+    const int q0 = 2 * k, q1 = (2 * k + 1 < QB) ? 2 * k + 1 : QB - 1;
+    qx[k] = pf2{pfw_uniform(xq[q0 * 3]), pfw_uniform(xq[q1 * 3])};
+    qy[k] = pf2{pfw_uniform(xq[q0 * 3 + 1]), pfw_uniform(xq[q1 * 3 + 1])};
+    qz[k] = pf2{pfw_uniform(xq[q0 * 3 + 2]), pfw_uniform(xq[q1 * 3 + 2])};
+  }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    sTr[i] = a.trans ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.trans[(size_t)f * 3 + i]))) : 0.f;
+  for (int i = 0; i < 3; ++i) sTr[i] = a.trans ? pfw_uniform(a.trans[(size_t)f * 3 + i]) : 0.f;
   // the distance bits of a (non-negative) squared distance order as unsigned exactly as the packed key does; a lane sees
   // its candidates in ascending order, so strict '<' keeps the first index on ties, as the packed comparison would
   unsigned bd[QB], bi[QB];
 #pragma unroll
   for (int q = 0; q < QB; ++q) bd[q] = bi[q] = 0xFFFFFFFFu;
   const float* Cf = a.C + (size_t)f * a.V * 3;
-  const float4* SB4 = reinterpret_cast<const float4*>(a.SB);
+  const float4* SB4 = reinterpret_cast<const float4*>(a.SB.get());
   __syncthreads();
   for (int c0 = tid; c0 < a.ns; c0 += PFW_T * PFW_U) {
-    bool ok[PFW_U];
     float p[PFW_U][3];
     unsigned pj[PFW_U];
     float4 ww[PFW_U];
 #pragma unroll
     for (int u = 0; u < PFW_U; ++u) {
-      ok[u] = (unsigned)vv[u] < (unsigned)a.V;  // (-1 past the end of the subset)
-      const unsigned v = ok[u] ? (unsigned)vv[u] : 0u, c = ok[u] ? (unsigned)cc[u] : 0u;
+      const unsigned v = min((unsigned)vv[u], (unsigned)(a.V - 1)), c = (unsigned)cc[u];  // (memory safety only)
       const float* pc = Cf + v * 3u;
       const float4 k0 = SB4[c * 2u];
       ww[u] = SB4[c * 2u + 1u];
@@ -245,34 +256,45 @@ __device__ __forceinline__ void part_fwd_body(const PartFwdArgs& a, int f) {
     int cn[PFW_U], vn[PFW_U];  // the next round's vertex ids
 #pragma unroll
     for (int u = 0; u < PFW_U; ++u) {
-      cn[u] = cc[u] + PFW_T * PFW_U;
-      vn[u] = cn[u] < a.ns ? a.subset[cn[u]] : -1;
+      cn[u] = min(c0 + PFW_T * (PFW_U + u), last);
+      vn[u] = a.subset[cn[u]];
     }
 #pragma unroll
     for (int u = 0; u < PFW_U; ++u) {
       const float wv[4] = {ww[u].x, ww[u].y, ww[u].z, ww[u].w};
-      float T[12];
+      pf2 T2[6];  // the blended 3x4 transform, two entries per register pair
 #pragma unroll
-      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+      for (int e = 0; e < 6; ++e) T2[e] = pf2{0.f, 0.f};
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         // byte n of pj = 3 * joint: the row's float4 index (an unused slot is joint 0 with weight 0: adds exact zeros)
         const float4* pa = reinterpret_cast<const float4*>(sA) + ((pj[u] >> (8 * n)) & 0xFFu);
         const float4 r0 = pa[0], r1 = pa[1], r2 = pa[2];
-        const float ar[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const pf2 ar[6] = {pf2{r0.x, r0.y}, pf2{r0.z, r0.w}, pf2{r1.x, r1.y}, pf2{r1.z, r1.w}, pf2{r2.x, r2.y}, pf2{r2.z, r2.w}};
+        const pf2 w2 = pf2{wv[n], wv[n]};
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = fmaf(wv[n], ar[e], T[e]);
+        for (int e = 0; e < 6; ++e) T2[e] = __builtin_elementwise_fma(w2, ar[e], T2[e]);
       }
       const float px = p[u][0], py = p[u][1], pz = p[u][2];
-      const float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3] + sTr[0];
-      const float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7] + sTr[1];
-      const float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11] + sTr[2];
+      const float ox = fmaf(T2[1].x, pz, fmaf(T2[0].y, py, T2[0].x * px)) + T2[1].y + sTr[0];
+      const float oy = fmaf(T2[3].x, pz, fmaf(T2[2].y, py, T2[2].x * px)) + T2[3].y + sTr[1];
+      const float oz = fmaf(T2[5].x, pz, fmaf(T2[4].y, py, T2[4].x * px)) + T2[5].y + sTr[2];
+      const pf2 ox2 = pf2{ox, ox}, oy2 = pf2{oy, oy}, oz2 = pf2{oz, oz};
 #pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const unsigned d = __float_as_uint(sqdist(sq[q * 3], sq[q * 3 + 1], sq[q * 3 + 2], ox, oy, oz));
-        const bool better = ok[u] && d < bd[q];
-        bd[q] = better ? d : bd[q];
-        bi[q] = better ? (unsigned)cc[u] : bi[q];
+      for (int k = 0; k < QP; ++k) {
+        // sqdist() for two markers: ((dx*dx) + (dy*dy)) + (dz*dz), every operation rounded separately
+        const pf2 dx = qx[k] - ox2, dy = qy[k] - oy2, dz = qz[k] - oz2;
+        const pf2 d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * k + h;
+          if (q < QB) {
+            const unsigned d = __float_as_uint(h ? d2.y : d2.x);
+            const bool better = d < bd[q];
+            bd[q] = better ? d : bd[q];
+            bi[q] = better ? (unsigned)cc[u] : bi[q];
+          }
+        }
       }
     }
 #pragma unroll
@@ -510,11 +532,11 @@ __device__ __forceinline__ void nn_cull_body(int M, int V, int nunits, int mper,
 struct NnCullArgs {
   UuoGridHdr h;
   int M, V, nunits, mper;
-  const float* x;
-  const float* verts;
-  const float* bbox;
-  unsigned long long* packed;
-  int* stats;
+  uuo_gptr<const float> x;
+  uuo_gptr<const float> verts;
+  uuo_gptr<const float> bbox;
+  uuo_gptr<unsigned long long> packed;
+  uuo_gptr<int> stats;
 };
 __global__ __launch_bounds__(CULL_T) void k_nn_cull(NnCullArgs a) {
   nn_cull_body(a.M, a.V, a.nunits, a.mper, a.x, a.verts, a.bbox, a.packed, a.stats);

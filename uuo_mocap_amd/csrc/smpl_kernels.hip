@@ -89,19 +89,19 @@ __device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoT
 struct PosePrepArgs {
   UuoGridHdr h;
   UuoPoseSrc src;
-  const UuoTree* tree;
+  uuo_gptr<const UuoTree> tree;
   int F;
-  float* pfaT;
-  float* A;
-  float* jposed;
-  float* frames;
-  const float* ST;        // part stage (k_part_fwd follows): shape blend and skin weight tables, the candidate's vertices,
-  const int* Wi;          // their count and the [ns][8] buffer that takes their per-vertex constants; null / 0 otherwise
-  const float* Ww;
+  uuo_gptr<float> pfaT;
+  uuo_gptr<float> A;
+  uuo_gptr<float> jposed;
+  uuo_gptr<float> frames;
+  uuo_gptr<const float> ST;        // part stage (k_part_fwd follows): shape blend and skin weight tables, the candidate's vertices,
+  uuo_gptr<const int> Wi;          // their count and the [ns][8] buffer that takes their per-vertex constants; null / 0 otherwise
+  uuo_gptr<const float> Ww;
   int V;
-  const int32_t* subset;
+  uuo_gptr<const int32_t> subset;
   int ns;
-  float* sb_out;
+  uuo_gptr<float> sb_out;
 };
 __global__ __launch_bounds__(64) void k_pose_prep(PosePrepArgs a) {
   pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out);
@@ -911,15 +911,15 @@ __device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int
 struct SkinCachedArgs {
   UuoGridHdr h;
   int F, V, ns;
-  const int32_t* subset;
-  const float* C;
-  const float* ST;
-  const int* Wi;
-  const float* Ww;
-  const float* A;
-  const float* betas;
-  const float* trans;
-  float* verts;
+  uuo_gptr<const int32_t> subset;
+  uuo_gptr<const float> C;
+  uuo_gptr<const float> ST;
+  uuo_gptr<const int> Wi;
+  uuo_gptr<const float> Ww;
+  uuo_gptr<const float> A;
+  uuo_gptr<const float> betas;
+  uuo_gptr<const float> trans;
+  uuo_gptr<float> verts;
 };
 __global__ __launch_bounds__(256) void k_skin_cached(SkinCachedArgs a) {
   skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts);

@@ -69,11 +69,11 @@ __device__ __forceinline__ void lb_axpy_body(int n, const float* __restrict__ x,
 struct LbNegArgs {
   UuoGridHdr h;
   int n;
-  const float* g;
-  float* d;
-  const float* x;
+  uuo_gptr<const float> g;
+  uuo_gptr<float> d;
+  uuo_gptr<const float> x;
   float t;
-  float* xt;
+  uuo_gptr<float> xt;
 };
 __global__ void k_lb_neg(LbNegArgs a) { lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt); }
 __global__ void k_lb_neg_b(const LbNegArgs* __restrict__ batch) {
@@ -83,10 +83,10 @@ __global__ void k_lb_neg_b(const LbNegArgs* __restrict__ batch) {
 struct LbAxpyArgs {
   UuoGridHdr h;
   int n;
-  const float* x;
+  uuo_gptr<const float> x;
   float t;
-  const float* d;
-  float* o;
+  uuo_gptr<const float> d;
+  uuo_gptr<float> o;
 };
 __global__ void k_lb_axpy(LbAxpyArgs a) { lb_axpy_body(a.n, a.x, a.t, a.d, a.o); }
 __global__ void k_lb_axpy_b(const LbAxpyArgs* __restrict__ batch) {
@@ -302,14 +302,14 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
 struct LbDotsArgs {
   UuoGridHdr h;
   int n, cap, capL, head, count, cand;
-  float* S;
-  float* Y;
-  const float* g;
-  const float* gp;
-  const float* d;
+  uuo_gptr<float> S;
+  uuo_gptr<float> Y;
+  uuo_gptr<const float> g;
+  uuo_gptr<const float> gp;
+  uuo_gptr<const float> d;
   float t;
   int ncb, gcb;
-  double* part;
+  uuo_gptr<double> part;
 };
 __global__ __launch_bounds__(256) void k_lb_dots(LbDotsArgs a) {
   lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part);
@@ -1100,8 +1100,8 @@ __device__ __forceinline__ void lb_small_inv_body(int nchunks, int cap, int hist
 struct LbSmallArgs {
   UuoGridHdr h;
   int nchunks, cap, hist, cand;
-  const double* part;
-  LbDev* st;
+  uuo_gptr<const double> part;
+  uuo_gptr<LbDev> st;
   int stop;
 };
 __global__ __launch_bounds__(512) void k_lb_small_inv(LbSmallArgs a) {
@@ -1224,14 +1224,14 @@ struct StageObjective : Objective {
 struct LbDirArgs {
   UuoGridHdr h;
   int n, cap, capL;
-  const float* S;
-  const float* Y;
-  const float* g;
-  LbDev* st;
-  float* d;
-  const float* x;
+  uuo_gptr<const float> S;
+  uuo_gptr<const float> Y;
+  uuo_gptr<const float> g;
+  uuo_gptr<LbDev> st;
+  uuo_gptr<float> d;
+  uuo_gptr<const float> x;
   float t;
-  float* xt;
+  uuo_gptr<float> xt;
 };
 __global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction(LbDirArgs a) {
   lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt);
@@ -1364,8 +1364,8 @@ static inline void lb_dispatch(int op, hipStream_t s, dim3 grid, dim3 block, K k
 }
 struct LbCopyArgs {  // UUO_OP_COPY: device-to-device copy of n floats
   UuoGridHdr h;
-  float* dst;
-  const float* src;
+  uuo_gptr<float> dst;
+  uuo_gptr<const float> src;
   size_t bytes;
 };
 static inline int lb_copy(hipStream_t s, float* dst, const float* src, size_t bytes) {

@@ -48,21 +48,27 @@ void uuo_set_error(const std::string& msg);
   } while (0)
 
 // the argument struct of every batched kernel (lock-step batches, below) starts with its own grid extent
-// A pointer read from an argument struct that itself lives in device memory (the lock-step kernels' `batch[...]`) would be
-// a generic pointer to the compiler: its loads become flat_load, which count on the LDS counter as well and so serialise
+// A pointer read from an argument struct that itself lives in device memory (the lock-step kernels' `batch[...]`) is a
+// generic pointer to the compiler: its loads become flat_load, which count on the LDS counter as well and so serialise
 // with the kernel's LDS traffic.  Everything this library hands to a kernel is global memory (device or pinned host), so
-// the pointer members of the argument structs say so in their type when compiled for the device (same size and layout
-// on the host, where they are plain pointers); uuo_p() gives the generic pointer where a callee wants one - after
-// inlining the compiler still knows where it came from and keeps the global_load.
+// the pointer members of the argument structs carry that in their type when compiled for the device: uuo_gptr<T> is a
+// T* in size, layout and use (it converts from and to T*), and the loads through it - also through pointers derived
+// from it in inlined callees - are global_load, as in the kernels that take their pointers as direct arguments.
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
 #define UUO_GLOBAL __attribute__((address_space(1)))
 #else
 #define UUO_GLOBAL
 #endif
 template <typename T>
-__host__ __device__ __forceinline__ T* uuo_p(UUO_GLOBAL T* p) {
-  return (T*)p;
-}
+struct uuo_gptr {
+  UUO_GLOBAL T* p;
+  uuo_gptr() = default;
+  __host__ __device__ uuo_gptr(T* q) : p((UUO_GLOBAL T*)q) {}
+  __host__ __device__ operator T*() const { return (T*)p; }
+  __host__ __device__ T* get() const { return (T*)p; }
+  __host__ __device__ T* operator->() const { return (T*)p; }
+};
+static_assert(sizeof(uuo_gptr<const float>) == sizeof(void*), "uuo_gptr must be a plain pointer in memory");
 struct UuoGridHdr {
   int gx, gy;
 };
@@ -116,14 +122,14 @@ struct uuo_model {
 enum { UUO_ROOT_RAW = 0, UUO_ROOT_GS = 1, UUO_ROOT_Z_GS = 2, UUO_ROOT_ZSHARED = 3 };
 
 struct UuoPoseSrc {
-  const float* body;   // [F,23,9]
+  uuo_gptr<const float> body;   // [F,23,9]
   int norm_body;       // Gram-Schmidt (rotation_6d round trip) on the body rotations
-  const float* root;   // [F,9]
+  uuo_gptr<const float> root;   // [F,9]
   int root_mode;       // UUO_ROOT_*
-  const float* z;      // [F] (Z_GS) or [1] (ZSHARED)
-  const float* betas;  // [10] or [F,10]
+  uuo_gptr<const float> z;      // [F] (Z_GS) or [1] (ZSHARED)
+  uuo_gptr<const float> betas;  // [10] or [F,10]
   int betas_stride;    // 0 or 10
-  const float* trans;  // [F,3] or null
+  uuo_gptr<const float> trans;  // [F,3] or null
 };
 
 struct uuo_fit {
@@ -191,11 +197,11 @@ int uuo_closure_forward_at(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
 struct PartScoreArgs {
   UuoGridHdr h;
   int F, M, V, ns;
-  const float* markers;             // [F][M][3]
-  const float* verts;               // [F][V][3], valid at the subset's vertices
-  const int32_t* subset;            // [ns]
-  const unsigned long long* nn;     // [F][M] packed (squared distance bits << 32 | candidate)
-  double* out;                      // [F][2]: sum_m d2(marker -> nearest subset vertex), sum_c d2(subset vertex -> nearest marker)
+  uuo_gptr<const float> markers;             // [F][M][3]
+  uuo_gptr<const float> verts;               // [F][V][3], valid at the subset's vertices
+  uuo_gptr<const int32_t> subset;            // [ns]
+  uuo_gptr<const unsigned long long> nn;     // [F][M] packed (squared distance bits << 32 | candidate)
+  uuo_gptr<double> out;                      // [F][2]: sum_m d2(marker -> nearest subset vertex), sum_c d2(subset vertex -> nearest marker)
 };
 int uuo_launch_part_scores(hipStream_t s, const void* d_args, int count, int F);
 // Optional zero-copy report of a closure evaluation: the finalize kernel copies the 80-byte block that starts 8 bytes
@@ -233,6 +239,7 @@ enum {
   UUO_OP_NN_FEWQ,
   UUO_OP_NN_CULL,
   UUO_OP_BWD,
+  UUO_OP_BWD_PART,         // k_bwd_part: the part stage on its cached pose blend
   UUO_OP_FIN,
   UUO_OP_COUNT
 };
