@@ -384,6 +384,8 @@ def main():
                             "against": "synthetic ground truth (float64 SMPL equations, uuo_mocap_amd/synthetic.py); "
                                        "HMR stand-in starts 100 deg off in yaw with 0.1 rad pose / 0.5 shape noise"},
             "stages_last_step": stage_summary(all_stats[-1]),
+            "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
+                              zip(all_stats[-1]["timeline"], [0.0] + [t for _, t in all_stats[-1]["timeline"][:-1]])},
             "roofline": roofline,
         }
         if world == 1 and args.config == "video_mocap" and not args.no_other_configs:

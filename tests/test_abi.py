@@ -199,8 +199,8 @@ def test_runner_conventions(tmp_path, tables):
     assert runner.run(args, fit_fn=fake_fit) == 0 and len(calls) == 2  # skip-if-exists
     args2 = runner.build_parser().parse_args(["--config", str(cfg), "--dataset", "cmu_kitchen_pilot_rb", "--input_dir",
                                               str(root), "--subjects", "s02", "--sequences", "jump"])
-    with pytest.raises(NotImplementedError):
-        runner.run(args2, fit_fn=fake_fit)  # .c3d readers are outside the accelerated path
+    # a .c3d sequence whose 4D-Humans result is missing is skipped, as the reference does (test/test.py:91-93)
+    assert runner.run(args2, fit_fn=fake_fit) == 0 and len(calls) == 2
 
 
 def test_evaluation_metrics_match_reference():

@@ -9,5 +9,6 @@ rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/p_$TAG -- python3 
 cd $R
 f=$(find gpurun_out/p_$TAG -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_timeline.py $f --frac ${FRAC:-0.5} > gpurun_out/${TAG}_timeline.log
+if [ -n "$ROUNDS" ]; then python3 tools/trace_rounds.py $f "$ROUNDS" --last ${ROUNDS_LAST:-200} > gpurun_out/${TAG}_rounds.log; fi
 rm -rf gpurun_out/p_$TAG
 cat gpurun_out/${TAG}_timeline.log

@@ -1299,6 +1299,7 @@ struct LbWs {
   LbDev* st = nullptr;
   float* loss_dev = nullptr;
   double* h_out = nullptr;  // pinned, device-visible: read-back block + sequence word
+  void* slab = nullptr;     // the one device allocation the pointers above are carved from
   unsigned long long seq = 0;
   int nchunks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1306,9 +1307,7 @@ struct LbWs {
 
 static int lbws_destroy(LbWs* w) {
   if (!w) return 0;
-  void* ptrs[] = {w->S, w->Y, w->vecs, w->part, w->st, w->loss_dev};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (w->slab) (void)hipFree(w->slab);
   if (w->h_out) (void)hipHostFree(w->h_out);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
@@ -1324,9 +1323,9 @@ static int lbws_create(int n, int hist, LbWs** out, bool sync = true) {
   w->cap = hist + 1;
   w->nchunks = LB_MAXCHUNK;
   hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(p, bytes);
-  };
+  struct Piece { void** p; size_t bytes; };
+  std::vector<Piece> pieces;
+  auto A = [&](void** p, size_t bytes) { pieces.push_back({p, (bytes + 255) / 256 * 256}); };
   const size_t hist_floats = (size_t)(n / LB_CW) * LB_CBSTRIDE(w->cap);
   A((void**)&w->S, hist_floats * sizeof(float));
   A((void**)&w->Y, hist_floats * sizeof(float));
@@ -1335,14 +1334,22 @@ static int lbws_create(int n, int hist, LbWs** out, bool sync = true) {
   A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
   A((void**)&w->st, sizeof(LbDev));
   A((void**)&w->loss_dev, 16 * sizeof(float));
+  {  // one allocation, one zero fill
+    size_t total = 0;
+    for (const Piece& q : pieces) total += q.bytes;
+    e = hipMalloc(&w->slab, total);
+    if (e == hipSuccess) e = hipMemset(w->slab, 0, total);
+    size_t off = 0;
+    if (e == hipSuccess)
+      for (const Piece& q : pieces) {
+        *q.p = (char*)w->slab + off;
+        off += q.bytes;
+      }
+  }
   if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) std::memset(w->h_out, 0, 32 * sizeof(double));
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
-  if (e == hipSuccess) e = hipMemset(w->part, 0, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(w->S, 0, hist_floats * sizeof(float));
-  if (e == hipSuccess) e = hipMemset(w->Y, 0, hist_floats * sizeof(float));
-  if (e == hipSuccess) e = hipMemset(w->vecs, 0, (size_t)LB_NVEC * n * sizeof(float));
   // null-stream memsets are not ordered with the (non-blocking) stream the first solve runs on
   if (e == hipSuccess && sync) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -1835,11 +1842,11 @@ static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bo
   fit->nFT = (F + UUO_FT - 1) / UUO_FT;
   fit->n_max = 219 * F + 10;
   const int nFT = fit->nFT;
+  // one device allocation and one zero fill for the whole workspace (a lock-step batch creates hundreds of these)
   hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(p, bytes);
-    if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
-  };
+  struct Piece { void** p; size_t bytes; };
+  std::vector<Piece> pieces;
+  auto A = [&](void** p, size_t bytes) { pieces.push_back({p, (bytes + 255) / 256 * 256}); };
   A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));
   A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
@@ -1853,6 +1860,18 @@ static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bo
   A((void**)&fit->scalars, 64 * sizeof(float));
   A((void**)&fit->zeros16, 16 * sizeof(float));
   A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
+  {
+    size_t total = 0;
+    for (const Piece& q : pieces) total += q.bytes;
+    e = hipMalloc(&fit->slab, total);
+    if (e == hipSuccess) e = hipMemset(fit->slab, 0, total);
+    size_t off = 0;
+    if (e == hipSuccess)
+      for (const Piece& q : pieces) {
+        *q.p = (char*)fit->slab + off;
+        off += q.bytes;
+      }
+  }
   if (e == hipSuccess) e = hipEventCreate(&fit->ev0);
   if (e == hipSuccess) e = hipEventCreate(&fit->ev1);
   if (e != hipSuccess) {
@@ -1867,10 +1886,8 @@ static int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bo
 
 extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
-  void* ptrs[] = {fit->pfaT, fit->A, fit->verts, fit->part_sb, fit->nn_flags, fit->bbox, fit->nn, fit->frame_part, fit->frames, fit->mask, fit->scalars, fit->vecs,
-                  fit->shared_pose_cache ? nullptr : fit->pose_cache, fit->zeros16};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (fit->slab) (void)hipFree(fit->slab);
+  if (fit->pose_cache && !fit->shared_pose_cache) (void)hipFree(fit->pose_cache);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);
   if (fit->ev1) (void)hipEventDestroy(fit->ev1);
   if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);
@@ -1954,6 +1971,8 @@ struct uuo_batch {
   double* d_scores = nullptr;  // uuo_batch_part_scores: [nb][F][2] per-frame sums
   double* h_scores = nullptr;
   size_t score_cap = 0;
+  hipStream_t s2 = nullptr;  // the second stepping group's stream (forked from / joined to the caller's stream)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static thread_local ucontext_t g_sched_ctx;
@@ -1981,6 +2000,9 @@ extern "C" int uuo_batch_destroy(uuo_batch_t* b) {
   if (b->d_blob) (void)hipFree(b->d_blob);
   if (b->d_scores) (void)hipFree(b->d_scores);
   if (b->h_scores) (void)hipHostFree(b->h_scores);
+  if (b->s2) (void)hipStreamDestroy(b->s2);
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   delete b;
   return 0;
 }
@@ -2015,6 +2037,9 @@ extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int
   b->blob_cap = 2 * ((size_t)B * 12 * UUO_OP_ARG_MAX + 4096);  // two halves: one per stepping group
   if (rc == 0 && hipHostMalloc((void**)&b->h_blob, b->blob_cap, hipHostMallocDefault) != hipSuccess) rc = -12;
   if (rc == 0 && hipMalloc((void**)&b->d_blob, b->blob_cap) != hipSuccess) rc = -12;
+  if (rc == 0 && hipStreamCreateWithFlags(&b->s2, hipStreamNonBlocking) != hipSuccess) rc = -5;
+  if (rc == 0 && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) rc = -5;
+  if (rc == 0 && hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess) rc = -5;
   if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -5;  // the workspaces' zero fills ran on the null stream
   if (rc != 0) {
     if (rc == -12) uuo_set_error("uuo_batch_create: allocation failed");
@@ -2061,8 +2086,8 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
   // have executed.  Inside a solve that is implied -- every round waits for its evaluations' reports, which follow the copy
   // on the stream -- and the flag is cleared there; a flush that follows another one with no such wait synchronises first.
   if (b->blob_pending[region] && total > 0) {
-    UUO_HIP_CHECK(hipStreamSynchronize(s));
-    b->blob_pending[0] = b->blob_pending[1] = false;
+    UUO_HIP_CHECK(hipStreamSynchronize(s));  // (a region is only ever used on one stream between two joins)
+    b->blob_pending[region] = false;
   }
   if (total > 0) {
     b->blob_pending[region] = true;
@@ -2209,10 +2234,18 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
   const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
   g_batch_yield = batch_yield_impl;
   int result = 0;
-  // Two stepping groups (halves of the batch) take turns on the one stream: while the kernels of one group's round run,
-  // the host steps the other group's coroutines and stages their launches, so the ~1 ms of host work per round of a
-  // 200-problem batch hides behind ~1.5 ms of kernels instead of adding to it.  Each group owns half of the staging blob.
+  // Two stepping groups (halves of the batch), each on its own stream: while the kernels of one group's round run, the
+  // host steps the other group's coroutines and stages their launches (the ~1 ms of host work per round of a 200-problem
+  // batch hides behind the kernels instead of adding to them), and the latency-bound tail of a round (finalize, the
+  // solver's small kernels, the launch gaps between them) overlaps the other group's wide kernels on the GPU.  The
+  // second stream is forked from the caller's and joined to it before returning.  Each group owns half of the staging blob.
   const int ngroups = nb >= 8 ? 2 : 1;
+  hipStream_t gs[2] = {s, ngroups == 2 ? b->s2 : s};
+  if (ngroups == 2) {
+    UUO_HIP_CHECK(hipEventRecord(b->ev_fork, s));
+    UUO_HIP_CHECK(hipStreamWaitEvent(b->s2, b->ev_fork, 0));
+    for (int i = nb / 2; i < nb; ++i) cos[i].s = b->s2;
+  }
   const int gbeg[2] = {0, ngroups == 2 ? nb / 2 : nb}, gend[2] = {ngroups == 2 ? nb / 2 : nb, nb};
   auto step_group = [&](int g) -> int {  // every live problem of the group to its next evaluation (or to its end)
     for (int i = gbeg[g]; i < gend[g]; ++i) {
@@ -2226,7 +2259,7 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       g_cur_co = nullptr;
       if (c.done && c.rc) return c.rc;
     }
-    return batch_flush(b, s, cos, gbeg[g], gend[g], g);
+    return batch_flush(b, gs[g], cos, gbeg[g], gend[g], g);
   };
   auto wait_group = [&](int g) -> int {  // the reports of the group's problems that are in an evaluation
     bool waited_any = false;
@@ -2241,7 +2274,7 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {
-          const hipError_t q = hipStreamQuery(s);
+          const hipError_t q = hipStreamQuery(gs[g]);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
             uuo_set_error(std::string("batch: an evaluation did not report: ") + hipGetErrorString(q));
             return -5;
@@ -2275,11 +2308,15 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
   }
   g_batch_yield = nullptr;
   uuo_recorder = nullptr;
+  if (ngroups == 2) {  // join: whatever follows on the caller's stream sees both groups' results
+    if (hipEventRecord(b->ev_join, b->s2) == hipSuccess) (void)hipStreamWaitEvent(s, b->ev_join, 0);
+  }
   if (result == 0) {
     UUO_HIP_CHECK(hipStreamSynchronize(s));  // (problems that ended in the last round flushed their final copies there)
     b->blob_pending[0] = b->blob_pending[1] = false;
   } else {
     (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
+    if (ngroups == 2) (void)hipStreamSynchronize(b->s2);
   }
   return result;
 }

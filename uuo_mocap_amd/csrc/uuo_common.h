@@ -141,6 +141,7 @@ struct uuo_fit {
   float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
   float* bbox = nullptr;            // [F][ceil(V/16)][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
+  void* slab = nullptr;             // the one device allocation every buffer below (but pose_cache) is carved from
   float* part_sb = nullptr;         // [V][8] per-vertex constants of a part-stage candidate (k_pose_prep -> k_part_fwd)
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)

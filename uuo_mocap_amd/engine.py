@@ -256,7 +256,7 @@ class DeviceModel:
             if h is not None:
                 del self._batches[key]
                 h = None
-            cap = max(int(count), 4)
+            cap = (max(int(count), 4) + 63) // 64 * 64  # whole 64s: a few more candidates next time re-use the batch
             ptr = c_void_p()
             with torch.cuda.device(self.device):
                 check(self.lib.uuo_batch_create(self.handle, int(stage), int(F), int(M), cap, byref(ptr)), "uuo_batch_create")
