@@ -180,6 +180,21 @@ int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float*
                     const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
                     void* cb_user);
 
+/* The same driver for a closure composed on the host (the reference's optional objectives: the 2D reprojection fit,
+ * utils/hmr_utils.py:170-425 (step at :367); the chamfer / marker / part stages with velocity, ground, foot-contact,
+ * per-part or reprojection terms, optimization.py:187-275,329-394, markers/markers_utils.py:454-562): replaces
+ * torch.optim.LBFGS(params, ..., line_search_fn="strong_wolfe").step(closure) over the flat parameter vector d_x
+ * (n floats, torch's order = the order of the params list).  `closure(user, stream, d_x_eval, d_loss, d_grad)` must
+ * enqueue on `stream` the work that writes the loss (1 float) and the gradient (n floats) at d_x_eval and return 0;
+ * a non-zero return aborts the solve with that code.  The history, the two-loop products, the line search and every
+ * termination test run on the device / in the library as in uuo_lbfgs_solve. */
+typedef int (*uuo_closure_fn)(void* user, void* stream, const float* d_x_eval, float* d_loss, float* d_grad);
+int uuo_lbfgs_minimize(void* stream, int n, float* d_x, const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats,
+                       uuo_closure_fn closure, void* user, uuo_eval_callback_t cb, void* cb_user);
+/* device -> device copy of `bytes` bytes ordered on `stream` (closures written in Python move the evaluated point and
+ * the gradient between their own tensors and the driver's vectors with it) */
+int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes);
+
 /* ---- lock-step batches of independent solves ---------------------------------------------------------
  * The reference solves the candidate body parts of find_best_part_fits one after the other
  * (markers/markers_utils.py:416-610: one torch.optim.LBFGS(...).step(closure) per sub-tree, 202 of them for a 10-marker

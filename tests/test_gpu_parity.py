@@ -277,6 +277,55 @@ def test_fused_part_forward_is_bit_identical_to_skinning_then_searching(smpl, de
         assert np.array_equal(nn_p.cpu().numpy(), got[0][2])
 
 
+def test_device_lbfgs_with_a_host_closure_follows_torch(dev):
+    """DeviceLBFGS (uuo_lbfgs_minimize: the device driver calling back a closure composed in Python) against
+    torch.optim.LBFGS on the same closure: a well-scaled coupled quadratic over three parameter tensors, one of which
+    receives no gradient (the reference's parameter lists hold such tensors, hmr_utils.py:218,292).  Same losses evaluation
+    by evaluation, same iteration and evaluation counts, same final parameters."""
+    from uuo_mocap_amd.device_lbfgs import DeviceLBFGS
+
+    gen = torch.Generator().manual_seed(4)
+    a = (1.0 + 3.0 * torch.rand(40, generator=gen)).to(dev)
+    c = torch.randn(40, generator=gen).to(dev)
+    bmat = torch.randn(6, 5, generator=gen).to(dev)
+
+    def run(make_opt):
+        p0 = torch.zeros(40, device=dev, requires_grad=True)
+        p1 = torch.full((6, 5), 0.3, device=dev, requires_grad=True)
+        fixed = torch.ones(3, device=dev)  # in the list, never part of the graph
+        opt = make_opt([p0, fixed, p1])
+        losses = []
+
+        def closure():
+            opt.zero_grad()
+            loss = 0.5 * (a * (p0 - c) ** 2).sum() + 0.5 * ((p1 - bmat) ** 2).sum() + 0.1 * (p0[:30].reshape(6, 5) * p1).sum()
+            loss.backward()
+            losses.append(float(loss.detach()))
+            return loss
+
+        opt.step(closure)
+        return losses, p0.detach().cpu().numpy(), p1.detach().cpu().numpy(), fixed.cpu().numpy(), opt
+
+    kw = dict(max_iter=60, tolerance_grad=1e-7, tolerance_change=1e-9, lr=1.0, line_search_fn="strong_wolfe")
+    l_ref, p0_ref, p1_ref, _, o_ref = run(lambda ps: torch.optim.LBFGS(ps, **kw))
+    l_dev, p0_dev, p1_dev, fixed, o_dev = run(lambda ps: DeviceLBFGS(ps, **kw))
+    assert o_dev.stats["driver"] == "device-lbfgs(host closure)" and np.array_equal(fixed, np.ones(3, np.float32))
+    n = min(len(l_ref), len(l_dev))
+    # the last evaluations sit on the fp32 plateau of the loss, where torch's fp32 loss differences reach the 1e-9 stop
+    # a few iterations before the driver's (which sees the same fp32 losses but fp64 directional derivatives)
+    assert n >= 8 and abs(len(l_ref) - len(l_dev)) <= 8
+    np.testing.assert_allclose(l_dev[:n - 2], l_ref[:n - 2], rtol=2e-5)
+    assert abs(o_dev.state[o_dev.params[0]]["n_iter"] - o_ref.state[o_ref._params[0]]["n_iter"]) <= 8
+    np.testing.assert_allclose(p0_dev, p0_ref, atol=2e-4)
+    np.testing.assert_allclose(p1_dev, p1_ref, atol=2e-4)
+
+    # a closure that raises ends the solve and the exception reaches the caller
+    def boom():
+        raise RuntimeError("closure failed")
+    with pytest.raises(RuntimeError, match="closure failed"):
+        DeviceLBFGS([torch.zeros(4, device=dev, requires_grad=True)], max_iter=3).step(boom)
+
+
 def test_marker_closure_matches_oracle_and_golden(smpl, oracle_smpl, golden, dev):
     from uuo_mocap_amd.engine import MarkerProblem
 
@@ -843,7 +892,7 @@ def test_smpl_forward_backward_matches_autograd(smpl, oracle_smpl, dev, F, share
 
 
 def test_reprojection_stage_matches_reference(smpl, golden, dev):
-    """uuo_mocap_amd.reprojection.optim_reprojection (differentiable HIP operators + torch.optim.LBFGS) against the
+    """uuo_mocap_amd.reprojection.optim_reprojection (differentiable HIP operators under the device L-BFGS driver, uuo_lbfgs_minimize) against the
     fixture captured from the reference's own hmr_utils.optim_reprojection: target key points, mask, the first
     closure evaluations of the recorded loss trajectory, and the converged outputs."""
     from uuo_mocap_amd.reprojection import optim_reprojection
@@ -854,7 +903,8 @@ def test_reprojection_stage_matches_reference(smpl, golden, dev):
     t = lambda k: torch.from_numpy(np.asarray(g[k])).float().to(dev)
     for name, angle in (("a0", 0.0), ("a1", float(np.pi / 2))):
         losses = []
-        real = torch.optim.LBFGS
+        import uuo_mocap_amd.reprojection as mod
+        real = mod.DeviceLBFGS  # the device driver with a host-composed closure (uuo_lbfgs_minimize)
 
         class Rec(real):
             def step(self, closure):
@@ -864,7 +914,7 @@ def test_reprojection_stage_matches_reference(smpl, golden, dev):
                     return l
                 return super().step(wrapped)
 
-        torch.optim.LBFGS = Rec
+        mod.DeviceLBFGS = Rec
         try:
             out = optim_reprojection(
                 markers=t("markers"), pose_body=t("hmr_pose_body"), betas=t("betas"), hmr_betas=t("hmr_betas"),
@@ -872,7 +922,7 @@ def test_reprojection_stage_matches_reference(smpl, golden, dev):
                 cam_size=t("size"), cam_scale=t("scale"), angle=torch.tensor(angle), img_mask=t("img_mask"),
                 smpl_inference=smpl, num_iters=200, config=cfg)
         finally:
-            torch.optim.LBFGS = real
+            mod.DeviceLBFGS = real
         ref = g[name + "_losses"]
         n = min(len(losses), len(ref), 10)
         np.testing.assert_allclose(losses[:n], ref[:n], rtol=2e-3)
@@ -917,7 +967,7 @@ def test_reprojection_part_stage_in_the_orchestrator(smpl, dev):
     out2 = multimodal_video_mocap(seq.img_smpl, seq.markers, dev, cfg, offset=0, print_options=[], save_stages=False,
                                   smpl_inference=smpl)
     part = last_run_stats()["part"]
-    assert len(part) == 1 and part[0]["driver"] == "torch.optim.LBFGS" and part[0]["n_eval"] >= 2
+    assert len(part) == 1 and part[0]["driver"] == "device-lbfgs(host closure)" and part[0]["n_eval"] >= 2
     assert all(torch.isfinite(out2[k]).all() for k in ("trans", "pose_body", "root_orient", "betas"))
     with pytest.raises(ValueError, match="reprojection_part"):
         cfg["stages"]["reprojection_part"]["num_iters"] = 0
@@ -928,7 +978,7 @@ def test_reprojection_part_stage_in_the_orchestrator(smpl, dev):
 @pytest.mark.gpu
 def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
     """find_best_part_fits with every optional term of the reference's part closure enabled (reproject, foot_contact,
-    foot_velocity, velocity, ground; differentiable HIP operators + torch.optim.LBFGS) against the fixture captured
+    foot_velocity, velocity, ground; differentiable HIP operators under the device L-BFGS driver) against the fixture captured
     from the reference's own find_best_part_fits fed by its own optim_reprojection camera."""
     from uuo_mocap_amd.markers_utils import find_best_part_fits
 
@@ -940,7 +990,8 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
     camera = {k[4:]: t(k).float() for k in ("cam_joints_2d_gt", "cam_focal_length", "cam_reproject_mask", "cam_cam_trans",
                                             "cam_camera_center")}
     runs = []
-    real = torch.optim.LBFGS
+    import uuo_mocap_amd.markers_utils as mod
+    real = mod.DeviceLBFGS
 
     class Rec(real):
         def step(self, closure):
@@ -953,14 +1004,14 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
                 return l
             return super().step(wrapped)
 
-    torch.optim.LBFGS = Rec
+    mod.DeviceLBFGS = Rec
     try:
         out = find_best_part_fits(
             markers=t("markers").float(), pose_body=t("pose_body").float(), betas=t("o_betas").float(),
             root_orient=t("o_root_orient").float(), marker_labels=t("seg"), smpl_inference=smpl,
             hierarchy=smpl.smpl.parents, config=cfg, foot_contacts=t("foot_contacts").float(), **camera)
     finally:
-        torch.optim.LBFGS = real
+        mod.DeviceLBFGS = real
     assert len(runs) == int(g["n_subtrees"])
     np.testing.assert_allclose([r[0] for r in runs], g["first_losses"], rtol=2e-4)
     # trajectories: the first evaluations follow the reference's, the converged values agree (the evaluation count of
@@ -974,7 +1025,8 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
     np.testing.assert_array_equal(out["marker_labels"].cpu().numpy(), g["out_marker_labels"])
     # converged parameters of the winning candidate (the objective is flat along the limb: cm-level agreement)
     np.testing.assert_allclose(out["trans"].cpu().numpy(), g["out_trans"], atol=1e-2)
-    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=2e-2)
+    # (the shape has nearly flat directions under 10 markers: the final losses agree to 1e-4 above, the betas to a few 1e-2)
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=3e-2)
     np.testing.assert_allclose(out["root_orient"].cpu().numpy(), g["out_root_orient"], atol=1e-2)
     np.testing.assert_allclose(out["marker_weights"].cpu().numpy(), g["out_marker_weights"], rtol=1e-2, equal_nan=True)
 
@@ -1063,7 +1115,8 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
 
     # marker stage on the reference's own matrix
     losses = []
-    real = torch.optim.LBFGS
+    import uuo_mocap_amd.optimization as mod
+    real = mod.DeviceLBFGS
 
     class Rec(real):
         def step(self, closure):
@@ -1074,14 +1127,14 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
             return super().step(wrapped)
 
     leaves = [x.clone().requires_grad_(True) for x in (pose, betas, root, trans)]
-    torch.optim.LBFGS = Rec
+    mod.DeviceLBFGS = Rec
     try:
         optim_markers(markers=markers, pose_body=leaves[0], o_pose_body=t("o_pose_body"), betas=leaves[1],
                       o_betas=t("o_betas"), root_orient=leaves[2], trans=leaves[3],
                       barycentric_coords_one_hot=dense("full"), img_mask=torch.ones(F, device=dev),
                       smpl_inference=smpl, config=cfg)
     finally:
-        torch.optim.LBFGS = real
+        mod.DeviceLBFGS = real
     ref = g["losses"]
     np.testing.assert_allclose(losses[:20], ref[:20], rtol=2e-3)
     assert losses[-1] == pytest.approx(float(ref[-1]), rel=2e-2)
@@ -1109,7 +1162,7 @@ def test_orchestrator_with_barycentric_placement(smpl, dev):
         outs.append(multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0,
                                            print_options=[], save_stages=False, smpl_inference=smpl))
         st = last_run_stats()
-        assert len(st["marker"]) == 2 and all(s["driver"] == "torch.optim.LBFGS" and s["n_eval"] >= 2 for s in st["marker"])
+        assert len(st["marker"]) == 2 and all(s["driver"] == "device-lbfgs(host closure)" and s["n_eval"] >= 2 for s in st["marker"])
     for k in ("trans", "pose_body", "root_orient", "betas"):
         assert torch.isfinite(outs[0][k]).all()
         np.testing.assert_array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy())
@@ -1258,7 +1311,7 @@ def test_recompute_marker_labels(smpl, dev):
 @pytest.mark.parametrize("tag", ["terms", "free"])
 def test_chamfer_stage_options_match_reference(smpl, golden, dev, tag):
     """optim_chamfer with the optional terms part_chamfer + trans_vel + ground ("terms") and with yaw_lock False
-    ("free") -- differentiable HIP operators under torch.optim.LBFGS -- against the fixture captured from the
+    ("free") -- differentiable HIP operators under the device L-BFGS driver -- against the fixture captured from the
     reference's own optim_chamfer: loss trajectory prefix, converged loss, converged translation."""
     from uuo_mocap_amd.optimization import last_stats, optim_chamfer
 
@@ -1272,7 +1325,8 @@ def test_chamfer_stage_options_match_reference(smpl, golden, dev, tag):
     t = lambda k: torch.from_numpy(np.asarray(g[k])).float().to(dev)
     pose, betas, root, trans = (t(k).clone().requires_grad_(True) for k in ("o_pose_body", "o_betas", "o_root_orient", "trans0"))
     losses = []
-    real = torch.optim.LBFGS
+    import uuo_mocap_amd.optimization as mod
+    real = mod.DeviceLBFGS
 
     class Rec(real):
         def step(self, closure):
@@ -1282,13 +1336,13 @@ def test_chamfer_stage_options_match_reference(smpl, golden, dev, tag):
                 return l
             return super().step(wrapped)
 
-    torch.optim.LBFGS = Rec
+    mod.DeviceLBFGS = Rec
     try:
         optim_chamfer(t("markers"), pose_body=pose, o_pose_body=t("o_pose_body"), betas=betas, o_betas=t("o_betas"),
                       root_orient=root, trans=trans, img_mask=torch.ones(8, device=dev),
                       marker_labels=torch.from_numpy(g["labels"]).to(dev), smpl_inference=smpl, config=cfg)
     finally:
-        torch.optim.LBFGS = real
+        mod.DeviceLBFGS = real
     ref = g[tag + "_losses"]
     if tag == "terms":
         np.testing.assert_allclose(losses[:25], ref[:25], rtol=2e-3)
@@ -1299,7 +1353,7 @@ def test_chamfer_stage_options_match_reference(smpl, golden, dev, tag):
         np.testing.assert_allclose(losses[:3], ref[:3], rtol=1e-5)
         np.testing.assert_allclose(losses[:25], ref[:25], rtol=8e-2)
     assert losses[-1] == pytest.approx(float(ref[-1]), rel=5e-2)
-    assert last_stats("chamfer")["driver"] == "torch.optim.LBFGS" and root.requires_grad
+    assert last_stats("chamfer")["driver"] == "device-lbfgs(host closure)" and root.requires_grad
     assert np.median(np.abs(trans.detach().cpu().numpy() - g[tag + "_out_trans"])) < 2e-2
     det = torch.linalg.det(root.detach())
     assert float((det - 1).abs().max()) < 1e-4
@@ -1409,7 +1463,7 @@ def test_soft_assignment_chamfer_extension(smpl, golden, dev):
                   root_orient=leaves[2], trans=leaves[3], img_mask=t("img_mask"), marker_labels=None, smpl_inference=smpl,
                   config=cfg)
     st = last_stats("chamfer")
-    assert st["driver"] == "torch.optim.LBFGS" and st["loss_final"] < 0.7 * st["loss_first"]
+    assert st["driver"] == "device-lbfgs(host closure)" and st["loss_final"] < 0.7 * st["loss_first"]
 
 
 @pytest.mark.gpu

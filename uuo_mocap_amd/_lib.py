@@ -69,6 +69,9 @@ _SIGNATURES = {
                                 POINTER(UuoLbfgsStats), c_void_p, c_void_p]),
     "uuo_time_closure": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_int, c_int,
                                  POINTER(c_float)]),
+    "uuo_lbfgs_minimize": (c_int, [c_void_p, c_int, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats), c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "uuo_copy_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "uuo_batch_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "uuo_batch_destroy": (c_int, [c_void_p]),
     "uuo_batch_solve": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), POINTER(c_void_p), c_int,
@@ -88,6 +91,9 @@ _DEBUG_SIGNATURES = {
     "uuo_debug_small_coeffs": (c_int, [c_int, c_int, c_int, c_void_p]),
     "uuo_debug_time_small": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }
+
+# uuo_closure_fn (include/uuo_hip.h): int closure(user, stream, d_x_eval, d_loss, d_grad)
+CLOSURE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 
 _lib = None
 _lib_debug = None

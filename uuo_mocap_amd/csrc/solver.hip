@@ -2396,6 +2396,46 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
 
 // host copy of a device vector, ordered on `stream` and complete on return (the iter_fn adapter of the Python mirror
 // uses it inside the evaluation callback, where it only has the raw pointer)
+// ---------------------------------------------------------------------------------------------------- host-composed closures
+struct CallbackObjective : Objective {
+  uuo_closure_fn fn = nullptr;
+  void* user = nullptr;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*, const UuoEvalReport*) override {
+    const int rc = fn(user, (void*)s, x, loss_dev, grad);
+    if (rc) {
+      uuo_set_error("uuo_lbfgs_minimize: the closure returned " + std::to_string(rc));
+      return rc < 0 ? rc : -rc;
+    }
+    return 0;
+  }
+};
+
+extern "C" int uuo_lbfgs_minimize(void* stream, int n, float* d_x, const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats,
+                                  uuo_closure_fn closure, void* user, uuo_eval_callback_t cb, void* cb_user) {
+  UUO_REQUIRE(d_x && opt && stats && closure && n > 0, "uuo_lbfgs_minimize: bad arguments");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_minimize: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_lbfgs_minimize: not inside a lock-step batch");
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = nullptr;
+  int rc = lbws_create(n, hist, &w);
+  if (rc) return rc;
+  CallbackObjective obj;
+  obj.fn = closure;
+  obj.user = user;
+  obj.n = n;
+  std::memset(stats, 0, sizeof(*stats));
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, cb, cb_user);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  lbws_destroy(w);
+  return rc;
+}
+
+extern "C" int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes) {
+  UUO_REQUIRE(d_dst && d_src, "uuo_copy_device: null argument");
+  if (bytes) UUO_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n) {
   UUO_REQUIRE(d_src && h_dst && n >= 0, "uuo_copy_to_host: bad arguments");
   UUO_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -1,0 +1,113 @@
+"""torch.optim.LBFGS(params, ..., line_search_fn="strong_wolfe") for closures composed in Python, with the optimiser itself
+on the device: `DeviceLBFGS(params, ...).step(closure)` hands the flat parameter vector to `uuo_lbfgs_minimize`
+(include/uuo_hip.h) -- the history, the two-loop products, the line search and the termination tests are the library's
+mirror of torch 2.10's L-BFGS (the one that drives the fused stage closures) -- and the closure is called back for every
+evaluation with the parameters set to the evaluated point.
+
+Used by the reference's optional objectives, whose terms are composed from the differentiable HIP operators rather than
+fused into one kernel: the 2D reprojection fit (reference utils/hmr_utils.py:170-425, step at :367), the chamfer / marker
+stages with velocity, ground or per-part terms (optimization.py:187-275,329-394) and the part stage with reprojection /
+foot-contact / velocity terms (markers/markers_utils.py:454-562).  Same constructor arguments, same `step(closure)`
+contract (the closure zeroes the gradients, runs backward and returns the loss), same final state of the parameters."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref
+from typing import Callable, Dict, List
+
+import torch
+
+from . import _lib
+from ._lib import CLOSURE_FN, UuoLbfgsOptions, UuoLbfgsStats, check
+
+STOP_REASONS = ["max_iter", "max_eval", "tolerance_grad", "tolerance_change(step)", "tolerance_change(loss)",
+                "directional_derivative", "tolerance_grad(initial)"]
+
+
+class DeviceLBFGS:
+    def __init__(self, params, lr: float = 1.0, max_iter: int = 20, max_eval=None, tolerance_grad: float = 1e-7,
+                 tolerance_change: float = 1e-9, history_size: int = 100, line_search_fn: str = "strong_wolfe"):
+        if line_search_fn != "strong_wolfe":
+            raise NotImplementedError("DeviceLBFGS mirrors torch.optim.LBFGS with line_search_fn='strong_wolfe' only")
+        self.params: List[torch.Tensor] = list(params)
+        if not self.params:
+            raise ValueError("DeviceLBFGS: empty parameter list")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_cuda:
+                raise ValueError("DeviceLBFGS: parameters must be float32 tensors on one GPU")
+        self.device = dev
+        self.options = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
+                                       float(tolerance_change), int(max_eval) if max_eval else 0, 0)
+        self.stats: Dict = {}
+        # torch.optim.LBFGS keeps its counters in state[params[0]]; the callers read n_iter from there
+        self.state = {self.params[0]: {"n_iter": 0, "func_evals": 0}}
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def _scatter(self, flat: torch.Tensor):
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+
+    def step(self, closure: Callable[[], torch.Tensor]):
+        from .engine import current_stream
+
+        lib = _lib.load()
+        x = torch.cat([p.detach().reshape(-1) for p in self.params]).contiguous()
+        n = x.numel()
+        x_eval = torch.empty_like(x)
+        grad = torch.empty_like(x)
+        loss_buf = torch.empty(1, dtype=torch.float32, device=self.device)
+        failure: List[BaseException] = []
+        first: List[torch.Tensor] = []
+
+        def on_closure(user, stream, d_x_eval, d_loss, d_grad):
+            try:
+                if lib.uuo_copy_device(stream, x_eval.data_ptr(), d_x_eval, 4 * n) != 0:
+                    return 1
+                self._scatter(x_eval)
+                with torch.enable_grad():
+                    loss = closure()
+                if not first:
+                    first.append(loss.detach())
+                off = 0
+                for p in self.params:
+                    k = p.numel()
+                    if p.grad is None:
+                        grad[off:off + k].zero_()
+                    else:
+                        grad[off:off + k].copy_(p.grad.reshape(-1))
+                    off += k
+                loss_buf.copy_(loss.detach().reshape(1).to(torch.float32))
+                if lib.uuo_copy_device(stream, d_grad, grad.data_ptr(), 4 * n) != 0:
+                    return 1
+                return lib.uuo_copy_device(stream, d_loss, loss_buf.data_ptr(), 4)
+            except BaseException as e:  # noqa: BLE001 -- re-raised by step() once the library has unwound
+                failure.append(e)
+                return 7
+
+        cb = CLOSURE_FN(on_closure)
+        st = UuoLbfgsStats()
+        with torch.cuda.device(self.device):
+            stream = current_stream(self.device)
+            rc = lib.uuo_lbfgs_minimize(stream, n, x.data_ptr(), byref(self.options), byref(st),
+                                        ctypes.cast(cb, ctypes.c_void_p), None, None, None)
+        if failure:
+            raise failure[0]
+        check(rc, "uuo_lbfgs_minimize")
+        self._scatter(x)
+        self.stats = {"n_iter": int(st.n_iter), "n_eval": int(st.n_eval), "first_loss": float(st.first_loss),
+                      "final_loss": float(st.final_loss), "stop_reason": STOP_REASONS[st.stop_reason],
+                      "device_ms": float(st.device_ms), "driver": "device-lbfgs(host closure)"}
+        self.state[self.params[0]].update(n_iter=int(st.n_iter), func_evals=int(st.n_eval))
+        return first[0] if first else None

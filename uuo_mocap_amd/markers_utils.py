@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .body_model import SMPL_JOINT_NAMES
+from .device_lbfgs import DeviceLBFGS
 from .engine import PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
 from .losses import chamfer_distance
 from .transforms import compute_root_orient_z
@@ -310,7 +311,7 @@ def find_best_part_fits(
             betas_s = o_betas.clone().requires_grad_(True)
             # with 'reproject' the camera translation is a (gradient-free, hence fixed) fourth parameter (:422-424)
             params = [z_angle, trans, betas_s] + ([camera["cam_trans"]] if camera is not None else [])
-            optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"],
+            optimizer = DeviceLBFGS(params, max_iter=st["num_iters"],
                                           tolerance_grad=config["optimizer"]["tolerance_grad"],
                                           tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
                                           line_search_fn="strong_wolfe")
@@ -350,7 +351,7 @@ def find_best_part_fits(
                 distance = chamfer_distance(markers_subset, verts[:, vertex_indices].contiguous(),
                                             single_directional=False)[0].item()
             res = {"stats": {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)),
-                             "device_ms": 0.0, "driver": "torch.optim.LBFGS"},
+                             "device_ms": 0.0, "driver": optimizer.stats.get("driver", "device-lbfgs(host closure)")},
                    "distance": distance, "betas": betas_s.detach().clone(), "root_orient": z_root.clone(),
                    "trans": trans.detach().clone()}
             if stream is not None:

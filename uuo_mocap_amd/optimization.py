@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .device_lbfgs import DeviceLBFGS
 from .engine import MARKER_DISTANCE, ChamferProblem, MarkerProblem
 from .losses import (MarkerLoss, chamfer_distance, soft_weighted_chamfer_distance,  # noqa: F401  (re-exported)
                      weighted_chamfer_distance)
@@ -208,7 +209,7 @@ def _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root
         z_angle = torch.eye(3, device=device).expand(root_orient.shape[0], root_orient.shape[1], 3, 3).clone().requires_grad_(True)
     p_trans, p_betas, p_pose = (t.detach().clone().requires_grad_(True) for t in (trans, betas, pose_body))
     params = [p_trans, z_angle, p_betas, p_pose]
-    optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
+    optimizer = DeviceLBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
                                   tolerance_change=config["optimizer"]["tolerance_change"], lr=0.1,
                                   line_search_fn="strong_wolfe")
     mask = get_marker_mask(markers)
@@ -262,7 +263,7 @@ def _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root
         root_orient[:] = (compute_root_orient_z(z_angle) if st["yaw_lock"] else normalize_rot(z_angle)) @ root_fixed
     root_orient.requires_grad_(True)
     stats = {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)), "device_ms": 0.0,
-             "driver": "torch.optim.LBFGS", "loss_first": float(trace[0]), "loss_final": float(min(trace))}
+             "driver": optimizer.stats.get("driver", "device-lbfgs(host closure)"), "loss_first": float(trace[0]), "loss_final": float(min(trace))}
     LAST_STATS["chamfer"] = stats
     _tls_stats.chamfer = stats
     return None
@@ -334,7 +335,7 @@ def _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root
     leaves = [pose_body, betas, root_orient, trans]
     params = [p.detach().clone().requires_grad_(True) for p in leaves]
     p_pose, p_betas, p_root, p_trans = params
-    optimizer = torch.optim.LBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
+    optimizer = DeviceLBFGS(params, max_iter=st["num_iters"], tolerance_grad=config["optimizer"]["tolerance_grad"],
                                   tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
                                   line_search_fn="strong_wolfe")
     weights = get_marker_mask(markers)
@@ -371,7 +372,7 @@ def _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root
         for leaf, p in zip(leaves, params):
             leaf.copy_(p)
     stats = {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)), "device_ms": 0.0,
-             "driver": "torch.optim.LBFGS", "loss_first": float(trace[0]), "loss_final": float(min(trace))}
+             "driver": optimizer.stats.get("driver", "device-lbfgs(host closure)"), "loss_first": float(trace[0]), "loss_final": float(min(trace))}
     LAST_STATS["marker"] = stats
     _tls_stats.marker = stats
     return None

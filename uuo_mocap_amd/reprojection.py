@@ -12,6 +12,7 @@ from typing import Dict, Optional
 
 import torch
 
+from .device_lbfgs import DeviceLBFGS
 from .losses import chamfer_distance
 from .smpl import SmplInference
 from .transforms import compute_root_orient_y
@@ -107,7 +108,7 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
     yaw = (torch.ones(1, 1, 1, 1, device=device) * angle).to(device).requires_grad_(True)
     focal = torch.mean(cam["focal_length"], dim=0, keepdim=True)                           # [1, 2]
     # `betas` is in the parameter list but detached (hmr_utils.py:218,292): it receives no gradient and stays put
-    optimizer = torch.optim.LBFGS([yaw, body_t, cam_single, betas], max_iter=num_iters,
+    optimizer = DeviceLBFGS([yaw, body_t, cam_single, betas], max_iter=num_iters,
                                   tolerance_grad=config["optimizer"]["tolerance_grad"],
                                   tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
                                   line_search_fn="strong_wolfe")
