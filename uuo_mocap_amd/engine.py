@@ -256,7 +256,9 @@ class DeviceModel:
             if h is not None:
                 del self._batches[key]
                 h = None
-            cap = (max(int(count), 4) + 63) // 64 * 64  # whole 64s: a few more candidates next time re-use the batch
+            # small batches (the yaw hypotheses) exactly; candidate lists in whole 32s, so that a few more candidates in
+            # the next sequence re-use the batch instead of re-creating its workspaces
+            cap = max(int(count), 4) if count <= 8 else (int(count) + 31) // 32 * 32
             ptr = c_void_p()
             with torch.cuda.device(self.device):
                 check(self.lib.uuo_batch_create(self.handle, int(stage), int(F), int(M), cap, byref(ptr)), "uuo_batch_create")
