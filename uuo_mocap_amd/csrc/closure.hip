@@ -81,16 +81,22 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 // PART (with SPARSE): the part stage with its cached pose blend.  The body pose is a constant there, so nothing of the
 // pose-feature path exists - no posedirs gather (2.5 KB per item), no feature gradient, no body-rotation epilogue - and
 // the posed-template vertex is read from the cache k_part_fwd searched: v_posed = C[f][v] + S[v] . beta.
-template <bool SPARSE, bool PART = false>
+// NWV = waves per block.  One wave per frame (part stage: <= 16 items, the tail's steps never use more than 60 lanes)
+// leaves the per-block latency about where it is and lets four times as many frames be resident.
+template <bool SPARSE, bool PART = false, int NWV = BWD_NW>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   static_assert(SPARSE || !PART, "the part-stage variant is built on the sparse item loop");
-  __builtin_amdgcn_s_setprio(2);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  static_assert(NWV == BWD_NW || (SPARSE && PART && NWV == 1), "one-wave blocks exist for the part stage only");
+  constexpr int NT = NWV * 64, SLOTS = NWV * 4;  // threads per block, (wave, 16-lane group) item slots
+  // latency-bound kernel of a solve chain: do not queue behind co-resident MFMA waves.  (Not the one-wave part-stage form:
+  // a batch launches tens of thousands of those, and at a raised priority they starve the other group's solver kernels.)
+  if constexpr (NWV == BWD_NW) __builtin_amdgcn_s_setprio(2);
   __shared__ FrameLds L;
   __shared__ float sA[UUO_NUM_JOINTS * 12];
   __shared__ float spf[UUO_KB];
-  __shared__ float w_dA[BWD_SLOTS][UUO_NUM_JOINTS * 12];  // private accumulators: one per (wave, 16-lane group)
-  __shared__ float w_dpf[PART ? 1 : BWD_SLOTS][PART ? 256 : UUO_KB];  // (the shape-gradient tail borrows 240 entries from row 0)
-  __shared__ float w_red[BWD_SLOTS][16];
+  __shared__ float w_dA[SLOTS][UUO_NUM_JOINTS * 12];  // private accumulators: one per (wave, 16-lane group)
+  __shared__ float w_dpf[PART ? 1 : SLOTS][PART ? 256 : UUO_KB];  // (the shape-gradient tail borrows 240 entries from row 0)
+  __shared__ float w_red[SLOTS][16];
   __shared__ float sdA[UUO_NUM_JOINTS * 12];
   __shared__ float sdpf[UUO_KB];
   __shared__ float red[16];
@@ -111,13 +117,18 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       (&s_lvl_j[0][0])[tid] = (&tr_->level_j[0][0])[tid];
       (&s_lvl_p[0][0])[tid] = (&tr_->level_p[0][0])[tid];
     }
-    if (tid >= 64 && tid < 64 + UUO_NUM_JOINTS) s_nch[tid - 64] = tr_->nchild[tid - 64];
-    if (tid >= 128 && tid < 128 + UUO_NUM_JOINTS * 4) (&s_ch[0][0])[tid - 128] = (&tr_->child[0][0])[tid - 128];
+    if constexpr (NWV >= 4) {
+      if (tid >= 64 && tid < 64 + UUO_NUM_JOINTS) s_nch[tid - 64] = tr_->nchild[tid - 64];
+      if (tid >= 128 && tid < 128 + UUO_NUM_JOINTS * 4) (&s_ch[0][0])[tid - 128] = (&tr_->child[0][0])[tid - 128];
+    } else {
+      if (tid < UUO_NUM_JOINTS) s_nch[tid] = tr_->nchild[tid];
+      for (int i = tid; i < UUO_NUM_JOINTS * 4; i += NT) (&s_ch[0][0])[i] = (&tr_->child[0][0])[i];
+    }
   }
   if (a.frames) {  // block-uniform
     constexpr int NW = sizeof(FrameLds) / 4;
     float* dst_l = reinterpret_cast<float*>(&L);
-    for (int i = tid; i < NW; i += BWD_NW * 64) dst_l[i] = a.frames[(size_t)f * NW + i];
+    for (int i = tid; i < NW; i += NT) dst_l[i] = a.frames[(size_t)f * NW + i];
     __syncthreads();
   } else {
     frame_forward(a.src, a.tree, f, L);
@@ -131,14 +142,14 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     }
     spf[tid] = v;
   }
-  for (int i = tid; i < BWD_SLOTS * UUO_NUM_JOINTS * 12; i += BWD_NW * 64) (&w_dA[0][0])[i] = 0.f;
+  for (int i = tid; i < SLOTS * UUO_NUM_JOINTS * 12; i += NT) (&w_dA[0][0])[i] = 0.f;
   // w_dpf is written whole by plain stores at the end of the item loop; w_red's used entries likewise (sparse path: every
   // slot stores its 14 sums; dense path: waves 0..3 store theirs, the other slots must read as zero)
   if constexpr (!SPARSE) {
-    for (int i = tid; i < BWD_SLOTS * UUO_KB; i += BWD_NW * 64) (&w_dpf[0][0])[i] = 0.f;
-    for (int i = tid; i < BWD_SLOTS * 16; i += BWD_NW * 64) (&w_red[0][0])[i] = 0.f;
+    for (int i = tid; i < SLOTS * UUO_KB; i += NT) (&w_dpf[0][0])[i] = 0.f;
+    for (int i = tid; i < SLOTS * 16; i += NT) (&w_red[0][0])[i] = 0.f;
   }
-  if (tid < 28 * 4) (&sstat[0][0])[tid] = 0.f;
+  for (int i = tid; i < 28 * 4; i += NT) (&sstat[0][0])[i] = 0.f;
   __syncthreads();
 
   if (a.stop == 1) return;
@@ -262,10 +273,10 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       v += dpp_rot<0x121>(v);
       return v;
     };
-    const int rounds = (M + BWD_SLOTS - 1) / BWD_SLOTS;
+    const int rounds = (M + SLOTS - 1) / SLOTS;
     Item16 cur;
     for (int r = 0; r < rounds; ++r) {
-      fetch16(slot + BWD_SLOTS * r, cur);
+      fetch16(slot + SLOTS * r, cur);
       const float wgt = cur.wgt, d2 = cur.d2;
       float vp[3];
       if constexpr (PART) {
@@ -510,20 +521,20 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     if (tid < UUO_KB) {
       float acc = w_dpf[0][tid];
 #pragma unroll
-      for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dpf[w][tid];
+      for (int w = 1; w < SLOTS; ++w) acc += w_dpf[w][tid];
       sdpf[tid] = acc;
     }
   }
-  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += BWD_NW * 64) {
+  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += NT) {
     float acc = w_dA[0][i];
 #pragma unroll
-    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_dA[w][i];
+    for (int w = 1; w < SLOTS; ++w) acc += w_dA[w][i];
     sdA[i] = acc;
   }
   if (tid < 14) {
     float acc = w_red[0][tid];
 #pragma unroll
-    for (int w = 1; w < BWD_SLOTS; ++w) acc += w_red[w][tid];
+    for (int w = 1; w < SLOTS; ++w) acc += w_red[w][tid];
     red[tid] = acc;
   }
   __syncthreads();
@@ -551,7 +562,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       for (int e = 0; e < 9; ++e) po_pre[e] = po[e];
     }
   }
-  for (int t = tid; t < UUO_NUM_JOINTS * 12; t += BWD_NW * 64) {  // 288 pairs on 256 threads
+  for (int t = tid; t < UUO_NUM_JOINTS * 12; t += NT) {  // 288 pairs on 256 threads
     const int jj = t / 12, e = t - jj * 12;
     if (e < 9) {
       const int r = e / 3, c = e - r * 3;
@@ -568,10 +579,12 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   __syncthreads();
   BWD_STAMP(5);
   {
-    const int role = tid >> 6;             // 0: parents of the step, 1: children of the step
     const int rl = tid & 63, k = rl / 12, e = rl - k * 12;
     const int max_depth = tree->max_depth;
     for (int d = max_depth - 1; d >= 0; --d) {
+     // the two roles of a step touch disjoint entries (parents: their own totals; children: their dR / dJ), so one wave
+     // can take them one after the other
+     for (int role = (NWV >= 2 ? (tid >> 6) : 0); role < 2; role += (NWV >= 2 ? 2 : 1)) {
       if (role == 0 && rl < 12 * UUO_LEVEL_W && k < s_lvl_n[d]) {  // pull from the children (depth d + 1, totals final)
         const int jj = s_lvl_j[d][k];
         const int nch = s_nch[jj];
@@ -614,6 +627,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
           sdJ[jj][aa] += fmaf(L.GR[p][6 + aa], sdGt[jj][2], fmaf(L.GR[p][3 + aa], sdGt[jj][1], L.GR[p][aa] * sdGt[jj][0]));
         }
       }
+     }
       __syncthreads();
     }
   }
@@ -625,9 +639,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
 
   BWD_STAMP(6);
   // shape gradient of this frame: direct (blend shapes) + joint path (240 threads: one (joint, beta) pair each)
-  if (tid < 240) {
-    const int jj = tid / 10, l = tid - jj * 10;
-    w_dpf[0][tid] = fmaf(tree->JS[jj][2][l], sdJ[jj][2], fmaf(tree->JS[jj][1][l], sdJ[jj][1], tree->JS[jj][0][l] * sdJ[jj][0]));
+  for (int t = tid; t < 240; t += NT) {
+    const int jj = t / 10, l = t - jj * 10;
+    w_dpf[0][t] = fmaf(tree->JS[jj][2][l], sdJ[jj][2], fmaf(tree->JS[jj][1][l], sdJ[jj][1], tree->JS[jj][0][l] * sdJ[jj][0]));
   }
   __syncthreads();
   if (tid < 10) {
@@ -771,10 +785,10 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
   bwd_body<true>(a);
 }
 // part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
-__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part(BwdArgs a) { bwd_body<true, true>(a); }
-__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
+__global__ __launch_bounds__(64) void k_bwd_part(BwdArgs a) { bwd_body<true, true, 1>(a); }
+__global__ __launch_bounds__(64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
   UUO_BATCH_PICK(BwdArgs, batch)
-  bwd_body<true, true>(a);
+  bwd_body<true, true, 1>(a);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -883,7 +897,7 @@ int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int co
   if (op == UUO_OP_BWD) {
     hipLaunchKernelGGL(k_bwd_sparse_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
   } else if (op == UUO_OP_BWD_PART) {
-    hipLaunchKernelGGL(k_bwd_part_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
+    hipLaunchKernelGGL(k_bwd_part_b, dim3(gx, gy, count), dim3(64), 0, s, (const BwdArgs*)d_args);
   } else if (op == UUO_OP_FIN) {
     hipLaunchKernelGGL(k_finalize_b, dim3(gx, gy, count), dim3(1024), 0, s, (const FinArgs*)d_args);
   } else {
@@ -1165,7 +1179,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
   if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && m->nnz <= 4 && !part_general) {
     a.C = fit->pose_cache;
-    if (!uuo_record(UUO_OP_BWD_PART, F, 1, a)) hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    if (!uuo_record(UUO_OP_BWD_PART, F, 1, a)) hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(64), 0, s, a);
   } else if (m->nnz <= 4) {
     if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else {
