@@ -785,10 +785,17 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
   bwd_body<true>(a);
 }
 // part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
-__global__ __launch_bounds__(64) void k_bwd_part(BwdArgs a) { bwd_body<true, true, 1>(a); }
-__global__ __launch_bounds__(64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
+// two forms: one wave per frame for <= 16 markers (the candidate search: four items per pass), four waves per frame above
+// that (hmr_full.yaml: 50 markers on the full skeleton would be 13 passes of one wave)
+__global__ __launch_bounds__(64) void k_bwd_part1(BwdArgs a) { bwd_body<true, true, 1>(a); }
+__global__ __launch_bounds__(64) void k_bwd_part1_b(const BwdArgs* __restrict__ batch) {
   UUO_BATCH_PICK(BwdArgs, batch)
   bwd_body<true, true, 1>(a);
+}
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part(BwdArgs a) { bwd_body<true, true>(a); }
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
+  UUO_BATCH_PICK(BwdArgs, batch)
+  bwd_body<true, true>(a);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -896,8 +903,11 @@ __global__ __launch_bounds__(1024) void k_finalize_b(const FinArgs* __restrict__
 int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int count, int gx, int gy) {
   if (op == UUO_OP_BWD) {
     hipLaunchKernelGGL(k_bwd_sparse_b, dim3(gx, gy, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
-  } else if (op == UUO_OP_BWD_PART) {
-    hipLaunchKernelGGL(k_bwd_part_b, dim3(gx, gy, count), dim3(64), 0, s, (const BwdArgs*)d_args);
+  } else if (op == UUO_OP_BWD_PART) {  // gy of the record = waves per frame (1 or BWD_NW; one value per batch: same M)
+    if (gy == 1)
+      hipLaunchKernelGGL(k_bwd_part1_b, dim3(gx, 1, count), dim3(64), 0, s, (const BwdArgs*)d_args);
+    else
+      hipLaunchKernelGGL(k_bwd_part_b, dim3(gx, 1, count), dim3(BWD_NW * 64), 0, s, (const BwdArgs*)d_args);
   } else if (op == UUO_OP_FIN) {
     hipLaunchKernelGGL(k_finalize_b, dim3(gx, gy, count), dim3(1024), 0, s, (const FinArgs*)d_args);
   } else {
@@ -1179,7 +1189,13 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
   if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && m->nnz <= 4 && !part_general) {
     a.C = fit->pose_cache;
-    if (!uuo_record(UUO_OP_BWD_PART, F, 1, a)) hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(64), 0, s, a);
+    const int waves = M <= 16 ? 1 : BWD_NW;
+    if (!uuo_record(UUO_OP_BWD_PART, F, waves, a)) {
+      if (waves == 1)
+        hipLaunchKernelGGL(k_bwd_part1, dim3(F), dim3(64), 0, s, a);
+      else
+        hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    }
   } else if (m->nnz <= 4) {
     if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else {
