@@ -1559,6 +1559,16 @@ def test_lockstep_batch_is_bit_identical_to_solving_one_by_one(smpl, dev):
 
     check(part_problems, lambda p, i: p.pack(torch.zeros(1, 1, 1, device=dev), trans, o_betas), max_iter=60, lr=1.0)
 
+    # eleven candidates: from eight problems on a batch steps two groups alternately, each on its own stream
+    from uuo_mocap_amd.markers_utils import get_sub_hierachies
+
+    few = subtrees
+    subtrees = [list(st_) for st_ in get_sub_hierachies(smpl.tables.parents, 3)[::2][:11]]
+    assert len(subtrees) == 11
+    check(part_problems, lambda p, i: p.pack(torch.full((1, 1, 1), 0.1 * i, device=dev), trans + 0.002 * i, o_betas),
+          max_iter=40, lr=1.0)
+    subtrees = few
+
     # ranking scores of the solved candidates: the batched kernel against the operator route (SMPL forward, two searches)
     from uuo_mocap_amd.engine import part_scores_batch
     from uuo_mocap_amd.losses import chamfer_distance
