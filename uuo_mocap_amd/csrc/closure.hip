@@ -826,6 +826,25 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
   __shared__ double sh[32][32];
   const int tid = threadIdx.x;
   const int comp = tid & 31, grp = tid >> 5;  // 32 groups of frames, components 0..UUO_FP-1
+  // thread 0's inputs for the tail (shape prior, direction entries, the part of the report block the direction kernels
+  // left) are on their way while the partials are summed
+  float pb[10], po[10], pd[10], pdz = 0.f;
+  unsigned long long rep_pre[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < 10; ++l) {
+      pb[l] = a.betas[l];
+      po[l] = a.o_betas[l];
+      pd[l] = a.dir_betas ? a.dir_betas[l] : 0.f;
+    }
+    if (a.dir_z) pdz = a.dir_z[0];
+    if (a.stats && a.rep_host) {
+      const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats.get()) - 1;
+      rep_pre[0] = blk[0];
+#pragma unroll
+      for (int i = 6; i < 10; ++i) rep_pre[i - 5] = blk[i];
+    }
+  }
   double acc = 0.0;
   if (comp < UUO_FP) {
     const bool is_max = (comp == 19);
@@ -855,11 +874,11 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
   if (tid == 0) {
     double bsq = 0.0, sd = sh[0][16], s1 = sh[0][17], s2 = sh[0][18], sm = sh[0][19];
     for (int l = 0; l < 10; ++l) {
-      const double diff = (double)a.betas[l] - (double)a.o_betas[l];
+      const double diff = (double)pb[l] - (double)po[l];
       bsq += diff * diff;
       const float gb = (float)(sh[0][4 + l] + 2.0 * a.cbetas * diff);
       a.g_betas[l] = gb;
-      if (a.dir_betas) sd += (double)gb * (double)a.dir_betas[l];
+      if (a.dir_betas) sd += (double)gb * (double)pd[l];
       s1 += fabs((double)gb);
       s2 += (double)gb * (double)gb;
       sm = fmax(sm, fabs((double)gb));
@@ -869,7 +888,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     if (a.stage == UUO_STAGE_PART) {
       const float gz = (float)sh[0][1];
       a.g_z[0] = gz;
-      if (a.dir_z) sd += (double)gz * (double)a.dir_z[0];
+      if (a.dir_z) sd += (double)gz * (double)pdz;
       s1 += fabs((double)gz);
       s2 += (double)gz * (double)gz;
       sm = fmax(sm, fabs((double)gz));
@@ -883,9 +902,13 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       if (a.rep_host) {
         // the solver's read-back block {max|d| bits, pad, out[9]} starts one word before stats; words 1..5 are
         // the values just written, the rest was left by the direction kernels of this iteration
-        const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats.get()) - 1;
+        // (the block is {max|d| bits, stats[0..4], four more words}; nothing is read back from device memory here)
+        const double five[5] = {(double)lossf, sd, sm, s1, s2};
+        a.rep_host[0] = rep_pre[0];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) a.rep_host[i] = blk[i];
+        for (int i = 0; i < 5; ++i) a.rep_host[1 + i] = (unsigned long long)__double_as_longlong(five[i]);
+#pragma unroll
+        for (int i = 6; i < 10; ++i) a.rep_host[i] = rep_pre[i - 5];
         __threadfence_system();
         __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
