@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction_b(const LbDirArgs* 
 }
 
 
-// test objectives for the optimiser itself (tests/test_lbfgs.py): 0 = convex quadratic with a spread
+// test objectives for the optimiser itself (tests/test_gpu_parity.py::test_lbfgs_*): 0 = convex quadratic with a spread
 // spectrum, 1 = chained Rosenbrock.  loss/grad are computed by one block (n is small in the tests).
 __global__ __launch_bounds__(256) void k_test_objective(int kind, int n, const float* __restrict__ x,
                                                          float* __restrict__ loss, float* __restrict__ grad) {
