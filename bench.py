@@ -69,6 +69,9 @@ def parse():
                          "are spread over the ranks (strong scaling, useful up to num_root_orient_angles ranks); "
                          "shared_betas = one sequence per rank, one shape vector for all of them (extension: joint L-BFGS, "
                          "one small all_gather per evaluation)")
+    ap.add_argument("--hypothesis-lockstep", action="store_true",
+                    help="step the yaw hypotheses as one lock-step batch instead of one host thread + stream each "
+                         "(multimodal_video_mocap(execution={'hypothesis_lockstep': True}); same results)")
     return ap.parse_args()
 
 
@@ -288,6 +291,8 @@ def main():
 
     tables = synthetic_smpl(0)
     cfg = packaged_config(args.config)
+    if args.hypothesis_lockstep:
+        cfg["execution"] = {"hypothesis_lockstep": True}
     smpl = SmplInference(dev, tables=tables)
     F, M = args.frames, args.markers
     n_seq = args.warmup + args.steps

@@ -83,6 +83,14 @@ int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d_x, const f
 int uuo_assign_mean_argmin(void* stream, int F, int M, int V, const float* d_verts, const float* d_markers,
                            const uint8_t* d_valid, int32_t* d_idx, void* d_workspace_u64);
 
+/* ---- rigidity matrix of the marker segmentation ---------------------------------------------------
+ * Replaces the double loop of segment_rigid (src/video_mocap/markers/markers_utils.py:254-259):
+ *   d_std[i*M+j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1))     d_points [F,M,3] float32
+ * in numpy's float32 arithmetic and numpy's summation order (pairwise summation, 8 accumulators per 128-element block,
+ * 8192-element reduction chunks), so the values -- which the average-linkage clustering cuts at 5 mm -- are bit-equal
+ * to the reference's.  d_std [M,M] float32 (the reference stores them in a float64 matrix: exact).  Asynchronous. */
+int uuo_rigid_distance_std(void* stream, int F, int M, const float* d_points, float* d_std);
+
 /* ---- EXTENSION: soft-assignment (soft-min) nearest neighbour ----------------------------------------
  * Not reference behaviour (the reference's chamfer term is the hard K=1 minimum above; BASELINE's north star names a
  * soft assignment).  softmin[n,i] = -tau log sum_j exp(-|x[n,i]-y[n,j]|^2 / tau); d_dmin / d_sumexp ([N,P1]) are the
@@ -179,6 +187,27 @@ typedef void (*uuo_eval_callback_t)(void* user, int eval_index, float loss, cons
 int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
                     const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
                     void* cb_user);
+
+/* EXTENSION (BASELINE configs[3] "shared beta over xGMI"; NOT reference behaviour -- the reference fits every sequence with
+ * its own betas, test/test.py:57-112): uuo_lbfgs_solve called together by the `world` ranks of a group, one stage problem
+ * (same stage) per rank, as ONE joint L-BFGS problem whose 10 betas are shared by all ranks' sequences.  Each rank keeps its
+ * own parameters and a replica of the betas on its own device; the driver is uuo_lbfgs_solve's, and all that crosses the
+ * ranks goes through `gather` -- called on the host, from the calling thread, at the same points on every rank:
+ *   once at the start (the betas themselves: rank 0's values win), once per closure evaluation (16 doubles: loss, g.d,
+ *   gradient norms of the rank's own parameters, max|d|, its 10 betas-gradient entries) and once per iteration (the new
+ *   Gram rows of the history, 627 doubles).  `gather(user, mine, n, all)` must fill all[r*n .. r*n+n) with rank r's `mine`
+ *   for r = 0..world-1 (an all_gather: RCCL / gloo through torch.distributed in the Python mirror) and return 0.  Every rank
+ *   reduces the gathered tables in rank order, so all ranks take bit-identical decisions and end with bit-identical betas.
+ * With world = 1 the result is bit-identical to uuo_lbfgs_solve (chamfer and marker stages). */
+typedef int (*uuo_gather_fn)(void* user, const double* mine, int n, double* all);
+typedef struct {
+  uuo_gather_fn gather;
+  void* user;
+  int32_t rank, world;
+} uuo_shared_t;
+int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                           const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
+                           uuo_eval_callback_t cb, void* cb_user);
 
 /* The same driver for a closure composed on the host (the reference's optional objectives: the 2D reprojection fit,
  * utils/hmr_utils.py:170-425 (step at :367); the chamfer / marker / part stages with velocity, ground, foot-contact,

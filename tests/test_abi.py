@@ -119,22 +119,11 @@ def test_transforms_match_oracle():
     torch.testing.assert_close(T.compute_root_orient_z(a), p3d_ref.axis_angle_to_matrix(z))
 
 
-def test_segment_rigid_and_subtrees_match_oracle(tables):
+def test_subtrees_match_oracle(tables):
+    """(segment_rigid's rigidity matrix is a GPU kernel since round 3: tests/test_gpu_parity.py checks it against numpy.)"""
     from oracle import stages_ref
     from uuo_mocap_amd import markers_utils as MU
-    from uuo_mocap_amd.synthetic import make_sequence
 
-    pts = make_sequence(tables, seed=9, num_frames=20, num_markers=14).markers.get_points()
-    assert MU.segment_rigid(pts) == stages_ref.segment_rigid(pts)
-    # the all-pairs evaluation of the rigidity matrix is bit-equal to the reference's per-pair loop
-    rng = np.random.default_rng(3)
-    for F, M in ((300, 50), (20, 14), (7, 3), (1, 4)):
-        p = (rng.standard_normal((F, M, 3)) * 0.4).astype(np.float32)
-        loop = np.zeros((M, M))
-        for i in range(M):
-            for j in range(M):
-                loop[i, j] = np.std(np.linalg.norm(p[:, i] - p[:, j], axis=-1))
-        assert np.array_equal(MU.rigid_distance_matrix(p), loop)
     for k in (2, 5, 12, 24):
         assert MU.get_sub_hierachies(tables.parents, k) == stages_ref.get_sub_hierarchies(tables.parents, k)
 
@@ -258,3 +247,65 @@ def test_dropin_package_exposes_the_reference_module_paths():
         for k in [k for k in sys.modules if k == "video_mocap" or k.startswith("video_mocap.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def _staging(ops, region_cap=4096):
+    """Runs a script against the batch's pinned-blob bookkeeping (csrc/uuo_common.h UuoStaging) through the debug library's
+    host-only hook; returns per op (flag, offset, pending bits, used bytes of the op's region)."""
+    dbg = _lib.load_debug()
+    arr = np.ascontiguousarray(np.asarray(ops, dtype=np.int64).reshape(-1, 3))
+    out = np.zeros((arr.shape[0], 4), dtype=np.int64)
+    rc = dbg.uuo_debug_staging_script(arr.ctypes.data, arr.shape[0], region_cap, out.ctypes.data)
+    assert rc == 0, dbg.uuo_last_error()
+    return [tuple(int(v) for v in row) for row in out]
+
+
+FLUSH, APPEND, REPORT, SYNCED = 0, 1, 2, 3
+
+
+def test_batch_staging_state_machine():
+    """Host logic behind the GPU memory fault of round 2 (gpurun_out/r2_t9.log: the score launch re-used the pinned
+    argument blob while the previous flush's host-to-device copy was still pending), tested without a GPU: a flush that
+    follows a flush with no report in between must synchronise first; a report clears that; the two regions (stepping
+    groups / streams) are independent; structs appended behind a flush never overwrite it and never need a wait."""
+    # flush -> flush without a wait: the second one has to synchronise; after a report it does not
+    r = _staging([(FLUSH, 0, 1000), (FLUSH, 0, 500), (REPORT, 0, 0), (FLUSH, 0, 700)])
+    assert [x[0] for x in r] == [0, 1, 0, 0]
+    assert r[1][2] == 1 and r[2][2] == 0 and r[3][2] == 1 and r[3][3] == 700
+    # an empty flush (a round in which nothing was recorded) neither waits nor changes anything
+    r = _staging([(FLUSH, 0, 1000), (FLUSH, 0, 0), (FLUSH, 0, 10)])
+    assert [x[0] for x in r] == [0, 0, 1] and r[1][3] == 1000
+    # regions are independent: region 1's flushes neither see nor clear region 0's pending copy
+    r = _staging([(FLUSH, 0, 100), (FLUSH, 1, 100), (REPORT, 1, 0), (FLUSH, 1, 100), (FLUSH, 0, 100)])
+    assert [x[0] for x in r] == [0, 0, 0, 0, 1]
+    assert r[1][2] == 3 and r[2][2] == 1
+    # flush then scores: the score structs go behind the flush's (256-byte aligned), also behind an earlier append, need no
+    # wait, and keep the region pending so that the NEXT flush waits for them too
+    r = _staging([(FLUSH, 0, 1000), (APPEND, 0, 300), (APPEND, 0, 100), (FLUSH, 0, 50)])
+    assert r[1][:2] == (1, 1024) and r[2][:2] == (1, 1536) and r[3][0] == 1
+    # an append on a region whose flush has already reported still lands behind it (its device copy may be in use by kernels)
+    r = _staging([(FLUSH, 0, 1000), (REPORT, 0, 0), (APPEND, 0, 300), (FLUSH, 0, 10)])
+    assert r[2][:3] == (1, 1024, 1) and r[3][0] == 1
+    # overflow is refused, state unchanged
+    r = _staging([(FLUSH, 0, 4000), (APPEND, 0, 200)], region_cap=4096)
+    assert r[1][0] == 0 and r[1][3] == 4000
+    # error exit / end of a solve: everything was synchronised
+    r = _staging([(FLUSH, 0, 100), (FLUSH, 1, 100), (SYNCED, 0, 0), (FLUSH, 0, 100), (FLUSH, 1, 100)])
+    assert [x[0] for x in r] == [0, 0, 0, 0, 0]
+
+
+def test_model_with_dense_skin_weights_is_refused():
+    """SMPL has at most four non-zero skinning weights per vertex and every kernel is built on that; a model that has more
+    is refused at creation with a message instead of reaching a slow generic path (round 2 shipped one that spilled)."""
+    lib = _lib.load()
+    V = 32
+    rng = np.random.default_rng(0)
+    W = np.zeros((V, 24), np.float32)
+    W[:, :5] = 0.2  # five non-zero weights
+    arrs = [rng.standard_normal((V, 3)).astype(np.float32), np.zeros((V, 3, 10), np.float32),
+            np.zeros((207, V * 3), np.float32), np.full((24, V), 1.0 / V, np.float32), W,
+            np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int64),
+            np.zeros(21, np.int64)]
+    handle = ctypes.c_void_p()
+    rc = lib.uuo_model_create(*[a.ctypes.data for a in arrs], V, ctypes.byref(handle))
+    assert rc == -22 and b"non-zero skinning weights" in lib.uuo_last_error()

@@ -277,6 +277,81 @@ def test_fused_part_forward_is_bit_identical_to_skinning_then_searching(smpl, de
         assert np.array_equal(nn_p.cpu().numpy(), got[0][2])
 
 
+@pytest.mark.parametrize("F,M,parts", [(300, 50, tuple(range(24))), (37, 23, (0, 3, 6, 9, 12, 15)), (21, 17, (20, 22))])
+def test_part_stage_pruned_search_is_bit_identical_to_brute_force(smpl, dev, F, M, parts):
+    """Part stage with more than 16 markers (hmr_full.yaml: 50 markers on the full skeleton; no fused forward there): the
+    candidate's vertices are written in subset order with a box per 16 candidates and searched by the box-pruned kernel,
+    against the brute-force subset search it replaces (UUO_PART_BRUTE=1 in the debug flavour).  Loss, gradient and the
+    reported candidate positions agree bit for bit, on the first call (no previous assignment: every pair enumerated) and
+    on later ones (pruned by the previous assignment), at three points."""
+    import ctypes
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd.engine import PartProblem, _ptr, current_stream
+
+    dbg = _lib.load_debug()
+    seq = make_sequence(smpl.tables, seed=7, num_frames=F, num_markers=M)
+    cfg = packaged_config("hmr_full")
+    markers = _t(np.nan_to_num(seq.markers.get_points()), dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    vertex_labels = torch.argmax(torch.as_tensor(smpl.tables.lbs_weights), dim=-1)
+    vidx = torch.cat([(vertex_labels == j).nonzero(as_tuple=True)[0] for j in parts]).to(dev)
+    prob = PartProblem(smpl, markers, seq.img_smpl.pose_body.to(dev), o_betas, seq.img_smpl.root_orient.to(dev), vidx, cfg)
+    gen = torch.Generator().manual_seed(F + M)
+    for k in range(3):
+        x = prob.pack(torch.full((1, 1, 1), 0.3 - 0.35 * k, device=dev),
+                      torch.median(markers, dim=1)[0] + 0.02 * torch.randn(F, 3, generator=gen).to(dev),
+                      o_betas + 0.3 * torch.randn(1, 10, generator=gen).to(dev))
+        got = []
+        for brute in ("0", "1"):
+            os.environ["UUO_PART_BRUTE"] = brute
+            try:
+                loss = torch.empty(1, device=dev)
+                grad = torch.empty(prob.n, device=dev)
+                nn = torch.full((F, M), -1, dtype=torch.int32, device=dev)
+                rc = dbg.uuo_closure_eval(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), _ptr(loss),
+                                          _ptr(grad), _ptr(nn))
+                assert rc == 0, dbg.uuo_last_error()
+                torch.cuda.synchronize()
+                got.append((loss.cpu().numpy(), grad.cpu().numpy(), nn.cpu().numpy()))
+            finally:
+                os.environ.pop("UUO_PART_BRUTE", None)
+        assert np.isfinite(got[0][0]).all() and got[0][2].min() >= 0 and got[0][2].max() < vidx.numel()
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a, b)
+        loss_p, grad_p, nn_p = prob.evaluate(x)  # the product library (no knob: always the pruned search)
+        assert np.float32(loss_p) == got[0][0][0] and np.array_equal(grad_p.cpu().numpy(), got[0][1])
+        assert np.array_equal(nn_p.cpu().numpy(), got[0][2])
+
+
+def test_rigidity_matrix_kernel_is_bit_equal_to_numpy(smpl, dev):
+    """uuo_rigid_distance_std (segment_rigid's O(M^2 F) matrix on the GPU) against the reference's per-pair
+    np.std(np.linalg.norm(...)) loop (markers/markers_utils.py:254-259): bit-equal for frame counts on every branch of numpy's
+    pairwise summation (< 8, one block, a sequential tail, several levels of the split, more than one 8192-element reduction
+    chunk), and the clustering built on it equals the oracle's on marker sequences."""
+    from oracle import stages_ref
+    from uuo_mocap_amd import markers_utils as MU
+
+    rng = np.random.default_rng(3)
+    for F, M in ((300, 50), (450, 39), (20, 14), (7, 3), (1, 4), (8, 5), (9, 5), (127, 6), (128, 6), (129, 6), (131, 3),
+                 (257, 4), (1000, 7), (8192, 3), (8193, 3), (20011, 2)):
+        p = (rng.standard_normal((F, M, 3)) * 0.4).astype(np.float32)
+        if F == 450:
+            p[100:140, 5] = 0.0  # missing markers are exact zeros
+        loop = np.zeros((M, M))
+        for i in range(M):
+            for j in range(M):
+                loop[i, j] = np.std(np.linalg.norm(p[:, i] - p[:, j], axis=-1))
+        got = MU.rigid_distance_matrix(torch.from_numpy(p).to(dev))
+        assert got.dtype == np.float64 and np.array_equal(got, loop), (F, M, np.abs(got - loop).max())
+        assert np.array_equal(MU.rigid_distance_matrix(p, device=dev), loop)  # host array in, same result
+    for seed, F, M in ((9, 20, 14), (2, 300, 50), (4, 60, 10)):
+        pts = make_sequence(smpl.tables, seed=seed, num_frames=F, num_markers=M, limb_only=(M == 10)).markers.get_points()
+        pts = np.nan_to_num(pts).astype(np.float32)
+        assert MU.segment_rigid(torch.from_numpy(pts).to(dev)) == stages_ref.segment_rigid(pts)
+
+
 def test_device_lbfgs_with_a_host_closure_follows_torch(dev):
     """DeviceLBFGS (uuo_lbfgs_minimize: the device driver calling back a closure composed in Python) against
     torch.optim.LBFGS on the same closure: a well-scaled coupled quadratic over three parameter tensors, one of which

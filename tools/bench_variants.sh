@@ -2,7 +2,7 @@
 set -e
 for v in "0 1" "1 1" "1 2" "1 3" "0 3"; do
   set -- $v
-  UUO_HYPOTHESIS_LOCKSTEP=$1 python bench.py --steps 6 --warmup 1 --inflight $2 --no-cpu-baseline --no-other-configs > gpurun_out/bv_$1_$2.log 2>gpurun_out/bv_$1_$2.err || { tail -5 gpurun_out/bv_$1_$2.err; exit 1; }
+  python bench.py $([ "$1" = 1 ] && echo --hypothesis-lockstep) --steps 6 --warmup 1 --inflight $2 --no-cpu-baseline --no-other-configs > gpurun_out/bv_$1_$2.log 2>gpurun_out/bv_$1_$2.err || { tail -5 gpurun_out/bv_$1_$2.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/bv_$1_$2.log").read().strip().splitlines()[-1])

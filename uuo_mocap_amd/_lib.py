@@ -52,6 +52,7 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "uuo_nn_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p]),
+    "uuo_rigid_distance_std": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "uuo_assign_mean_argmin": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "uuo_soft_nn_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
@@ -90,6 +91,7 @@ _DEBUG_SIGNATURES = {
     "uuo_debug_nn_flags": (c_int, [c_void_p, c_void_p]),
     "uuo_debug_small_coeffs": (c_int, [c_int, c_int, c_int, c_void_p]),
     "uuo_debug_time_small": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
+    "uuo_debug_staging_script": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p]),
 }
 
 # uuo_closure_fn (include/uuo_hip.h): int closure(user, stream, d_x_eval, d_loss, d_grad)

@@ -16,7 +16,6 @@ struct BwdArgs {
   uuo_gptr<const float> PT;
   uuo_gptr<const float> ST;
   uuo_gptr<const float> vt;
-  uuo_gptr<const float> Wd;
   uuo_gptr<const int> Wi;
   uuo_gptr<const float> Ww;
   uuo_gptr<const UuoTree> tree;
@@ -83,10 +82,9 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 // the posed-template vertex is read from the cache k_part_fwd searched: v_posed = C[f][v] + S[v] . beta.
 // NWV = waves per block.  One wave per frame (part stage: <= 16 items, the tail's steps never use more than 60 lanes)
 // leaves the per-block latency about where it is and lets four times as many frames be resident.
-template <bool SPARSE, bool PART = false, int NWV = BWD_NW>
+template <bool PART = false, int NWV = BWD_NW>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
-  static_assert(SPARSE || !PART, "the part-stage variant is built on the sparse item loop");
-  static_assert(NWV == BWD_NW || (SPARSE && PART && NWV == 1), "one-wave blocks exist for the part stage only");
+  static_assert(NWV == BWD_NW || (PART && NWV == 1), "one-wave blocks exist for the part stage only");
   constexpr int NT = NWV * 64, SLOTS = NWV * 4;  // threads per block, (wave, 16-lane group) item slots
   // latency-bound kernel of a solve chain: do not queue behind co-resident MFMA waves.  (Not the one-wave part-stage form:
   // a batch launches tens of thousands of those, and at a raised priority they starve the other group's solver kernels.)
@@ -143,12 +141,8 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     spf[tid] = v;
   }
   for (int i = tid; i < SLOTS * UUO_NUM_JOINTS * 12; i += NT) (&w_dA[0][0])[i] = 0.f;
-  // w_dpf is written whole by plain stores at the end of the item loop; w_red's used entries likewise (sparse path: every
-  // slot stores its 14 sums; dense path: waves 0..3 store theirs, the other slots must read as zero)
-  if constexpr (!SPARSE) {
-    for (int i = tid; i < SLOTS * UUO_KB; i += NT) (&w_dpf[0][0])[i] = 0.f;
-    for (int i = tid; i < SLOTS * 16; i += NT) (&w_red[0][0])[i] = 0.f;
-  }
+  // w_dpf is written whole by plain stores at the end of the item loop; w_red's used entries likewise (every slot stores
+  // its 14 sums)
   for (int i = tid; i < 28 * 4; i += NT) (&sstat[0][0])[i] = 0.f;
   __syncthreads();
 
@@ -160,8 +154,6 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     tr[1] = a.src.trans[(size_t)f * 3 + 1];
     tr[2] = a.src.trans[(size_t)f * 3 + 2];
   }
-  float acc_dpf[4] = {0.f, 0.f, 0.f, 0.f};
-  float acc_db = 0.f, acc_dt = 0.f, acc_loss = 0.f;
   // direction entries this thread will need for the fused g.d (fetched now, consumed after the item loop)
   float dpre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (a.dir) {
@@ -181,7 +173,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     }
   }
 
-  if constexpr (SPARSE) {
+  {
     // Four items per wave, one per 16-lane group: the per-item scalar work (blended transform, residual, dv) used
     // to be computed redundantly by all 64 lanes for ONE item at a time; now the four DPP rows of a wave carry four
     // items, each sub-lane owning 13 of the 208 pose-blend rows (k = sl + 16 t), and the sums are row reductions
@@ -356,160 +348,6 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     if (sl == 0) w_red[slot][0] = acc_loss16;
     if (sl < 3) w_red[slot][1 + sl] = acc_dt16;
     if (sl < 10) w_red[slot][4 + sl] = acc_db16;
-  } else {
-  // Items are software-pipelined: every global load of item m + BWD_NW (assignment key, marker, the vertex's
-    // posedirs rows, template, shape rows, skin weights) is issued before item m is processed, so the L2/MALL
-    // round trips of the gather overlap the arithmetic and the wave reductions of the previous item.
-    struct Item {
-      float p[3][4];
-      float x0, x1, x2, wgt, d2, vt0, vt1, vt2, stv;
-      int vi;
-      int4 wi;
-      float4 ww;
-      bool on;
-    };
-    auto fetch = [&](int m, Item& q) {
-      q.on = false;
-      q.wgt = 1.f;
-      q.d2 = 0.f;
-      if (m >= M) return;
-      int vi;
-      if (a.stage == UUO_STAGE_MARKER) {
-        q.wgt = a.mask[(size_t)f * M + m];
-        vi = a.assign[m];
-      } else {
-        const unsigned long long key = a.nn[(size_t)f * M + m];
-        q.d2 = __uint_as_float((unsigned)(key >> 32));
-        vi = (int)(unsigned)(key & 0xFFFFFFFFull);
-        if (a.stage == UUO_STAGE_PART)
-          vi = a.subset[vi];
-        else
-          q.wgt = a.mask[(size_t)f * M + m];
-      }
-      if (q.wgt == 0.f) return;  // wave-uniform
-      q.on = true;
-      q.vi = vi;
-      const float* px = a.markers + ((size_t)f * M + m) * 3;
-      q.x0 = px[0];
-      q.x1 = px[1];
-      q.x2 = px[2];
-      const float* pt = a.PT + (size_t)vi * 3 * UUO_KB;
-  #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-  #pragma unroll
-        for (int r = 0; r < 3; ++r) q.p[c][r] = pt[c * UUO_KB + lane + 64 * r];
-        q.p[c][3] = (lane < UUO_KB - 192) ? pt[c * UUO_KB + lane + 192] : 0.f;
-      }
-      q.vt0 = a.vt[(size_t)vi * 3];
-      q.vt1 = a.vt[(size_t)vi * 3 + 1];
-      q.vt2 = a.vt[(size_t)vi * 3 + 2];
-      q.stv = (lane < 30) ? a.ST[(size_t)vi * 30 + lane] : 0.f;  // lane 10 c + l holds S[vi][c][l]
-      if (SPARSE) {
-        q.wi = *reinterpret_cast<const int4*>(a.Wi + (size_t)vi * 4);
-        q.ww = *reinterpret_cast<const float4*>(a.Ww + (size_t)vi * 4);
-      }
-    };
-    const float f0 = spf[lane], f1 = spf[lane + 64], f2 = spf[lane + 128],
-                f3 = (lane < UUO_KB - 192) ? spf[lane + 192] : 0.f;
-    const float beta_l = L.beta[lane % 10];
-    Item cur, nxt;
-    fetch(wave, cur);
-    for (int m = wave; m < M; m += BWD_NW) {
-      fetch(m + BWD_NW, nxt);
-      if (cur.on) {
-        const float wgt = cur.wgt, d2 = cur.d2;
-        const int vi = cur.vi;
-        const float x0 = cur.x0, x1 = cur.x1, x2 = cur.x2;
-        // v_posed of the touched vertex: template + shape blend (lanes 0..29 hold the 3x10 shape rows) + pose blend
-        const float sprod = cur.stv * beta_l;
-        float vp[3];
-  #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float part = fmaf(cur.p[c][3], f3, fmaf(cur.p[c][2], f2, fmaf(cur.p[c][1], f1, cur.p[c][0] * f0)));
-          const float offs = wave_sum_fast(part);
-          const float sb = wave_sum_fast((lane >= 10 * c && lane < 10 * c + 10) ? sprod : 0.f);
-          const float vs = (c == 0) ? cur.vt0 : ((c == 1) ? cur.vt1 : cur.vt2);
-          vp[c] = offs + (vs + sb);
-        }
-        // blended skinning matrix
-        float T[12];
-  #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        int wj[4];
-        float ww[4];
-        if (SPARSE) {
-          wj[0] = cur.wi.x; wj[1] = cur.wi.y; wj[2] = cur.wi.z; wj[3] = cur.wi.w;
-          ww[0] = cur.ww.x; ww[1] = cur.ww.y; ww[2] = cur.ww.z; ww[3] = cur.ww.w;
-  #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-  #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], sA[wj[n] * 12 + e], T[e]);
-          }
-        } else {
-          for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
-            const float w = a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn];
-  #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = fmaf(w, sA[jn * 12 + e], T[e]);
-          }
-        }
-        const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
-        const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
-        const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
-        const float dx = x0 - vx, dy = x1 - vy, dz = x2 - vz;
-        float g[3];
-        float loss_item;
-        if (a.stage == UUO_STAGE_MARKER) {
-          const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
-          const float e = rr - a.d0;
-          loss_item = wgt * (e * e);
-          const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
-          g[0] = sc * dx;
-          g[1] = sc * dy;
-          g[2] = sc * dz;
-        } else {
-          loss_item = wgt * d2;
-          const float sc = -a.cg * wgt;
-          g[0] = sc * dx;
-          g[1] = sc * dy;
-          g[2] = sc * dz;
-        }
-        // d v_posed = T_R^T g
-        float dvp[3];
-  #pragma unroll
-        for (int c = 0; c < 3; ++c) dvp[c] = fmaf(T[8 + c], g[2], fmaf(T[4 + c], g[1], T[c] * g[0]));
-  #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc_dpf[r] += fmaf(cur.p[2][r], dvp[2], fmaf(cur.p[1][r], dvp[1], cur.p[0][r] * dvp[0]));
-        {  // d beta (direct path): lane 10 c + l holds S[c][l]; fold the three coordinate groups onto lanes 0..9
-          const int cgrp = lane / 10;
-          const float contrib = (lane < 30) ? cur.stv * ((cgrp == 0) ? dvp[0] : ((cgrp == 1) ? dvp[1] : dvp[2])) : 0.f;
-          const float c1v = __shfl(contrib, lane + 10, 64), c2v = __shfl(contrib, lane + 20, 64);
-          if (lane < 10) acc_db += contrib + c1v + c2v;
-        }
-        if (lane < 12) {
-          const int r = lane >> 2, c = lane & 3;
-          const float gr = (r == 0) ? g[0] : ((r == 1) ? g[1] : g[2]);
-          const float pc = (c == 0) ? vp[0] : ((c == 1) ? vp[1] : ((c == 2) ? vp[2] : 1.f));
-          const float val = gr * pc;
-          if (SPARSE) {
-  #pragma unroll
-            for (int n = 0; n < 4; ++n) w_dA[wave][wj[n] * 12 + lane] += ww[n] * val;
-          } else {
-            for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn)
-              w_dA[wave][jn * 12 + lane] += a.Wd[(size_t)vi * UUO_NUM_JOINTS + jn] * val;
-          }
-        }
-        if (lane < 3) acc_dt += (lane == 0) ? g[0] : ((lane == 1) ? g[1] : g[2]);
-        acc_loss += loss_item;
-      }
-      cur = nxt;
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) w_dpf[wave][lane + 64 * r] = acc_dpf[r];
-    if (lane < UUO_KB - 192) w_dpf[wave][lane + 192] = acc_dpf[3];
-    if (lane == 0) w_red[wave][0] = acc_loss;
-    if (lane < 3) w_red[wave][1 + lane] = acc_dt;
-    if (lane < 10) w_red[wave][4 + lane] = acc_db;
   }
 
   if (a.stop == 2) return;
@@ -772,30 +610,29 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   BWD_STAMP(10);
 }
 
-// Two entry points so that each gets its own register budget.  The sparse one (<= 4 skin weights per vertex: SMPL) is
+// The general backward kernel (<= 4 skin weights per vertex: SMPL; uuo_model_create refuses anything else) is
 // held to 168 VGPRs = 3 waves per SIMD: k_skin2 keeps 2 x 168 of the 512 registers of every SIMD for the whole of its
 // run, and a backward block of another yaw hypothesis / sequence can only start beside it if it fits in the remaining
 // 176 (at 238 registers it waited for the skinning kernel to drain: +1.7 % fit throughput, same single-stream time).
 __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bwd_sparse(BwdArgs a) {
-  bwd_body<true>(a);
+  bwd_body<false>(a);
 }
-__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_dense(BwdArgs a) { bwd_body<false>(a); }
 __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bwd_sparse_b(const BwdArgs* __restrict__ batch) {
   UUO_BATCH_PICK(BwdArgs, batch)
-  bwd_body<true>(a);
+  bwd_body<false>(a);
 }
 // part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
 // two forms: one wave per frame for <= 16 markers (the candidate search: four items per pass), four waves per frame above
 // that (hmr_full.yaml: 50 markers on the full skeleton would be 13 passes of one wave)
-__global__ __launch_bounds__(64) void k_bwd_part1(BwdArgs a) { bwd_body<true, true, 1>(a); }
+__global__ __launch_bounds__(64) void k_bwd_part1(BwdArgs a) { bwd_body<true, 1>(a); }
 __global__ __launch_bounds__(64) void k_bwd_part1_b(const BwdArgs* __restrict__ batch) {
   UUO_BATCH_PICK(BwdArgs, batch)
-  bwd_body<true, true, 1>(a);
+  bwd_body<true, 1>(a);
 }
-__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part(BwdArgs a) { bwd_body<true, true>(a); }
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part(BwdArgs a) { bwd_body<true>(a); }
 __global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part_b(const BwdArgs* __restrict__ batch) {
   UUO_BATCH_PICK(BwdArgs, batch)
-  bwd_body<true, true>(a);
+  bwd_body<true>(a);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -885,6 +722,12 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     }
     const float lossf = (float)(a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq);
     a.loss[0] = lossf;
+    // the statistics of this problem's OWN parameters (everything but the shape vector), for solves that share the betas
+    // with other ranks (uuo_lbfgs_solve_shared: the betas' gradient is summed over the ranks before it enters any norm)
+    double own1 = sh[0][17], own2 = sh[0][18], ownm = sh[0][19];
+    float gb_local[10];
+#pragma unroll
+    for (int l = 0; l < 10; ++l) gb_local[l] = (float)(sh[0][4 + l] + 2.0 * a.cbetas * ((double)pb[l] - (double)po[l]));
     if (a.stage == UUO_STAGE_PART) {
       const float gz = (float)sh[0][1];
       a.g_z[0] = gz;
@@ -892,6 +735,9 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       s1 += fabs((double)gz);
       s2 += (double)gz * (double)gz;
       sm = fmax(sm, fabs((double)gz));
+      own1 += fabs((double)gz);
+      own2 += (double)gz * (double)gz;
+      ownm = fmax(ownm, fabs((double)gz));
     }
     if (a.stats) {
       a.stats[0] = (double)lossf;
@@ -909,6 +755,12 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
         for (int i = 0; i < 5; ++i) a.rep_host[1 + i] = (unsigned long long)__double_as_longlong(five[i]);
 #pragma unroll
         for (int i = 6; i < 10; ++i) a.rep_host[i] = rep_pre[i - 5];
+        // words 11..23: own-parameter statistics and this problem's shape gradient (read by shared-betas solves only)
+        a.rep_host[11] = (unsigned long long)__double_as_longlong(ownm);
+        a.rep_host[12] = (unsigned long long)__double_as_longlong(own1);
+        a.rep_host[13] = (unsigned long long)__double_as_longlong(own2);
+#pragma unroll
+        for (int l = 0; l < 10; ++l) a.rep_host[14 + l] = (unsigned long long)__double_as_longlong((double)gb_local[l]);
         __threadfence_system();
         __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1031,7 +883,7 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   const uuo_model* m = fit->model;
   int rc = 0;
   static const int no_cache = UUO_ENV_INT("UUO_PART_NOCACHE", 0);  // comparison only
-  const bool cached = p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && m->nnz <= 4 && !no_cache;
+  const bool cached = p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && !no_cache;
   if (cached && fit->pose_cache_id != p->pose_cache_id) {
     // first evaluation of a solve whose body pose is constant: C = v_t + P . feat through the MFMA kernel with zero
     // shape, identity skinning transforms and no translation
@@ -1060,6 +912,17 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
   if (rc) return rc;
   if (cached) {
+    // more than 16 markers on a cached pose (hmr_full.yaml: 50 markers, the full skeleton): the candidate's vertices in
+    // subset order with a box per 16 candidates, then the box-pruned exact search on that compact cloud -- it reports
+    // candidate positions (first position on ties) exactly as the brute-force subset search does, at a third of its time
+    const int part_brute = UUO_ENV_INT("UUO_PART_BRUTE", 0);  // debug flavour only: the brute-force search, for comparison
+    const int nuc = (p->n_subset + 15) / 16;
+    if (!need_verts && !part_brute && nuc <= 512 && p->M <= 512 && p->n_subset >= 16) {
+      rc = uuo_launch_skin_cached(m, s, p->F, fit->pose_cache, fit->A, src.betas, src.trans, p->d_subset, p->n_subset,
+                                  fit->verts, fit->bbox);
+      if (rc) return rc;
+      return uuo_launch_nn_cull(s, p->F, p->M, p->n_subset, nuc, p->d_markers, fit->verts, fit->bbox, fit->nn, fit->nn_flags);
+    }
     rc = uuo_launch_skin_cached(m, s, p->F, fit->pose_cache, fit->A, src.betas, src.trans, p->d_subset, p->n_subset,
                                 fit->verts);
     if (rc) return rc;
@@ -1138,7 +1001,7 @@ int uuo_launch_part_scores(hipStream_t s, const void* d_args, int count, int F) 
 // Builds the pose-corrective blend cache of a part-stage problem now (normally the first evaluation does): a lock-step
 // batch shares ONE cache among its candidates (same body pose) and must have it before its first recorded round.
 int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {
-  if (p->stage != UUO_STAGE_PART || p->pose_cache_id == 0 || fit->model->nnz > 4) return 0;
+  if (p->stage != UUO_STAGE_PART || p->pose_cache_id == 0) return 0;
   if (fit->pose_cache_id == p->pose_cache_id) return 0;
   const StageLayout lay = stage_layout(p->stage, p->F);
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
@@ -1183,7 +1046,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
 
   BwdArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wd = m->W; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
+  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
   a.src = src;
   a.stage = p->stage; a.F = F; a.M = M;
   a.markers = p->d_markers;
@@ -1210,7 +1073,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.h.gx = F;
   a.h.gy = 1;
   const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
-  if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && m->nnz <= 4 && !part_general) {
+  if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && !part_general) {
     a.C = fit->pose_cache;
     const int waves = M <= 16 ? 1 : BWD_NW;
     if (!uuo_record(UUO_OP_BWD_PART, F, waves, a)) {
@@ -1219,11 +1082,8 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
       else
         hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
     }
-  } else if (m->nnz <= 4) {
-    if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else {
-    UUO_REQUIRE(!uuo_recorder, "lock-step batches need the sparse skin-weight tables (<= 4 weights per vertex)");
-    hipLaunchKernelGGL(k_bwd_dense, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   }
   UUO_HIP_CHECK(hipGetLastError());
 
@@ -1351,11 +1211,10 @@ extern "C" int uuo_smpl_backward(uuo_model_t* m, void* stream, int F, const floa
   UUO_REQUIRE(d_up_verts || d_up_joints, "uuo_smpl_backward: no upstream gradient");
   UUO_REQUIRE(F > 0, "uuo_smpl_backward: F must be positive");
   UUO_REQUIRE(betas_rows == 1 || betas_rows == F, "uuo_smpl_backward: betas rows must be 1 or F");
-  UUO_REQUIRE(m->nnz <= 4, "uuo_smpl_backward: needs the sparse skin-weight table (<= 4 weights per vertex)");
   hipStream_t s = (hipStream_t)stream;
   BwdArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wd = m->W; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
+  a.PT = m->PT; a.ST = m->ST; a.vt = m->vt; a.Wi = m->Wi; a.Ww = m->Ww; a.tree = m->tree; a.V = m->V;
   a.src.body = d_poses;
   a.src.norm_body = 0;
   a.src.root = d_root;

@@ -78,6 +78,14 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
       Wi[(size_t)v * 4 + n] = Wi[(size_t)(V - 1) * 4 + n];
       Ww[(size_t)v * 4 + n] = Ww[(size_t)(V - 1) * 4 + n];
     }
+  if (max_nnz > 4) {
+    // SMPL's skinning weights have at most four non-zero entries per vertex and every kernel of the fitted path is built on
+    // that (sparse joint lists in registers); a dense-weight model is refused here rather than falling off a cliff later
+    delete m;
+    uuo_set_error("uuo_model_create: a vertex has " + std::to_string(max_nnz) +
+                  " non-zero skinning weights; the SMPL family has at most 4 and nothing else is supported");
+    return -22;
+  }
   m->nnz = max_nnz;
 
   // kinematic tree + hoisted joint tables (J = Jt + JS.beta, with Jt = Jreg.v_template, JS = Jreg.shapedirs)
@@ -137,10 +145,9 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
   rc |= upload(&m->P3, P3);
   rc |= upload(&m->vt3, vt3);
   rc |= upload(&m->PT, PT);
-  std::vector<float> ST(S, S + (size_t)V * 30), vtv(vt, vt + (size_t)V * 3), Wd(W, W + (size_t)V * UUO_NUM_JOINTS);
+  std::vector<float> ST(S, S + (size_t)V * 30), vtv(vt, vt + (size_t)V * 3);
   rc |= upload(&m->ST, ST);
   rc |= upload(&m->vt, vtv);
-  rc |= upload(&m->W, Wd);
   rc |= upload(&m->Wi, Wi);
   rc |= upload(&m->Ww, Ww);
   if (rc == 0) {
@@ -160,7 +167,7 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
 
 extern "C" int uuo_model_destroy(uuo_model_t* m) {
   if (!m) return 0;
-  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->W, m->Wi, m->Ww, m->tree};
+  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->Wi, m->Ww, m->tree};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& kv : m->fwd) {

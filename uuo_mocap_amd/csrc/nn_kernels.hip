@@ -5,6 +5,13 @@
 
 #define UUO_INF __builtin_huge_valf()
 
+// IEEE square root and division, correctly rounded.  HIP's __fsqrt_rn is NOT that: without OCML_BASIC_ROUNDED_OPERATIONS it
+// is __ocml_native_sqrt_f32 (v_sqrt_f32, 1 ulp) -- found in round 3 when the rigidity matrix differed from numpy's in a third
+// of its entries by one ulp.  The plain operators are correctly rounded in HIP device code
+// (-fhip-fp32-correctly-rounded-divide-sqrt is the compiler's default and this library never turns it off).
+__device__ __forceinline__ float uuo_sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float uuo_div_rn(float x, float y) { return x / y; }
+
 __device__ __forceinline__ unsigned long long pack_key(float d, unsigned idx) {
   return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)idx;
 }
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(PFW_T) void k_part_fwd_b(const PartFwdArgs* __restr
 int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
                         const float* trans, const int32_t* subset, int n_subset, const float* markers,
                         unsigned long long* packed) {
-  UUO_REQUIRE(m->nnz <= 4 && P1 >= 1 && P1 <= NNQ_MAX && subset && n_subset > 0 && F > 0, "uuo_launch_part_fwd: bad arguments");
+  UUO_REQUIRE(P1 >= 1 && P1 <= NNQ_MAX && subset && n_subset > 0 && F > 0, "uuo_launch_part_fwd: bad arguments");
   PartFwdArgs a{{F, P1}, F, m->V, n_subset, P1, subset, cache, sb, A, trans, markers, packed};
   if (uuo_record(UUO_OP_PART_FWD, F, P1, a)) return 0;  // P1 rides in the record's gy
   const dim3 grid(8 * ((F + 7) / 8));
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(256) void k_assign(int F, int M, int V, const float
 #pragma unroll
       for (int g = 0; g < ASSIGN_MG; ++g) {
         const float d2 = sqdist(vx, vy, vz, sm[g * 3], sm[g * 3 + 1], sm[g * 3 + 2]);
-        acc[g] = __fadd_rn(acc[g], __fsqrt_rn(d2));
+        acc[g] = __fadd_rn(acc[g], uuo_sqrt_rn(d2));
       }
     }
   }
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256) void k_assign(int F, int M, int V, const float
   for (int g = 0; g < ASSIGN_MG; ++g) {
     if (m0 + g < M) {  // uniform across the block
       unsigned long long key = ~0ull;
-      if (v < V) key = pack_key(__fdiv_rn(acc[g], (float)count), (unsigned)v);
+      if (v < V) key = pack_key(uuo_div_rn(acc[g], (float)count), (unsigned)v);
       // wave-level lexicographic min (all 64 lanes participate) before the global atomic
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
@@ -986,6 +993,112 @@ __global__ __launch_bounds__(256) void k_mask(int count, const float* __restrict
 
 int uuo_launch_mask(hipStream_t s, int F, int M, const float* markers, float* mask, float* mask_sum_dev) {
   hipLaunchKernelGGL(k_mask, dim3(1), dim3(256), 0, s, F * M, markers, mask, mask_sum_dev);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Rigidity matrix of segment_rigid (reference markers/markers_utils.py:254-259):
+//   mat[i][j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1))        points [F, M, 3] float32
+// The average-linkage clustering cuts this matrix at 5 mm, so the values are reproduced BIT FOR BIT, which means numpy's
+// float32 arithmetic in numpy's order: norm = sqrt((dx*dx + dy*dy) + dz*dz); std = sqrt(sum((d - mean)^2) / F) with
+// mean = sum(d) / F, and both sums are numpy's PAIRWISE summation of a contiguous float32 vector (umath loops_utils.h,
+// @TYPE@_pairwise_sum): blocks of <= 128 elements summed on 8 interleaved accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail, longer vectors split at floor(n/2) rounded down to a multiple
+// of 8, and the reduction itself chunked by the ufunc buffer (8192 elements), the chunks' sums added in order.  One thread
+// per marker pair walks that tree with an explicit stack; distances are recomputed in the second pass instead of being
+// stored (F floats per pair would not fit in registers).  2 500 pairs x 300 frames: a few microseconds, instead of 2-3 ms
+// of numpy on the host per fit.
+// ----------------------------------------------------------------------------------------------------
+#define NPY_PW_BLOCK 128
+#define NPY_BUFSIZE 8192
+template <class Elem>
+__device__ __forceinline__ float npy_pairwise_leaf(const Elem& elem, int lo, int n) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = __fadd_rn(res, elem(lo + i));
+    return res;
+  }
+  float r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = elem(lo + k);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = __fadd_rn(r[k], elem(lo + i + k));
+  }
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, elem(lo + i));
+  return res;
+}
+template <class Elem>
+__device__ __forceinline__ float npy_pairwise_sum(const Elem& elem, int lo0, int n0) {  // n0 <= NPY_BUFSIZE
+  // post-order walk of numpy's recursion: state 0 = entered, 1 = left half done, 2 = right half done
+  int lo_s[8], n_s[8], st_s[8];
+  float left_s[8];
+  int sp = 0;
+  lo_s[0] = lo0; n_s[0] = n0; st_s[0] = 0;
+  float ret = 0.f;
+  while (sp >= 0) {
+    const int lo = lo_s[sp], n = n_s[sp];
+    if (st_s[sp] == 0) {
+      if (n <= NPY_PW_BLOCK) {
+        ret = npy_pairwise_leaf(elem, lo, n);
+        --sp;
+        continue;
+      }
+      int n2 = n / 2;
+      n2 -= n2 % 8;
+      st_s[sp] = 1;
+      ++sp;
+      lo_s[sp] = lo; n_s[sp] = n2; st_s[sp] = 0;
+    } else if (st_s[sp] == 1) {
+      int n2 = n / 2;
+      n2 -= n2 % 8;
+      left_s[sp] = ret;
+      st_s[sp] = 2;
+      ++sp;
+      lo_s[sp] = lo + n2; n_s[sp] = n - n2; st_s[sp] = 0;
+    } else {
+      ret = __fadd_rn(left_s[sp], ret);
+      --sp;
+    }
+  }
+  return ret;
+}
+template <class Elem>
+__device__ __forceinline__ float npy_sum_f32(const Elem& elem, int n) {  // np.add.reduce of a contiguous float32 vector
+  float res = 0.f;
+  for (int c = 0; c < n; c += NPY_BUFSIZE) res = __fadd_rn(res, npy_pairwise_sum(elem, c, min(NPY_BUFSIZE, n - c)));
+  return res;
+}
+
+__global__ __launch_bounds__(64) void k_rigid_std(int F, int M, const float* __restrict__ pts, float* __restrict__ out) {
+  const int pair = blockIdx.x * 64 + threadIdx.x;
+  if (pair >= M * M) return;
+  const int i = pair / M, j = pair - i * M;
+  const float* pi = pts + (size_t)i * 3;
+  const float* pj = pts + (size_t)j * 3;
+  const size_t fs = (size_t)M * 3;
+  auto dist = [&](int f) -> float {
+    const float dx = __fsub_rn(pi[f * fs], pj[f * fs]), dy = __fsub_rn(pi[f * fs + 1], pj[f * fs + 1]),
+                dz = __fsub_rn(pi[f * fs + 2], pj[f * fs + 2]);
+    return uuo_sqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  };
+  const float nf = (float)F;
+  const float mean = uuo_div_rn(npy_sum_f32(dist, F), nf);
+  auto sq = [&](int f) -> float {
+    const float x = __fsub_rn(dist(f), mean);
+    return __fmul_rn(x, x);
+  };
+  out[pair] = uuo_sqrt_rn(uuo_div_rn(npy_sum_f32(sq, F), nf));
+}
+
+extern "C" int uuo_rigid_distance_std(void* stream, int F, int M, const float* d_points, float* d_std) {
+  UUO_REQUIRE(d_points && d_std, "uuo_rigid_distance_std: null argument");
+  UUO_REQUIRE(F > 0 && M > 0 && (long)M * M < (1L << 30), "uuo_rigid_distance_std: bad sizes");
+  hipLaunchKernelGGL(k_rigid_std, dim3((M * M + 63) / 64), dim3(64), 0, (hipStream_t)stream, F, M, d_points, d_std);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
 }

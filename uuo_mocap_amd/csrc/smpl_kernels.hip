@@ -159,10 +159,10 @@ __device__ __forceinline__ float row16_max(float v) {
 #define SKIN_CG 2                  // groups per register buffer  -> 7 chunks, 24 MFMAs each
 #define SKIN_NCHUNK (SKIN_GROUPS / SKIN_CG)
 
-template <bool SPARSE, int VAR>
+template <int VAR>
 __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restrict__ P3, const float* __restrict__ vt3,
                                                            const int* __restrict__ Wi, const float* __restrict__ Ww,
-                                                           const float* __restrict__ Wd, const float* __restrict__ pfaT,
+                                                           const float* __restrict__ pfaT,
                                                            const float* __restrict__ A, const float* __restrict__ trans,
                                                            float* __restrict__ verts, float* __restrict__ bbox, int F,
                                                            int V, int VP, int nFT, int nVB, int nblocks) {
@@ -238,10 +238,8 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
     tn0 = vt3[v];
     tn1 = vt3[VP + v];
     tn2 = vt3[2 * VP + v];
-    if (SPARSE) {
-      wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
-      ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
-    }
+    wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
+    ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
   }
   for (; u < u_end; u += SKIN_WAVES) {
     const int v = u * 16 + j;  // < VP
@@ -272,20 +270,14 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
         tn0 = vt3[vn];
         tn1 = vt3[VP + vn];
         tn2 = vt3[2 * VP + vn];
-        if (SPARSE) {
-          wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)vn * 4);
-          ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)vn * 4);
-        }
+        wi_n = *reinterpret_cast<const int4*>(Wi + (size_t)vn * 4);
+        ww_n = *reinterpret_cast<const float4*>(Ww + (size_t)vn * 4);
       }
     }
 
     // ---- skinning epilogue: lane = vertex j, frames 4*kq .. 4*kq+3
-    int wj[4];
-    float ww[4];
-    if (SPARSE) {
-      wj[0] = wi4.x; wj[1] = wi4.y; wj[2] = wi4.z; wj[3] = wi4.w;
-      ww[0] = ww4.x; ww[1] = ww4.y; ww[2] = ww4.z; ww[3] = ww4.w;
-    }
+    const int wj[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
+    const float ww[4] = {ww4.x, ww4.y, ww4.z, ww4.w};
     const bool vok = v < V;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -296,7 +288,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
       for (int c = 0; c < 12; ++c) T[c] = 0.f;
       if (VAR == 5) {
         T[0] = T[5] = T[10] = ww[0] + 1.f;
-      } else if (SPARSE) {
+      } else {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const float4* pt = reinterpret_cast<const float4*>(sT + (i * UUO_NUM_JOINTS + wj[n]) * 12);
@@ -305,13 +297,6 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) void k_skin(const float* __restric
           T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
           T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
           T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
-        }
-      } else {
-        for (int jn = 0; jn < UUO_NUM_JOINTS; ++jn) {
-          const float w = vok ? Wd[(size_t)v * UUO_NUM_JOINTS + jn] : 0.f;
-          const float* pt = sT + (i * UUO_NUM_JOINTS + jn) * 12;
-#pragma unroll
-          for (int c = 0; c < 12; ++c) T[c] = fmaf(w, pt[c], T[c]);
         }
       }
       const float px = acc0[e], py = acc1[e], pz = acc2[e];
@@ -783,7 +768,7 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
   static const int force_v1 = UUO_ENV_INT("UUO_SKIN_V1", 0);  // ablation / comparison only
   const int nur = (m->V + 15) / 16;  // units with vertices = stride of the box table
   const int npos = 1 << SK2_NPOS_LOG2;  // 8 XCDs x 32 CUs, one 8-wave block per CU
-  if (m->nnz > 4 || force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+  if (force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
   const int nFT_all = (F + UUO_FT - 1) / UUO_FT;
   for (int ft0 = 0; ft0 < nFT_all; ft0 += SK2_MAX_FT) {
     const int nFT = (nFT_all - ft0 < SK2_MAX_FT) ? nFT_all - ft0 : SK2_MAX_FT;
@@ -800,6 +785,7 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
                      reinterpret_cast<const float4*>(m->P3), m->vt3, m->Wi, m->Ww, pf, pA, pt, pv,      \
                      (BB) ? bbox + (size_t)f0 * nur * 6 : (float*)nullptr, Fl, m->V, m->VP, nFT)
     if (!bbox) SK2_LAUNCH(false, 0);
+#ifdef UUO_DEBUG_HOOKS  // timing ablations (MFMAs off, epilogue off, refills off, cycle stamps): never in the product binary
     else if (var2 == 1) SK2_LAUNCH(true, 1);
     else if (var2 == 2) SK2_LAUNCH(true, 2);
     else if (var2 == 4) SK2_LAUNCH(true, 4);
@@ -810,7 +796,9 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
     else if (var2 == 11) SK2_LAUNCH(true, 11);
     else if (var2 == 12) SK2_LAUNCH(true, 12);
     else if (var2 == 24) SK2_LAUNCH(false, 8);
+#endif
     else SK2_LAUNCH(true, 0);
+    (void)var2;
 #undef SK2_LAUNCH
   }
   UUO_HIP_CHECK(hipGetLastError());
@@ -836,16 +824,19 @@ static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const fl
   if (nVB < 1) nVB = 1;
   const int nblocks = nFT * nVB;
   static const int variant = UUO_ENV_INT("UUO_SKIN_VARIANT", 0);  // ablation only
-#define SKIN_LAUNCH(SP, VAR)                                                                                     \
-  hipLaunchKernelGGL((k_skin<SP, VAR>), dim3(nblocks), dim3(SKIN_WAVES * 64), 0, s, m->P3, m->vt3, m->Wi, m->Ww, \
-                     m->W, pfaT, A, trans, verts, bbox, F, m->V, m->VP, nFT, nVB, nblocks)
-  if (m->nnz > 4) SKIN_LAUNCH(false, 0);
-  else if (variant == 1) SKIN_LAUNCH(true, 1);
-  else if (variant == 2) SKIN_LAUNCH(true, 2);
-  else if (variant == 3) SKIN_LAUNCH(true, 3);
-  else if (variant == 4) SKIN_LAUNCH(true, 4);
-  else if (variant == 5) SKIN_LAUNCH(true, 5);
-  else SKIN_LAUNCH(true, 0);
+#define SKIN_LAUNCH(VAR)                                                                                     \
+  hipLaunchKernelGGL((k_skin<VAR>), dim3(nblocks), dim3(SKIN_WAVES * 64), 0, s, m->P3, m->vt3, m->Wi, m->Ww, \
+                     pfaT, A, trans, verts, bbox, F, m->V, m->VP, nFT, nVB, nblocks)
+#ifdef UUO_DEBUG_HOOKS  // timing ablations: never in the product binary
+  if (variant == 1) SKIN_LAUNCH(1);
+  else if (variant == 2) SKIN_LAUNCH(2);
+  else if (variant == 3) SKIN_LAUNCH(3);
+  else if (variant == 4) SKIN_LAUNCH(4);
+  else if (variant == 5) SKIN_LAUNCH(5);
+  else
+#endif
+    SKIN_LAUNCH(0);
+  (void)variant;
 #undef SKIN_LAUNCH
   UUO_HIP_CHECK(hipGetLastError());
   return 0;
@@ -864,11 +855,15 @@ static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const fl
 // in LDS: 12 B read + 12 B written per vertex and frame instead of the 207-term contraction.
 // ----------------------------------------------------------------------------------------------------
 #define SKC_FB 10  // frames per block
+// `bbox` != null selects the COMPACT form: vertex of candidate i is written at verts[f][i] (subset order, stride ns) and
+// every 16 consecutive candidates get their bounding box bbox[f][i / 16][6] -- the layout the box-pruned search
+// (k_nn_cull) works on, which then reports candidate positions directly, ties and all, as the subset search must.
 __device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int32_t* __restrict__ subset,
                                                  const float* __restrict__ C, const float* __restrict__ ST,
                                                  const int* __restrict__ Wi, const float* __restrict__ Ww,
                                                  const float* __restrict__ A, const float* __restrict__ betas,
-                                                 const float* __restrict__ trans, float* __restrict__ verts) {
+                                                 const float* __restrict__ trans, float* __restrict__ verts,
+                                                 float* __restrict__ bbox) {
   __shared__ float sA[SKC_FB * UUO_NUM_JOINTS * 12];
   __shared__ float sTr[SKC_FB * 3];
   const int f0 = blockIdx.y * SKC_FB, nf = min(SKC_FB, F - f0);
@@ -876,20 +871,28 @@ __device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int
   if (threadIdx.x < nf * 3) sTr[threadIdx.x] = trans ? trans[(size_t)f0 * 3 + threadIdx.x] : 0.f;
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= ns) return;
-  const int v = subset ? subset[i] : i;
-  if ((unsigned)v >= (unsigned)V) return;
+  const bool compact = bbox != nullptr;  // block-uniform
+  if (!compact && i >= ns) return;
+  if (compact && (i & ~15) >= ns) return;  // whole DPP rows past the end leave together; a partly filled one stays whole
+  const bool mine = i < ns;
+  const int ic = mine ? i : ns - 1;  // lanes past the end of a partly filled unit repeat the last candidate: same box
+  const int v = subset ? subset[ic] : ic;
+  if ((unsigned)v >= (unsigned)V) {
+    if (!compact) return;
+  }
+  const int vs = ((unsigned)v < (unsigned)V) ? v : 0;  // (memory safety only: subsets hold valid vertex ids)
   float sb[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int l = 0; l < 10; ++l) sb[c] = fmaf(ST[(size_t)v * 30 + c * 10 + l], betas[l], sb[c]);
-  const int4 wi = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
-  const float4 ww = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
+    for (int l = 0; l < 10; ++l) sb[c] = fmaf(ST[(size_t)vs * 30 + c * 10 + l], betas[l], sb[c]);
+  const int4 wi = *reinterpret_cast<const int4*>(Wi + (size_t)vs * 4);
+  const float4 ww = *reinterpret_cast<const float4*>(Ww + (size_t)vs * 4);
   const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
   const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+  const int nuc = (ns + 15) >> 4;  // units of 16 candidates (compact form)
   for (int q = 0; q < nf; ++q) {
-    const float* pc = C + ((size_t)(f0 + q) * V + v) * 3;
+    const float* pc = C + ((size_t)(f0 + q) * V + vs) * 3;
     const float px = pc[0] + sb[0], py = pc[1] + sb[1], pz = pc[2] + sb[2];
     float T[12];
 #pragma unroll
@@ -901,10 +904,26 @@ __device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int
 #pragma unroll
       for (int e = 0; e < 12; ++e) T[e] = fmaf(w, a[e], T[e]);
     }
-    float* o = verts + ((size_t)(f0 + q) * V + v) * 3;
-    o[0] = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3] + sTr[q * 3];
-    o[1] = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7] + sTr[q * 3 + 1];
-    o[2] = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11] + sTr[q * 3 + 2];
+    const float ox = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3] + sTr[q * 3];
+    const float oy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7] + sTr[q * 3 + 1];
+    const float oz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11] + sTr[q * 3 + 2];
+    if (!compact) {
+      float* o = verts + ((size_t)(f0 + q) * V + v) * 3;
+      o[0] = ox; o[1] = oy; o[2] = oz;
+    } else {
+      if (mine) {
+        float* o = verts + ((size_t)(f0 + q) * ns + i) * 3;
+        o[0] = ox; o[1] = oy; o[2] = oz;
+      }
+      // the 16 candidates of a unit sit on the 16 lanes of one DPP row
+      const float lx = row16_min(ox), ly = row16_min(oy), lz = row16_min(oz);
+      const float hx = row16_max(ox), hy = row16_max(oy), hz = row16_max(oz);
+      if ((i & 15) == 0) {
+        float* pb = bbox + ((size_t)(f0 + q) * nuc + (i >> 4)) * 6;
+        pb[0] = lx; pb[1] = ly; pb[2] = lz;
+        pb[3] = hx; pb[4] = hy; pb[5] = hz;
+      }
+    }
   }
 }
 
@@ -920,22 +939,23 @@ struct SkinCachedArgs {
   uuo_gptr<const float> betas;
   uuo_gptr<const float> trans;
   uuo_gptr<float> verts;
+  uuo_gptr<float> bbox;  // null: vertices by vertex id; else the compact form (see skin_cached_body)
 };
 __global__ __launch_bounds__(256) void k_skin_cached(SkinCachedArgs a) {
-  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts);
+  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts, a.bbox);
 }
 __global__ __launch_bounds__(256) void k_skin_cached_b(const SkinCachedArgs* __restrict__ batch) {
   UUO_BATCH_PICK(SkinCachedArgs, batch)
-  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts);
+  skin_cached_body(a.F, a.V, a.ns, a.subset, a.C, a.ST, a.Wi, a.Ww, a.A, a.betas, a.trans, a.verts, a.bbox);
 }
 
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
-                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts) {
-  UUO_REQUIRE(m->nnz <= 4, "uuo_launch_skin_cached: needs the sparse skin-weight tables");
+                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts,
+                           float* bbox_compact) {
   const int ns = subset ? n_subset : m->V;
   if (F <= 0 || ns <= 0) return 0;
   const int gx = (ns + 255) / 256, gy = (F + SKC_FB - 1) / SKC_FB;
-  SkinCachedArgs a{{gx, gy}, F, m->V, ns, subset, cache, m->ST, m->Wi, m->Ww, A, betas, trans, verts};
+  SkinCachedArgs a{{gx, gy}, F, m->V, ns, subset, cache, m->ST, m->Wi, m->Ww, A, betas, trans, verts, bbox_compact};
   if (uuo_record(UUO_OP_SKIN_CACHED, gx, gy, a)) return 0;
   hipLaunchKernelGGL(k_skin_cached, dim3(gx, gy), dim3(256), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());

@@ -191,7 +191,8 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
                                                   float* __restrict__ S, float* __restrict__ Y,
                                                   const float* __restrict__ g, const float* __restrict__ gp,
                                                   const float* __restrict__ d, float t, int ncb, int gcb,
-                                                  double* __restrict__ part /* [groups][LB_ROWS][3] */) {
+                                                  double* __restrict__ part /* [groups][LB_ROWS][3] */,
+                                                  int skip_lo = 0, int skip_hi = 0) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   const int grp = blockIdx.x, rs = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -253,6 +254,18 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
 #define LB_MASK(c, k_) { const bool in_ = i + k_ < n; vg.c = in_ ? vg.c : 0.f; vy.c = in_ ? vy.c : 0.f; vs.c = in_ ? vs.c : 0.f; }
     LB_MASK(x, 0) LB_MASK(y, 1) LB_MASK(z, 2) LB_MASK(w, 3)
 #undef LB_MASK
+    if (special) {  // wave-uniform: the store of the new pair (before the shared range is masked: the history keeps it)
+      const size_t o = (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + h * 256 + lane * 4;
+      *reinterpret_cast<float4*>(Y + o) = vy;
+      *reinterpret_cast<float4*>(S + o) = vs;
+    }
+    // shared-betas solves (uuo_lbfgs_solve_shared): the replicated shape entries belong to rank 0's partial sums only, so
+    // the other ranks drop [skip_lo, skip_hi) from every dot product (kernel-uniform: an empty range everywhere else)
+    if (skip_hi > skip_lo && i < skip_hi && i + 4 > skip_lo) {
+#define LB_SKIP(c, k_) { const bool out_ = i + k_ >= skip_lo && i + k_ < skip_hi; vg.c = out_ ? 0.f : vg.c; vy.c = out_ ? 0.f : vy.c; vs.c = out_ ? 0.f : vs.c; }
+      LB_SKIP(x, 0) LB_SKIP(y, 1) LB_SKIP(z, 2) LB_SKIP(w, 3)
+#undef LB_SKIP
+    }
 #pragma unroll
     for (int q = 0; q < LB_DRW; ++q) {
       const float4 r = rv[q];
@@ -263,10 +276,7 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
       LB_ACC(x) LB_ACC(y) LB_ACC(z) LB_ACC(w)
 #undef LB_ACC
     }
-    if (special) {  // wave-uniform: the new pair's own rows and g, and the store of the pair
-      const size_t o = (size_t)cb * LB_CBSTRIDE(capL) + (size_t)cand * LB_CW + h * 256 + lane * 4;
-      *reinterpret_cast<float4*>(Y + o) = vy;
-      *reinterpret_cast<float4*>(S + o) = vs;
+    if (special) {  // wave-uniform: the new pair's own rows and g
 #define LB_SP(c)                                                                                         \
       {                                                                                                  \
         const double y_ = (double)vy.c, s_ = (double)vs.c, g_ = (double)vg.c;                            \
@@ -310,13 +320,50 @@ struct LbDotsArgs {
   float t;
   int ncb, gcb;
   uuo_gptr<double> part;
+  int skip_lo, skip_hi;  // elements left out of the dot products (shared betas on ranks > 0); empty otherwise
 };
 __global__ __launch_bounds__(256) void k_lb_dots(LbDotsArgs a) {
-  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part);
+  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part, a.skip_lo,
+               a.skip_hi);
 }
 __global__ __launch_bounds__(256) void k_lb_dots_b(const LbDotsArgs* __restrict__ batch) {
   UUO_BATCH_PICK(LbDotsArgs, batch)
-  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part);
+  lb_dots_body(a.n, a.cap, a.capL, a.head, a.count, a.cand, a.S, a.Y, a.g, a.gp, a.d, a.t, a.ncb, a.gcb, a.part, a.skip_lo,
+               a.skip_hi);
+}
+
+// Shared-betas solves: the chunk sums of the new Gram rows of THIS rank (what k_lb_small_inv's first phase computes), written
+// to pinned host memory followed by a sequence word; the host gathers the rows of all ranks, adds them in rank order and
+// hands the totals back to k_lb_small_inv (rd_in), so every rank computes identical direction coefficients.
+__global__ __launch_bounds__(512) void k_lb_rows(int nchunks, int cap, int cand, const double* __restrict__ part,
+                                                  const LbDev* __restrict__ st, double* __restrict__ host_rows,
+                                                  unsigned long long seq) {
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  const int head = st->head, count = st->count;
+  for (int e = tid; e < LB_ROWS * 3; e += 512) {
+    const int row = e / 3;
+    const int slot = (row < LB_MAXH) ? row : row - LB_MAXH;
+    bool active = (row == 2 * LB_MAXH);
+    if (!active && slot < cap) {
+      const int rel = (slot - head + cap) % cap;
+      active = (rel < count) || (slot == cand);
+    }
+    double acc = 0.0;
+    if (active) {
+      double v[LB_MAXCHUNK];
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) v[c] = (c < nchunks) ? part[(size_t)c * LB_ROWS * 3 + e] : 0.0;
+#pragma unroll
+      for (int c = 0; c < LB_MAXCHUNK; ++c) acc += v[c];
+    }
+    host_rows[e] = acc;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_rows + LB_ROWS * 3), seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One block: reduce the dot partials, update the Gram matrices and the ring, then run the two-loop recursion of
@@ -901,7 +948,7 @@ __device__ __forceinline__ double quad_sum_d(double v) {  // sum over the 4 lane
 }
 __device__ __forceinline__ void lb_small_inv_body(int nchunks, int cap, int hist, int cand,
                                                        const double* __restrict__ part, LbDev* __restrict__ st,
-                                                       int stop) {
+                                                       int stop, const double* __restrict__ rd_in = nullptr) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ double Ws[LB_MAXH * LB_US];  // W by slot
   __shared__ double Sg[LB_MAXH], Yg[LB_MAXH], al[LB_MAXH], cs_s[LB_MAXH], cy_s[LB_MAXH], wv[LB_MAXH], vv[LB_MAXH];
@@ -935,7 +982,9 @@ __device__ __forceinline__ void lb_small_inv_body(int nchunks, int cap, int hist
       active = (rel < count) || (slot == cand);
     }
     double acc = 0.0;
-    if (active) {
+    if (active && rd_in) {  // kernel-uniform: the rows summed over the ranks of a shared-betas solve (k_lb_rows + host)
+      acc = rd_in[e];
+    } else if (active) {
       double v[LB_MAXCHUNK];
 #pragma unroll
       for (int c = 0; c < LB_MAXCHUNK; ++c) v[c] = (c < nchunks) ? part[(size_t)c * LB_ROWS * 3 + e] : 0.0;
@@ -1103,13 +1152,14 @@ struct LbSmallArgs {
   uuo_gptr<const double> part;
   uuo_gptr<LbDev> st;
   int stop;
+  uuo_gptr<const double> rd_in;  // shared-betas solves: the Gram rows already summed over chunks AND ranks; null otherwise
 };
 __global__ __launch_bounds__(512) void k_lb_small_inv(LbSmallArgs a) {
-  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop);
+  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop, a.rd_in);
 }
 __global__ __launch_bounds__(512) void k_lb_small_inv_b(const LbSmallArgs* __restrict__ batch) {
   UUO_BATCH_PICK(LbSmallArgs, batch)
-  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop);
+  lb_small_inv_body(a.nchunks, a.cap, a.hist, a.cand, a.part, a.st, a.stop, a.rd_in);
 }
 
 #define LB_DQ 4  // slot ranges per 256-column strip of k_lb_direction (one wave each)
@@ -1303,12 +1353,22 @@ struct LbWs {
   unsigned long long seq = 0;
   int nchunks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // shared-betas solves only (created on first use): pinned staging of the Gram rows / the summed shape gradient
+  double* h_rows = nullptr;     // [LB_ROWS*3 + 1]: this rank's rows, written by k_lb_rows, + its sequence word
+  double* h_joint = nullptr;    // [2][LB_ROWS*3]: the rows summed over the ranks, on their way to rd_joint (two slots)
+  float* h_gb = nullptr;        // [4][16]: the summed shape gradient on its way into the gradient vector (four slots)
+  double* rd_joint = nullptr;   // device [LB_ROWS*3]
+  unsigned long long row_seq = 0, joint_slot = 0, gb_slot = 0;
 };
 
 static int lbws_destroy(LbWs* w) {
   if (!w) return 0;
   if (w->slab) (void)hipFree(w->slab);
   if (w->h_out) (void)hipHostFree(w->h_out);
+  if (w->h_rows) (void)hipHostFree(w->h_rows);
+  if (w->h_joint) (void)hipHostFree(w->h_joint);
+  if (w->h_gb) (void)hipHostFree(w->h_gb);
+  if (w->rd_joint) (void)hipFree(w->rd_joint);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1426,8 +1486,35 @@ struct LbHostOut {  // mirror of the tail of LbDev read back after every closure
 // back to the batch scheduler instead of polling; the scheduler resumes the solve when the evaluation has reported
 static thread_local void (*g_batch_yield)(void) = nullptr;
 
+// Shared-betas solves (uuo_lbfgs_solve_shared, EXTENSION): this rank's problem is one block of a joint problem whose shape
+// vector x[off .. off + cnt) is replicated on every rank.  The driver below is unchanged but for three exchanges, each ONE
+// rank-ordered gather through the caller's hook, after which every rank holds the same numbers and decides the same:
+//   * after every closure evaluation {loss, g.d, own-parameter gradient statistics, max|d|, local shape gradient}: the
+//     shape gradient is summed and written back into the gradient vector before anything reads it, the line search sees the
+//     joint loss / g.d / norms;
+//   * per iteration the new Gram rows (k_lb_rows): summed in rank order and handed to k_lb_small_inv (ranks > 0 leave the
+//     replicated range out of their dot products, so every entry of the joint vector is counted once);
+//   * once, at the start, the shape vector itself (rank 0's values win: the replicas must be bit-identical).
+struct SharedCtx {
+  uuo_gather_fn gather = nullptr;
+  void* user = nullptr;
+  int rank = 0, world = 1;
+  int off = 0, cnt = 0;
+  std::vector<double> all;  // gather target
+};
+
+static int shared_gather(SharedCtx* sh, const double* mine, int n) {
+  sh->all.resize((size_t)sh->world * n);
+  const int rc = sh->gather(sh->user, mine, n, sh->all.data());
+  if (rc) {
+    uuo_set_error("uuo_lbfgs_solve_shared: the gather hook returned " + std::to_string(rc));
+    return rc < 0 ? rc : -rc;
+  }
+  return 0;
+}
+
 static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
-                     uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user) {
+                     uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user, SharedCtx* sh = nullptr) {
   const bool batched = uuo_recorder != nullptr;
   const int n = obj.n;
   UUO_REQUIRE(n > 0 && n <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
@@ -1473,6 +1560,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
   // the slowest evaluation of the path (first closure at F = 3000) is ~10 ms; a minute means the device is gone
   const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
   unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(w->h_out);
+  auto host_dmax = [&]() -> double {
+    float f;
+    std::memcpy(&f, &hh->dmax_bits, sizeof(float));
+    return (double)f;
+  };
   auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
     const float* dir = with_dir ? d : (const float*)nullptr;
     const bool poll = obj.fused_stats && poll_mode != 0;
@@ -1513,6 +1605,38 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           }
         }
       }
+      if (sh) {
+        // joint statistics of this evaluation: one gather of 6 + cnt doubles per rank, reduced here in rank order
+        double mine[6 + 16];
+        auto word = [&](int i) { double v; std::memcpy(&v, &rep_words[i], sizeof(double)); return v; };
+        mine[0] = ho->loss; mine[1] = ho->gtd_new;
+        mine[2] = word(11); mine[3] = word(12); mine[4] = word(13);  // own parameters: max|g|, sum|g|, g.g
+        mine[5] = host_dmax();
+        for (int l = 0; l < sh->cnt; ++l) mine[6 + l] = word(14 + l);
+        const int m_ = 6 + sh->cnt;
+        const int grc = shared_gather(sh, mine, m_);
+        if (grc) return grc;
+        double loss_j = 0.0, gtd_j = 0.0, g1_j = 0.0, gg_j = 0.0, gmax_j = 0.0, dmax_j = 0.0, gb[16] = {0.0};
+        for (int r = 0; r < sh->world; ++r) {
+          const double* a_ = sh->all.data() + (size_t)r * m_;
+          loss_j += a_[0]; gtd_j += a_[1];
+          gmax_j = std::fmax(gmax_j, a_[2]); g1_j += a_[3]; gg_j += a_[4];
+          dmax_j = std::fmax(dmax_j, a_[5]);
+          for (int l = 0; l < sh->cnt; ++l) gb[l] += a_[6 + l];
+        }
+        float* slot = w->h_gb + 16 * (w->gb_slot++ & 3);  // (a slot is reused four reports later: its copy has executed)
+        for (int l = 0; l < sh->cnt; ++l) {
+          const float gbf = (float)gb[l];
+          slot[l] = gbf;
+          g1_j += std::fabs((double)gbf);
+          gg_j += (double)gbf * (double)gbf;
+          gmax_j = std::fmax(gmax_j, std::fabs((double)gbf));
+        }
+        UUO_HIP_CHECK(hipMemcpyAsync(gv + sh->off, slot, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
+        ho->loss = loss_j; ho->gtd_new = gtd_j; ho->gmax = gmax_j; ho->g1 = g1_j; ho->gg = gg_j;
+        const float dmf = (float)dmax_j;
+        std::memcpy(&hh->dmax_bits, &dmf, sizeof(float));
+      }
       return 0;
     }
     if (!obj.fused_stats) {
@@ -1525,17 +1649,35 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     UUO_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
   };
-  auto host_dmax = [&]() -> double {
-    float f;
-    std::memcpy(&f, &hh->dmax_bits, sizeof(float));
-    return (double)f;
-  };
   auto report = [&](double loss, const float* x_eval) {
     if (cb) cb(cb_user, evals_total, (float)loss, x_eval);
     if (opt->verbose) std::printf("lbfgs eval %d loss %.9g\n", evals_total, loss);
     ++evals_total;
   };
 
+  if (sh) {
+    UUO_REQUIRE(!batched && obj.fused_stats && poll_mode != 0, "lbfgs: shared solves need the fused, polled report path");
+    UUO_REQUIRE(sh->cnt > 0 && sh->cnt <= 16 && sh->off >= 0 && sh->off + sh->cnt <= n && sh->world >= 1 &&
+                sh->rank >= 0 && sh->rank < sh->world && sh->gather, "lbfgs: bad shared-parameter description");
+    if (!w->h_rows) {
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_rows, (LB_ROWS * 3 + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_joint, 2 * LB_ROWS * 3 * sizeof(double), hipHostMallocDefault));
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_gb, 4 * 16 * sizeof(float), hipHostMallocDefault));
+      UUO_HIP_CHECK(hipMalloc((void**)&w->rd_joint, LB_ROWS * 3 * sizeof(double)));
+      std::memset(w->h_rows, 0, (LB_ROWS * 3 + 1) * sizeof(double));
+    }
+    // the replicas of the shared entries must be bit-identical: every rank takes rank 0's values
+    float hb[16];
+    double mine[16];
+    UUO_HIP_CHECK(hipMemcpyAsync(hb, d_x + sh->off, sizeof(float) * sh->cnt, hipMemcpyDeviceToHost, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));
+    for (int l = 0; l < sh->cnt; ++l) mine[l] = (double)hb[l];
+    const int grc = shared_gather(sh, mine, sh->cnt);
+    if (grc) return grc;
+    for (int l = 0; l < sh->cnt; ++l) hb[l] = (float)sh->all[l];
+    UUO_HIP_CHECK(hipMemcpyAsync(d_x + sh->off, hb, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));  // (hb is a stack buffer)
+  }
   if (!batched) UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
   hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, w->st);
   int ig = pool_alloc();  // gradient at the current iterate
@@ -1573,7 +1715,45 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         const int cand = (head + count) % cap;
         const int nrows = 2 * (count + 1) + 1;
         LbDotsArgs da{{0, 0}, n, cap, w->cap, head, count, cand, w->S, w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part};
+        if (sh && sh->rank != 0) {  // the replicated entries are counted once in the joint dot products: on rank 0
+          da.skip_lo = sh->off;
+          da.skip_hi = sh->off + sh->cnt;
+        }
         lb_dispatch(UUO_OP_DOTS, s, dim3(nchunks, LB_DRS), dim3(256), k_lb_dots, da);
+        const double* rd_in = nullptr;
+        if (sh) {
+          const unsigned long long rseq = ++w->row_seq;
+          hipLaunchKernelGGL(k_lb_rows, dim3(1), dim3(512), 0, s, nchunks, cap, cand, w->part, w->st, w->h_rows, rseq);
+          UUO_HIP_CHECK(hipGetLastError());
+          unsigned long long* rw = reinterpret_cast<unsigned long long*>(w->h_rows + LB_ROWS * 3);
+          unsigned long spins = 0;
+          timespec t_start;
+          clock_gettime(CLOCK_MONOTONIC, &t_start);
+          while (__atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0) {
+              const hipError_t q = hipStreamQuery(s);
+              timespec t_now;
+              clock_gettime(CLOCK_MONOTONIC, &t_now);
+              const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
+              if ((q != hipErrorNotReady && __atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) || waited > eval_timeout_s) {
+                uuo_set_error(std::string("lbfgs: the Gram rows of a shared solve did not arrive: ") + hipGetErrorString(q));
+                return -5;
+              }
+            }
+          }
+          const int nr = LB_ROWS * 3;
+          const int grc = shared_gather(sh, w->h_rows, nr);
+          if (grc) return grc;
+          double* joint = w->h_joint + (size_t)nr * (w->joint_slot++ & 1);  // (reused two iterations later)
+          for (int e = 0; e < nr; ++e) {
+            double acc = 0.0;
+            for (int r = 0; r < sh->world; ++r) acc += sh->all[(size_t)r * nr + e];
+            joint[e] = acc;
+          }
+          UUO_HIP_CHECK(hipMemcpyAsync(w->rd_joint, joint, sizeof(double) * nr, hipMemcpyHostToDevice, s));
+          rd_in = w->rd_joint;
+        }
         static const int small_stop = UUO_ENV_INT("UUO_SMALL_STOP", 0);  // ablation only
         static const int small_ref = UUO_ENV_INT("UUO_SMALL_REF", 0);  // comparison only
         static const int small_block = UUO_ENV_INT("UUO_SMALL_BLOCK", 0);  // comparison only
@@ -1583,6 +1763,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           hipLaunchKernelGGL(k_lb_small, dim3(1), dim3(512), 0, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
         else {
           LbSmallArgs sa{{0, 0}, nchunks, cap, hist, cand, w->part, w->st, small_stop};
+          sa.rd_in = rd_in;
           lb_dispatch(UUO_OP_SMALL, s, dim3(1), dim3(512), k_lb_small_inv, sa);
         }
         LbDirArgs ra{{0, 0}, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur, (float)t, xoth};
@@ -1931,6 +2112,52 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
 }
 
+// EXTENSION (BASELINE configs[3]; not reference behaviour): uuo_lbfgs_solve where the `world` ranks that call
+// it together -- one stage problem each, same stage -- share the shape vector.  See SharedCtx above.
+extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                                      const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
+                                      uuo_eval_callback_t cb, void* cb_user) {
+  UUO_REQUIRE(shared && shared->gather && shared->world >= 1 && shared->rank >= 0 && shared->rank < shared->world,
+              "uuo_lbfgs_solve_shared: bad rank description");
+  int rc = uuo_validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && opt && stats, "uuo_lbfgs_solve_shared: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve_shared: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_lbfgs_solve_shared: not inside a lock-step batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  const int n_params = uuo_problem_num_params(p);
+  LbWs* w = (LbWs*)fit->lbws;
+  if (!w || w->cap < hist + 1 || w->n_cap < n_params) {
+    const int keep_hist = w ? std::max(hist, w->cap - 1) : hist;
+    if (w) {
+      UUO_HIP_CHECK(hipStreamSynchronize(s));
+      lbws_destroy(w);
+    }
+    fit->lbws = nullptr;
+    rc = lbws_create(n_params, keep_hist, &w);
+    if (rc) return rc;
+    fit->lbws = w;
+  }
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  StageObjective obj;
+  obj.fit = fit;
+  obj.p = p;
+  obj.fused_stats = true;
+  obj.n = n_params;
+  SharedCtx sh;
+  sh.gather = shared->gather;
+  sh.user = shared->user;
+  sh.rank = shared->rank;
+  sh.world = shared->world;
+  sh.cnt = UUO_NUM_BETAS;
+  const int F = p->F;  // offset of the betas in the stage's packing (closure.hip stage_layout)
+  sh.off = (p->stage == UUO_STAGE_CHAMFER) ? 4 * F : (p->stage == UUO_STAGE_MARKER) ? 207 * F : 3 * F + 1;
+  std::memset(stats, 0, sizeof(*stats));
+  return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user, &sh);
+}
+
 // ---------------------------------------------------------------------------------------------------- lock-step batches
 // B independent L-BFGS problems of one stage and one (F, M) -- the candidate body parts of find_best_part_fits
 // (reference markers/markers_utils.py:416-610 solves them one after the other) or the yaw hypotheses of
@@ -1940,11 +2167,36 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
 // its own stack; where the single-problem driver would poll for its evaluation's report it yields to the scheduler, which
 // merges the launches the live problems recorded, stages their argument structs with one host-to-device copy, issues them
 // in the canonical order of uuo_common.h and waits for every report.  A problem that converged simply stops taking part.
+#include <sys/mman.h>
 #include <ucontext.h>
+
+// a coroutine's stack: 1 MB of private pages below a PROT_NONE guard page (lbfgs_run calls into the HIP runtime -- lazy code
+// object loading on a first launch, error strings -- from it: an overflow must fault, not run into a neighbour's heap)
+struct CoStack {
+  static constexpr size_t kGuard = 4096, kBytes = 1024 * 1024;
+  void* base = nullptr;
+  bool alloc() {
+    void* p = mmap(nullptr, kGuard + kBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (p == MAP_FAILED) return false;
+    if (mprotect(p, kGuard, PROT_NONE) != 0) {  // stacks grow down: the guard sits at the low end
+      munmap(p, kGuard + kBytes);
+      return false;
+    }
+    base = p;
+    return true;
+  }
+  void* sp() const { return (char*)base + kGuard; }
+  CoStack() = default;
+  CoStack(const CoStack&) = delete;
+  CoStack& operator=(const CoStack&) = delete;
+  ~CoStack() {
+    if (base) munmap(base, kGuard + kBytes);
+  }
+};
 
 struct BatchCo {
   ucontext_t ctx;
-  std::vector<unsigned char> stack;
+  CoStack stack;
   UuoRecorder rec;
   StageObjective obj;
   LbWs* w = nullptr;
@@ -1966,8 +2218,7 @@ struct uuo_batch {
   unsigned char* d_blob = nullptr;
   size_t blob_cap = 0;
   int lb_n = 0, lb_hist = 0;
-  size_t blob_used = 0;        // bytes of the blob the last flush staged
-  bool blob_pending[2] = {false, false};  // per blob half: that flush's host-to-device copy may not have executed yet
+  UuoStaging staging;          // which parts of the blob may still be waiting for their host-to-device copy (uuo_common.h)
   double* d_scores = nullptr;  // uuo_batch_part_scores: [nb][F][2] per-frame sums
   double* h_scores = nullptr;
   size_t score_cap = 0;
@@ -2010,7 +2261,6 @@ extern "C" int uuo_batch_destroy(uuo_batch_t* b) {
 extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int B, uuo_batch_t** out) {
   UUO_REQUIRE(model && out, "uuo_batch_create: null argument");
   UUO_REQUIRE(stage >= 0 && stage <= 2 && F > 0 && M > 0 && B > 0 && B <= 4096, "uuo_batch_create: bad stage / sizes");
-  UUO_REQUIRE(model->nnz <= 4, "uuo_batch_create: needs the sparse skin-weight tables (<= 4 weights per vertex)");
   uuo_batch* b = new uuo_batch();
   b->model = model;
   b->stage = stage;
@@ -2035,6 +2285,7 @@ extern "C" int uuo_batch_create(uuo_model_t* model, int stage, int F, int M, int
     }
   }
   b->blob_cap = 2 * ((size_t)B * 12 * UUO_OP_ARG_MAX + 4096);  // two halves: one per stepping group
+  b->staging.region_cap = b->blob_cap / 2;
   if (rc == 0 && hipHostMalloc((void**)&b->h_blob, b->blob_cap, hipHostMallocDefault) != hipSuccess) rc = -12;
   if (rc == 0 && hipMalloc((void**)&b->d_blob, b->blob_cap) != hipSuccess) rc = -12;
   if (rc == 0 && hipStreamCreateWithFlags(&b->s2, hipStreamNonBlocking) != hipSuccess) rc = -5;
@@ -2082,17 +2333,11 @@ static int batch_flush(uuo_batch* b, hipStream_t s, std::vector<BatchCo>& cos, i
   unsigned char* h_blob = b->h_blob + region_off;
   unsigned char* d_blob = b->d_blob + region_off;
   UUO_REQUIRE(total <= region_cap, "batch: argument staging buffer too small");
-  // A flush overwrites the pinned blob from its start, so the previous flush's (asynchronous) host-to-device copy must
-  // have executed.  Inside a solve that is implied -- every round waits for its evaluations' reports, which follow the copy
-  // on the stream -- and the flag is cleared there; a flush that follows another one with no such wait synchronises first.
-  if (b->blob_pending[region] && total > 0) {
+  // A flush overwrites its region of the pinned blob from the start, so the region's previous (asynchronous) host-to-device
+  // copy must have executed.  Inside a solve that is implied -- every round waits for its evaluations' reports, which follow
+  // the copy on the stream; a flush that follows another one with no such wait synchronises first (UuoStaging).
+  if (b->staging.begin_flush(region, total))
     UUO_HIP_CHECK(hipStreamSynchronize(s));  // (a region is only ever used on one stream between two joins)
-    b->blob_pending[region] = false;
-  }
-  if (total > 0) {
-    b->blob_pending[region] = true;
-    b->blob_used = total;
-  }
   size_t fill[UUO_OP_COUNT];
   for (int k = 0; k < UUO_OP_COUNT; ++k) fill[k] = 0;
   for (int i = i0; i < i1; ++i)
@@ -2210,10 +2455,9 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
   }
 
   std::vector<BatchCo> cos(nb);
-  const size_t stack_bytes = 256 * 1024;
   for (int i = 0; i < nb; ++i) {
     BatchCo& c = cos[i];
-    c.stack.resize(stack_bytes);
+    UUO_REQUIRE(c.stack.alloc(), "uuo_batch_solve: could not map a coroutine stack");
     c.obj.fit = b->fits[i];
     c.obj.p = &problems[i];
     c.obj.fused_stats = true;
@@ -2225,14 +2469,21 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
     c.s = s;
     std::memset(&stats[i], 0, sizeof(stats[i]));
     getcontext(&c.ctx);
-    c.ctx.uc_stack.ss_sp = c.stack.data();
-    c.ctx.uc_stack.ss_size = stack_bytes;
+    c.ctx.uc_stack.ss_sp = c.stack.sp();
+    c.ctx.uc_stack.ss_size = CoStack::kBytes;
     c.ctx.uc_link = &g_sched_ctx;
     const unsigned long long pv = (unsigned long long)reinterpret_cast<uintptr_t>(&c);
     makecontext(&c.ctx, (void (*)())batch_co_entry, 2, (unsigned)(pv & 0xFFFFFFFFull), (unsigned)(pv >> 32));
   }
   const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
-  g_batch_yield = batch_yield_impl;
+  struct YieldScope {  // whatever path leaves this function, the thread is out of batch mode afterwards
+    YieldScope() { g_batch_yield = batch_yield_impl; }
+    ~YieldScope() {
+      g_batch_yield = nullptr;
+      uuo_recorder = nullptr;
+      g_cur_co = nullptr;
+    }
+  } yield_scope;
   int result = 0;
   // Two stepping groups (halves of the batch), each on its own stream: while the kernels of one group's round run, the
   // host steps the other group's coroutines and stages their launches (the ~1 ms of host work per round of a 200-problem
@@ -2290,7 +2541,7 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       }
     }
     // a report of this group arrived: its flush's copy (enqueued before the kernels that reported) has executed
-    if (waited_any) b->blob_pending[g] = false;
+    if (waited_any) b->staging.report_arrived(g);
     return 0;
   };
   auto group_live = [&](int g) {
@@ -2306,18 +2557,16 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       if (result == 0) result = step_group(g);
     }
   }
-  g_batch_yield = nullptr;
-  uuo_recorder = nullptr;
   if (ngroups == 2) {  // join: whatever follows on the caller's stream sees both groups' results
     if (hipEventRecord(b->ev_join, b->s2) == hipSuccess) (void)hipStreamWaitEvent(s, b->ev_join, 0);
   }
   if (result == 0) {
     UUO_HIP_CHECK(hipStreamSynchronize(s));  // (problems that ended in the last round flushed their final copies there)
-    b->blob_pending[0] = b->blob_pending[1] = false;
   } else {
     (void)hipStreamSynchronize(s);  // unfinished coroutines are abandoned with their stacks; nothing of theirs is in flight
     if (ngroups == 2) (void)hipStreamSynchronize(b->s2);
   }
+  b->staging.synchronized();  // both paths: the second stream was joined to s (or synchronised) before s was waited for
   return result;
 }
 
@@ -2355,10 +2604,10 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
     UUO_HIP_CHECK(hipHostMalloc((void**)&b->h_scores, out_doubles * sizeof(double), hipHostMallocDefault));
     b->score_cap = out_doubles;
   }
-  // The forward's argument structs were staged in the first b->blob_used bytes of the pinned blob and their host-to-device
-  // copy may not have executed yet (it is asynchronous): the score kernel's structs go BEHIND them, never over them.
-  const size_t score_off = (b->blob_used + 255) / 256 * 256;
-  UUO_REQUIRE(score_off + (size_t)nb * sizeof(PartScoreArgs) <= b->blob_cap / 2, "uuo_batch_part_scores: staging buffer too small");
+  // The forward's argument structs sit at the start of region 0 of the pinned blob and their host-to-device copy may not
+  // have executed yet (it is asynchronous): the score kernel's structs go BEHIND them, never over them.
+  size_t score_off = 0;
+  UUO_REQUIRE(b->staging.append(0, (size_t)nb * sizeof(PartScoreArgs), &score_off), "uuo_batch_part_scores: staging buffer too small");
   PartScoreArgs* ha = reinterpret_cast<PartScoreArgs*>(b->h_blob + score_off);
   for (int i = 0; i < nb; ++i) {
     PartScoreArgs a;
@@ -2381,7 +2630,7 @@ extern "C" int uuo_batch_part_scores(uuo_batch_t* b, void* stream, const uuo_pro
   if (rc) return rc;
   UUO_HIP_CHECK(hipMemcpyAsync(b->h_scores, b->d_scores, out_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
   UUO_HIP_CHECK(hipStreamSynchronize(s));
-  b->blob_pending[0] = b->blob_pending[1] = false;
+  b->staging.synchronized();
   for (int i = 0; i < nb; ++i) {
     double cx = 0.0, cy = 0.0;
     const double* o = b->h_scores + (size_t)i * F * 2;
@@ -2445,6 +2694,39 @@ extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, 
 
 #ifdef UUO_DEBUG_HOOKS
 // ---- everything below exists only in libuuo_hip_debug.so (tests/ and tools/) ------------------------------------------
+// host-only: runs a script of staging operations against a fresh UuoStaging (no device call: usable without a GPU).
+// ops[3 i ..] = {code, region, bytes}; code 0 begin_flush -> out = {needs a synchronise first, 0}; 1 append -> {fits, offset};
+// 2 report_arrived -> {0, 0}; 3 synchronized -> {0, 0}.  After every op out[4 i + 2 ..] = pending[0] | pending[1] << 1, used[region].
+extern "C" int uuo_debug_staging_script(const long long* ops, int n_ops, long long region_cap, long long* out) {
+  UUO_REQUIRE(ops && out && n_ops >= 0 && region_cap > 0, "uuo_debug_staging_script: bad arguments");
+  UuoStaging st;
+  st.region_cap = (size_t)region_cap;
+  for (int i = 0; i < n_ops; ++i) {
+    const int code = (int)ops[3 * i], r = (int)ops[3 * i + 1];
+    const size_t bytes = (size_t)ops[3 * i + 2];
+    UUO_REQUIRE(r == 0 || r == 1, "uuo_debug_staging_script: region must be 0 or 1");
+    long long a = 0, bval = 0;
+    if (code == 0) {
+      a = st.begin_flush(r, bytes) ? 1 : 0;
+    } else if (code == 1) {
+      size_t off = 0;
+      a = st.append(r, bytes, &off) ? 1 : 0;
+      bval = (long long)off;
+    } else if (code == 2) {
+      st.report_arrived(r);
+    } else if (code == 3) {
+      st.synchronized();
+    } else {
+      UUO_REQUIRE(false, "uuo_debug_staging_script: unknown op");
+    }
+    out[4 * i] = a;
+    out[4 * i + 1] = bval;
+    out[4 * i + 2] = (st.pending[0] ? 1 : 0) | (st.pending[1] ? 2 : 0);
+    out[4 * i + 3] = (long long)st.used[r];
+  }
+  return 0;
+}
+
 // optimiser self-test on analytic objectives (tests/test_gpu_parity.py::test_lbfgs_* compare with torch.optim.LBFGS on
 // the CPU, evaluation by evaluation through `cb`)
 extern "C" int uuo_lbfgs_selftest(void* stream, int kind, int n, float* d_x, const uuo_lbfgs_options_t* opt,

@@ -93,7 +93,7 @@ struct UuoTree {
 struct uuo_model {
   int V = 0;    // vertices
   int VP = 0;   // padded to a multiple of 128
-  int nnz = 0;  // max non-zero skin weights per vertex (sparse path iff <= 4)
+  int nnz = 0;  // max non-zero skin weights per vertex (<= 4: uuo_model_create refuses anything else)
   // device tables
   float* P3 = nullptr;    // [3][VP/16][14][64][4]  blend basis (posedirs rows then shapedirs rows) in MFMA-operand order:
                           //   per (coord, 16-vertex unit, group of 4 K-steps) one 1-KB block = lane l's 4 B values
@@ -101,7 +101,6 @@ struct uuo_model {
   float* PT = nullptr;    // [V][3][UUO_KB]    per-vertex posedirs rows (backward / gather-LBS)
   float* ST = nullptr;    // [V][3][10]        shapedirs
   float* vt = nullptr;    // [V][3]
-  float* W = nullptr;     // [V][24]           dense skin weights
   int* Wi = nullptr;      // [VP][4]           sparse joint ids (ascending), -1 padded -> 0 weight
   float* Ww = nullptr;    // [VP][4]
   UuoTree* tree = nullptr;  // device copy
@@ -171,7 +170,8 @@ int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox);
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
-                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts);
+                           const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts,
+                           float* bbox_compact = nullptr);
 int uuo_launch_identity_transforms(hipStream_t s, int count, float* A);
 int uuo_launch_nn_cull(hipStream_t s, int F, int M, int V, int nunits, const float* markers, const float* verts,
                        const float* bbox, unsigned long long* packed, int* flags);
@@ -209,7 +209,8 @@ int uuo_launch_part_scores(hipStream_t s, const void* d_args, int count, int F);
 // before d_stats (the solver's {max|d| bits, pad, out[9]}) into `host` (pinned, device-visible) and then publishes
 // `seq` in host[10]; the solver polls that word instead of enqueueing a copy and synchronising the stream.
 struct UuoEvalReport {
-  unsigned long long* host = nullptr;  // [11]
+  unsigned long long* host = nullptr;  // [24]: 0..9 the block, 10 the sequence word, 11..13 max|g| / sum|g| / g.g over the problem's
+                                       // own parameters (all but the betas), 14..23 its shape gradient (as doubles)
   unsigned long long seq = 0;
 };
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
@@ -268,6 +269,38 @@ inline bool uuo_record(int op, int gx, int gy, const A& a) {
   uuo_recorder->ops.push_back(r);
   return true;
 }
+// Host-only bookkeeping of a batch's pinned argument blob (two regions: one per stepping group / stream).  A flush stages
+// its structs from the START of its region and copies them to the device asynchronously, so before the next flush may
+// overwrite the region that copy must have executed: inside a solve this is implied (the round's reports follow the copy
+// on the stream: report_arrived), otherwise the caller has to synchronise the region's stream first (begin_flush says
+// so).  Structs that must coexist with the last flush's (the score kernel's) are appended BEHIND it and never need a
+// wait.  The GPU memory fault of round 2 (two processes on one device) was this state machine done wrong; it has no
+// device code and is unit-tested on the CPU through uuo_debug_staging_script (tests/test_abi.py).
+struct UuoStaging {
+  size_t region_cap = 0;
+  size_t used[2] = {0, 0};           // bytes of each region holding structs whose copy may still be pending
+  bool pending[2] = {false, false};  // the region's last host-to-device copy may not have executed yet
+  // a new flush of `bytes` (> 0) at the start of region r; returns true iff the region's stream must be synchronised first
+  bool begin_flush(int r, size_t bytes) {
+    if (bytes == 0) return false;
+    const bool need_sync = pending[r];
+    pending[r] = true;
+    used[r] = bytes;
+    return need_sync;
+  }
+  // `bytes` behind everything region r holds; false if they do not fit.  *off is relative to the region's start.
+  bool append(int r, size_t bytes, size_t* off) {
+    const size_t at = (used[r] + 255) / 256 * 256;
+    if (at + bytes > region_cap) return false;
+    *off = at;
+    used[r] = at + bytes;
+    pending[r] = true;
+    return true;
+  }
+  void report_arrived(int r) { pending[r] = false; }  // a kernel enqueued after the region's copy has reported
+  void synchronized() { pending[0] = pending[1] = false; }  // every stream that used the blob has been synchronised
+};
+
 #define UUO_BATCH_PICK(ArgsT, batch)                                      \
   const ArgsT a = (batch)[blockIdx.z];                                    \
   if ((int)blockIdx.x >= a.h.gx || (int)blockIdx.y >= a.h.gy) return;

@@ -390,7 +390,7 @@ class _StageProblem:
     stage = -1
 
     def __init__(self, model: DeviceModel, markers, o_pose, o_betas, root, w_data, w_pose, w_betas,
-                 assign=None, subset=None):
+                 assign=None, subset=None, own_workspace: bool = True):
         self.model = model
         self.lib = model.lib
         self.device = model.device
@@ -401,8 +401,10 @@ class _StageProblem:
         self.root = _f32(root, "root_orient").reshape(self.F, 9) if root is not None else None
         self.assign = assign.to(device=self.device, dtype=torch.int32).contiguous() if assign is not None else None
         self.subset = subset.to(device=self.device, dtype=torch.int32).contiguous() if subset is not None else None
-        self._fit_ref = model.fit(self.F, self.M)  # keeps the workspace alive while this problem exists
-        self.fit = self._fit_ref.ptr
+        # the calling thread's (F, M) workspace, kept alive while this problem exists; a problem that is only ever solved
+        # as a member of a lock-step batch (solve_batch: the batch owns its workspaces) does not need one
+        self._fit_ref = model.fit(self.F, self.M) if own_workspace else None
+        self.fit = self._fit_ref.ptr if own_workspace else None
         p = UuoProblem()
         p.stage, p.F, p.M = self.stage, self.F, self.M
         p.d_markers = self.markers.data_ptr()
@@ -417,9 +419,15 @@ class _StageProblem:
         self.problem = p
         self.n = int(self.lib.uuo_problem_num_params(byref(p)))
 
+    def _need_workspace(self):
+        if self.fit is None:  # created for a lock-step batch only: give it the thread's workspace on first standalone use
+            self._fit_ref = self.model.fit(self.F, self.M)
+            self.fit = self._fit_ref.ptr
+
     def evaluate(self, x: torch.Tensor, want_nn: bool = True):
         """One closure evaluation: (loss, flat grad, nn index [F,M] int32 | None)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        self._need_workspace()
         loss = torch.empty((1,), dtype=torch.float32, device=self.device)
         grad = torch.empty((self.n,), dtype=torch.float32, device=self.device)
         nn = None
@@ -438,6 +446,7 @@ class _StageProblem:
         `callback(i, loss)` runs after every closure evaluation; `point_callback(i, loss, x_eval)` additionally gets a
         host copy of the evaluated parameter vector (one device -> host copy per evaluation: iter_fn support)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        self._need_workspace()
         opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
                               float(tolerance_change), 0, 0)
         stats = UuoLbfgsStats()
@@ -495,6 +504,7 @@ class _StageProblem:
         fused HIP closure (uuo_closure_eval), the update itself a handful of element-wise device ops; x updated in place.
         No host synchronisation inside the loop unless a callback asks for the loss."""
         assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        self._need_workspace()
         p = x.detach().requires_grad_(True)
         opt = torch.optim.Adam([p], lr=lr, betas=betas, eps=eps)
         loss = torch.empty((1,), dtype=torch.float32, device=self.device)
@@ -516,6 +526,7 @@ class _StageProblem:
                 "stop_reason": "num_steps", "device_ms": 0.0, "driver": "adam"}
 
     def time_closure(self, x: torch.Tensor, iters: int = 20, dominant_only: bool = False) -> float:
+        self._need_workspace()
         ms = c_float(0.0)
         with torch.cuda.device(self.device):
             check(self.lib.uuo_time_closure(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
@@ -583,14 +594,15 @@ class PartProblem(_StageProblem):
 
     stage = UUO_STAGE_PART
 
-    def __init__(self, smpl_inference, markers, pose_body, o_betas, root_orient, vertex_indices, config):
+    def __init__(self, smpl_inference, markers, pose_body, o_betas, root_orient, vertex_indices, config,
+                 own_workspace: bool = True):
         losses = config["stages"]["part"]["losses"]
         unsupported = set(losses) - {"chamfer", "reg_betas"}
         if unsupported:
             raise NotImplementedError("part-stage losses outside the shipped configs: %s" % sorted(unsupported))
         super().__init__(smpl_inference.device_model, markers, pose_body, o_betas, root_orient,
                          float(losses.get("chamfer", 0.0)), 0.0, float(losses.get("reg_betas", 0.0)),
-                         subset=vertex_indices)
+                         subset=vertex_indices, own_workspace=own_workspace)
         # the body pose is a constant of this problem: let the library compute its pose-corrective blend once
         self.problem.pose_cache_id = next(_POSE_CACHE_IDS)
 

@@ -7,7 +7,6 @@ from __future__ import annotations
 import contextlib
 import functools
 import itertools
-import os
 import queue
 from collections.abc import Callable
 from concurrent.futures import ThreadPoolExecutor
@@ -18,11 +17,16 @@ import torch
 
 from .body_model import SMPL_JOINT_NAMES
 from .device_lbfgs import DeviceLBFGS
-from .engine import PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
+from .engine import _f32, PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
 from .losses import chamfer_distance
 from .transforms import compute_root_orient_z
 
 LAST_STATS: Dict[str, list] = {}
+
+# how independent solves are scheduled on the device (never what they compute); see find_best_part_fits /
+# multimodal_video_mocap.  These were environment variables in round 2: the product path reads no environment now.
+EXECUTION_DEFAULTS = {"subtree_lockstep": True, "subtree_batch": 256, "subtree_threads": 4,
+                      "hypothesis_lockstep": False, "hypothesis_threads": 4}
 
 
 def get_joint_name(joint_id: int) -> str:
@@ -45,38 +49,50 @@ def get_aabb_volume(aabb: torch.Tensor) -> torch.Tensor:
     return d[:, 0] * d[:, 1] * d[:, 2]
 
 
-def rigid_distance_matrix(points: np.ndarray) -> np.ndarray:
-    """mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1)) for every marker pair, as the
-    reference's double loop computes it (markers/markers_utils.py:254-259), evaluated for all pairs at once.  The
-    values are bit-equal to the per-pair calls: the norm is sqrt((dx*dx + dy*dy) + dz*dz) in the input precision and
-    np.std reduces the contiguous frame axis of each pair with the same pairwise summation as the 1-D call."""
-    pts = np.asarray(points)
-    P = np.ascontiguousarray(pts.transpose(1, 2, 0))  # [M, 3, F]
-    d = P[:, None, 0, :] - P[None, :, 0, :]
-    s = d * d
-    d = P[:, None, 1, :] - P[None, :, 1, :]
-    s += d * d
-    d = P[:, None, 2, :] - P[None, :, 2, :]
-    s += d * d
-    np.sqrt(s, out=s)
-    return np.std(s, axis=-1).astype(np.float64)
+def rigid_distance_matrix(points, device=None) -> np.ndarray:
+    """mat[i, j] = np.std(np.linalg.norm(points[:, i] - points[:, j], axis=-1)) for every marker pair, as the reference's
+    double loop computes it (markers/markers_utils.py:254-259) -- on the GPU (uuo_rigid_distance_std: one thread per pair
+    walking numpy's pairwise-summation tree, so the values are bit-equal to numpy's; the clustering below cuts them at
+    5 mm).  `points` [F, M, 3]: a CUDA tensor, or a host array that is uploaded to `device` (default: the current CUDA
+    device).  There is no host implementation: the reference's loop lives in oracle/stages_ref.py as the checker."""
+    from . import _lib
+    from .engine import _ptr, check, current_stream
+
+    if torch.is_tensor(points) and points.is_cuda:
+        pts = points.detach()
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("rigid_distance_matrix runs on the GPU only (no CUDA/HIP device visible)")
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        pts = torch.as_tensor(np.asarray(points)).to(dev)
+    if pts.dtype != torch.float32:
+        # the reference hands float32 marker arrays (multimodal.py:187); numpy would compute a float64 input in float64
+        raise TypeError("rigid_distance_matrix expects float32 points (got %s)" % pts.dtype)
+    pts = pts.contiguous()
+    F, M = int(pts.shape[0]), int(pts.shape[1])
+    out = torch.empty((M, M), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(_lib.load().uuo_rigid_distance_std(current_stream(pts.device), F, M, _ptr(pts), _ptr(out)),
+              "uuo_rigid_distance_std")
+    return out.cpu().numpy().astype(np.float64)
 
 
-def segment_rigid(points: np.ndarray) -> List[List[int]]:
+def segment_rigid(points, device=None) -> List[List[int]]:
     """Clusters markers that keep their mutual distance over time (std of the pairwise distance, average-linkage
-    agglomerative clustering cut at 5 mm).  points [F, M, 3] -> list of marker-id lists."""
+    agglomerative clustering cut at 5 mm).  points [F, M, 3] (host array as in the reference, or a CUDA tensor) -> list of
+    marker-id lists.  The O(M^2 F) rigidity matrix is computed on the GPU; the clustering of the M x M matrix is host logic."""
     from sklearn.cluster import AgglomerativeClustering
 
-    mat = rigid_distance_matrix(points)
+    mat = rigid_distance_matrix(points, device=device)
     labels = AgglomerativeClustering(n_clusters=None, distance_threshold=0.005, metric="precomputed",
                                      linkage="average").fit(mat).labels_
     return [np.where(labels == v)[0].tolist() for v in np.unique(labels).tolist()]
 
 
-def filter_rigid(points: np.ndarray, labels: np.ndarray) -> np.ndarray:
+def filter_rigid(points, labels: np.ndarray, device=None) -> np.ndarray:
     """Every rigid cluster of markers takes the median of its members' labels (reference markers_utils.py:220-241)."""
     output = np.array(labels)
-    for group in segment_rigid(points):
+    for group in segment_rigid(points, device=device):
         output[:, group] = np.median(labels[:, group])
     return output
 
@@ -204,9 +220,16 @@ def find_best_part_fits(
     foot_contacts: torch.Tensor = None,
     visualize_fn=None,
     iter_fn: Callable = None,
+    execution: Dict = None,
 ):
     """Rigidly aligns the HMR body to the marker cloud for every candidate body part (yaw about z, translation,
-    shape) and keeps the best by two-directional chamfer distance.  Returns the reference's dict."""
+    shape) and keeps the best by two-directional chamfer distance.  Returns the reference's dict.
+
+    `execution` (not in the reference; how the independent candidate solves are scheduled, never what they compute):
+    {"subtree_lockstep": True, "subtree_batch": 256, "subtree_threads": 4} -- one lock-step batch of up to
+    `subtree_batch` candidates (default), or `subtree_threads` host threads with a stream each.  An `execution` section of
+    `config` sets the same keys; the argument wins."""
+    exe = dict(EXECUTION_DEFAULTS, **(config.get("execution") or {}), **(execution or {}))
     st = config["stages"]["part"]
     if st["mode"] != "cluster":
         raise NotImplementedError("stages.part.mode 'network' needs segmenter checkpoints the reference does not ship")
@@ -365,14 +388,20 @@ def find_best_part_fits(
         from .engine import part_scores_batch, solve_batch
 
         vis = [part_vertex_indices(st_) for st_ in subtrees]
-        probs = [PartProblem(smpl_inference, markers_subset, pose_body, o_betas, root_orient, vi, config) for vi in vis]
+        # the candidates share their inputs: one contiguous fp32 copy each (uuo_batch_solve requires ONE body-pose pointer
+        # for the shared pose-blend cache; a strided / fp64 caller tensor would otherwise be re-materialised per problem),
+        # and no standalone (F, M) workspace per problem -- the batch owns its own
+        pose_c, markers_c = _f32(pose_body, "pose_body"), _f32(markers_subset, "markers")
+        root_c, betas_c = _f32(root_orient, "root_orient"), _f32(o_betas, "betas")
+        probs = [PartProblem(smpl_inference, markers_c, pose_c, betas_c, root_c, vi, config, own_workspace=False)
+                 for vi in vis]
         for p_ in probs[1:]:  # one body pose, one pose-blend cache for the whole batch
             p_.problem.pose_cache_id = probs[0].problem.pose_cache_id
         z0 = torch.zeros((1, 1, 1), device=device)
         x_all = probs[0].pack(z0, trans0, o_betas).repeat(len(probs), 1)   # same start for every candidate (:418-421)
         xs = [x_all[i] for i in range(len(probs))]
         out = []
-        chunk = int(os.environ.get("UUO_SUBTREE_BATCH", "256"))
+        chunk = max(1, int(exe["subtree_batch"]))
         for c0 in range(0, len(probs), chunk):
             sl = slice(c0, c0 + chunk)
             stats_l = solve_batch(probs[sl], xs[sl], max_iter=st["num_iters"], lr=1.0,
@@ -389,11 +418,11 @@ def find_best_part_fits(
     if extra:
         fit_subtree = fit_subtree_general
 
-    n_threads = min(len(subtrees), int(os.environ.get("UUO_SUBTREE_THREADS", "4")))
+    n_threads = min(len(subtrees), max(1, int(exe["subtree_threads"])))
     if extra:
         n_threads = 1  # autograd graphs of concurrent candidates would share the engine's forward scratch
     lockstep = (not extra and iter_fn is None and device.type == "cuda" and len(subtrees) > 1
-                and os.environ.get("UUO_SUBTREE_LOCKSTEP", "1") != "0")
+                and bool(exe["subtree_lockstep"]))
     if lockstep:
         results = fit_subtrees_lockstep()
     elif n_threads > 1 and device.type == "cuda":

@@ -8,7 +8,6 @@ root stages are disabled in every shipped config and are not built (SURVEY.md 8f
 from __future__ import annotations
 
 import contextlib
-import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -22,6 +21,7 @@ from .engine import set_workspace_group, set_workspace_slot, worker_pool, worker
 from .markers_utils import find_best_part_fits, get_aabb, get_aabb_volume, segment_rigid
 from .optimization import (compute_marker_labels_from_coords, compute_nearest_points, get_marker_mask,
                            optim_chamfer, optim_markers, weighted_chamfer_distance)
+from .losses import knn_points_k1
 from .smpl import SmplInference
 from .transforms import compute_root_orient_z, normalize_rot
 
@@ -76,9 +76,14 @@ def multimodal_video_mocap(
     save_iterations: bool = False,
     visualize_fits: bool = False,
     smpl_inference: SmplInference = None,
+    execution: Dict = None,
 ) -> Dict:
     """See the reference docstring (multimodal.py:49-84) for the meaning of the inputs and output keys.
-    `smpl_inference` (extension) lets callers reuse one model/workspace across sequences."""
+    `smpl_inference` (extension) lets callers reuse one model/workspace across sequences.  `execution` (extension; how the
+    independent solves are scheduled on the device, never what they compute -- markers_utils.EXECUTION_DEFAULTS):
+    {"hypothesis_lockstep": False, "hypothesis_threads": 4, "subtree_lockstep": True, "subtree_batch": 256,
+    "subtree_threads": 4}; an `execution` section of `config` sets the same keys, the argument wins."""
+    exe = dict(markers_utils.EXECUTION_DEFAULTS, **(config.get("execution") or {}), **(execution or {}))
     if visualize_fits:
         raise NotImplementedError("visualize_fits renders with pyrender, not built")
     for key in ("reprojection_full", "root"):
@@ -170,7 +175,7 @@ def multimodal_video_mocap(
         if config["stages"]["part"]["mode"] != "cluster":
             raise NotImplementedError("stages.part.mode 'network' is not built")
         segmented_markers = torch.zeros((markers.shape[:2]))
-        for group_index, group in enumerate(segment_rigid(markers.detach().cpu().numpy())):
+        for group_index, group in enumerate(segment_rigid(markers)):
             segmented_markers[:, group] = group_index
         segmented_markers = segmented_markers.long().to(device)
         mean_out = smpl_inference(poses=o_pose_body, betas=o_betas * 0, root_orient=o_root_orient, trans=o_trans * 0)
@@ -222,7 +227,7 @@ def multimodal_video_mocap(
         filter_output = find_best_part_fits(
             markers=markers, pose_body=o_pose_body, betas=o_betas, root_orient=o_root_orient,
             marker_labels=segmented_markers, smpl_inference=smpl_inference, hierarchy=smpl_inference.smpl.parents,
-            config=config, foot_contacts=o_foot_contacts, iter_fn=save_iter_fn, **camera)
+            config=config, foot_contacts=o_foot_contacts, iter_fn=save_iter_fn, execution=exe, **camera)
         stats["part"] = list(markers_utils.LAST_STATS.get("part", []))
         segmented_markers = filter_output["marker_labels"].detach().clone()
         root_orient = filter_output["root_orient"].detach().clone()
@@ -254,7 +259,7 @@ def multimodal_video_mocap(
         joint of the vertex they were placed on, optionally smoothed over the rigid clusters."""
         labels = compute_marker_labels_from_coords(smpl_inference, coords, num_frames).detach().cpu().numpy()
         if config["stages"]["segment"]["rigid_filter"]:
-            labels = markers_utils.filter_rigid(markers.detach().cpu().numpy(), labels)
+            labels = markers_utils.filter_rigid(markers, labels)
         return labels
 
     group = workspace_group()  # worker threads do not inherit thread-locals
@@ -271,6 +276,26 @@ def multimodal_video_mocap(
             score = weighted_chamfer_distance(x=markers, y=vertices, x_weights=get_marker_mask(markers),
                                               single_directional=True)[0]
         return float(score)
+
+    def yaw_scores_batched(records):
+        """The scores of ALL hypotheses from one SMPL forward over their stacked frames and one K=1 search (the reference
+        runs one forward + one chamfer call per hypothesis, :576-599; four of each were 4 ms of an `hmr_full` fit).  Each
+        hypothesis' frames go through exactly the arithmetic of `yaw_score` (the kernels treat frames independently, the
+        masked mean is taken on a copy of the hypothesis' own [F, M] block): bit-identical scores."""
+        H, Fh = len(records), records[0]["pose_body"].shape[0]
+        cat = lambda key: torch.from_numpy(np.concatenate([r[key] for r in records], axis=0)).to(device)  # noqa: E731
+        betas_all = torch.from_numpy(np.concatenate([np.repeat(r["betas"][None], Fh, axis=0) for r in records], axis=0)).to(device)
+        with torch.no_grad():
+            vertices = smpl_inference(poses=cat("pose_body"), betas=betas_all, root_orient=cat("root_orient"),
+                                      trans=cat("trans"))["vertices"]
+            d, _ = knn_points_k1(markers.repeat(H, 1, 1), vertices)
+            w = get_marker_mask(markers)
+            wf = w.to(d.dtype)
+            wsum = w.sum()
+            if wsum == 0.0:
+                return [0.0] * H
+            per = torch.stack([(d[k * Fh:(k + 1) * Fh].clone() * wf).sum() / wsum for k in range(H)])
+        return [float(v) for v in per.cpu()]
 
     def final_stage(r, labels):
         """Final placement + marker L-BFGS from a hypothesis' marker-stage result (reference :601-677)."""
@@ -425,8 +450,8 @@ def multimodal_video_mocap(
                 and save_iter_fn is None and not verbose and not recompute_labels
                 and (not run_chamfer or optimization.lockstep_supported(config, "chamfer"))
                 and (not run_marker or optimization.lockstep_supported(config, "marker"))
-                and os.environ.get("UUO_HYPOTHESIS_LOCKSTEP", "0") == "1")
-    n_threads = min(len(root_orient_angles), int(os.environ.get("UUO_HYPOTHESIS_THREADS", "4")))
+                and bool(exe["hypothesis_lockstep"]))
+    n_threads = min(len(root_orient_angles), max(1, int(exe["hypothesis_threads"])))
     if not run_chamfer and not run_marker:
         n_threads = 1  # nothing to solve per hypothesis (hmr_full.yaml): worker threads would only add their start-up
     if recompute_labels and config["stages"]["segment"]["granularity"] == "part":
@@ -493,10 +518,10 @@ def multimodal_video_mocap(
 
     # ---- best yaw hypothesis by masked chamfer distance (first minimum wins)
     best_angle_chamfer, best_angle, best_index = np.inf, None, 0
-    yaw_scores = []
-    for k, (root_orient_angle, local) in enumerate(zip(root_orient_angles, results)):
-        score = yaw_score(smpl_marker_rotations[root_orient_angle])
-        yaw_scores.append(score)
+    records = [smpl_marker_rotations[a] for a in root_orient_angles]
+    batched = device.type == "cuda" and len(records) > 1 and len({r["pose_body"].shape[0] for r in records}) == 1
+    yaw_scores = yaw_scores_batched(records) if batched else [yaw_score(r) for r in records]
+    for k, (root_orient_angle, score) in enumerate(zip(root_orient_angles, yaw_scores)):
         if score < best_angle_chamfer:
             best_angle_chamfer, best_angle, best_index = score, root_orient_angle, k
     stats["yaw_scores"] = yaw_scores
