@@ -39,6 +39,13 @@ class UuoLbfgsStats(ctypes.Structure):
 
 
 EVAL_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_float, c_void_p)
+# uuo_gather_fn (include/uuo_hip.h): int gather(user, const double* mine, int n, double* all /* [world][n] */)
+GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(ctypes.c_double), c_int, POINTER(ctypes.c_double))
+
+
+class UuoShared(ctypes.Structure):
+    _fields_ = [("gather", GATHER_FN), ("user", c_void_p), ("rank", c_int32), ("world", c_int32)]
+
 
 _SIGNATURES = {
     "uuo_last_error": (c_char_p, []),
@@ -68,6 +75,8 @@ _SIGNATURES = {
     "uuo_closure_eval": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_void_p, c_void_p, c_void_p]),
     "uuo_lbfgs_solve": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, POINTER(UuoLbfgsOptions),
                                 POINTER(UuoLbfgsStats), c_void_p, c_void_p]),
+    "uuo_lbfgs_solve_shared": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, POINTER(UuoLbfgsOptions),
+                                       POINTER(UuoLbfgsStats), POINTER(UuoShared), c_void_p, c_void_p]),
     "uuo_time_closure": (c_int, [c_void_p, c_void_p, POINTER(UuoProblem), c_void_p, c_int, c_int,
                                  POINTER(c_float)]),
     "uuo_lbfgs_minimize": (c_int, [c_void_p, c_int, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats), c_void_p,

@@ -14,8 +14,13 @@ evals, termination tests in torch's order) -- the same mirror as the device driv
 in COEFFICIENT SPACE from Gram matrices of the (s, y) history, so an iteration needs a fixed, small number of collectives
 instead of 2 x history dependent dot products:
 
-* per closure evaluation ONE ``all_gather`` of ``[loss, g.d, |g|_1, g.g, max|g|, grad(shared)...]`` (<= 16 + n_shared doubles);
-* per iteration ONE ``all_gather`` of the new Gram row / column (``4 k + 4`` doubles) and one of ``max|d|``.
+* per closure evaluation TWO ``all_gather``s when there are shared entries (the loss and the local shared gradients first;
+  the statistics of the completed gradient second), one otherwise;
+* per iteration ONE ``all_gather`` of the new Gram row / column (``5 k + 4`` doubles) and one of ``max|d|``.
+
+Since round 3 this Python driver is the CHECKER: the product path (engine._StageProblem.solve_shared) runs the joint problem
+on the device solver itself (csrc/solver.hip, ``uuo_lbfgs_solve_shared``: one gather per evaluation, one per iteration,
+through ``Reducer.gather_array``); tests compare the two.
 
 Messages are < 1 KB: latency-bound, the 7 x 153 GB/s xGMI links of an MI355X node are irrelevant here.  Every
 rank reduces the gathered partials in rank order in fp64, so all ranks take bit-identical decisions and stay in lock-step
@@ -40,6 +45,9 @@ class LocalReducer:
     def gather(self, values: Sequence[float]) -> np.ndarray:
         return np.asarray(values, dtype=np.float64)[None, :]
 
+    def gather_array(self, mine: np.ndarray, out: np.ndarray) -> None:
+        out[0, :] = mine
+
 
 class DistReducer:
     """Partials of every rank through ONE all_gather on a torch.distributed process group ("nccl" = RCCL on ROCm, "gloo" in
@@ -54,11 +62,27 @@ class DistReducer:
         self.rank = dist.get_rank(group)
         self.device = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
 
+        self._bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
     def gather(self, values: Sequence[float]) -> np.ndarray:
         local = torch.tensor(list(values), dtype=torch.float64, device=self.device)
         out = torch.empty(self.world * local.numel(), dtype=torch.float64, device=self.device)  # flat: gloo wants 1-D
         self.dist.all_gather_into_tensor(out, local, group=self.group)
         return out.cpu().numpy().reshape(self.world, local.numel())
+
+    def gather_array(self, mine: np.ndarray, out: np.ndarray) -> None:
+        """all_gather of a float64 vector into out[world, n] (rank order), through buffers that are allocated once per
+        message length: the hook of the device solver (uuo_gather_fn) calls this once per closure evaluation."""
+        n = int(mine.shape[0])
+        bufs = self._bufs.get(n)
+        if bufs is None:
+            bufs = (torch.empty(n, dtype=torch.float64, device=self.device),
+                    torch.empty(self.world * n, dtype=torch.float64, device=self.device))
+            self._bufs[n] = bufs
+        local, full = bufs
+        local.copy_(torch.from_numpy(mine))
+        self.dist.all_gather_into_tensor(full, local, group=self.group)
+        out[...] = (full.cpu() if full.is_cuda else full).numpy().reshape(self.world, n)
 
 
 def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):

@@ -470,12 +470,50 @@ class _StageProblem:
                 "device_ms": stats.device_ms}
 
     def solve_shared(self, x: torch.Tensor, reducer, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
-                     tolerance_change: float = 1e-9, history_size: int = 100) -> Dict:
+                     tolerance_change: float = 1e-9, history_size: int = 100,
+                     callback: Optional[Callable[[int, float], None]] = None) -> Dict:
         """EXTENSION (BASELINE configs[3], not reference behaviour): this stage's problem on every rank of `reducer`'s
-        process group solved as ONE joint L-BFGS problem whose shape vector (the 10 betas) is shared by all ranks' sequences
-        -- dist_lbfgs.ShardedLBFGS drives the fused HIP closure of each rank; per evaluation the ranks exchange
-        [loss, d loss / d betas (10), g.d, |g|_1, g.g, max|g|], per iteration the new Gram row of the history (< 1 KB).
-        x is updated in place; betas end bit-identical on every rank."""
+        process group solved as ONE joint L-BFGS problem whose shape vector (the 10 betas) is shared by all ranks' sequences,
+        ON THE DEVICE SOLVER (uuo_lbfgs_solve_shared: the same driver, kernels and closures as `solve`).  What crosses the
+        ranks goes through `reducer.gather_array` (one all_gather of 16 doubles per closure evaluation, one of 627 per
+        iteration, one of 10 at the start -- rank 0's betas win); every rank reduces the gathered tables in rank order, so
+        all ranks take the same decisions and end with bit-identical betas.  x is updated in place."""
+        from ._lib import GATHER_FN, UuoShared
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        self._need_workspace()
+        opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
+                              float(tolerance_change), 0, 0)
+        stats = UuoLbfgsStats()
+        world = int(reducer.world)
+        failure = []
+
+        def gather(user, mine, n, out):
+            try:
+                reducer.gather_array(np.ctypeslib.as_array(mine, shape=(n,)), np.ctypeslib.as_array(out, shape=(world, n)))
+                return 0
+            except BaseException as exc:  # an exception must not unwind through the C driver
+                failure.append(exc)
+                return 5
+
+        gather_c = GATHER_FN(gather)
+        shared = UuoShared(gather_c, None, int(reducer.rank), world)
+        cb = EVAL_CALLBACK(lambda user, i, loss, d_x_eval: callback(i, loss)) if callback is not None else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.uuo_lbfgs_solve_shared(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),
+                                                 byref(opt), byref(stats), byref(shared),
+                                                 ctypes.cast(cb, c_void_p) if cb else None, None)
+        if failure:
+            raise failure[0]
+        check(rc, "uuo_lbfgs_solve_shared")
+        return {"n_iter": stats.n_iter, "n_eval": stats.n_eval, "first_loss": stats.first_loss,
+                "final_loss": stats.final_loss, "stop_reason": STOP_REASONS[stats.stop_reason],
+                "device_ms": stats.device_ms, "driver": "device-lbfgs(shared betas, world=%d)" % world}
+
+    def solve_shared_reference(self, x: torch.Tensor, reducer, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
+                               tolerance_change: float = 1e-9, history_size: int = 100) -> Dict:
+        """The joint problem of `solve_shared` on dist_lbfgs.ShardedLBFGS (a Python L-BFGS in coefficient space over the
+        fused HIP closure of each rank; round 2's driver): kept as the CHECKER of the device route."""
         from .dist_lbfgs import ShardedLBFGS
 
         assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()

@@ -521,6 +521,15 @@ def multimodal_video_mocap(
     records = [smpl_marker_rotations[a] for a in root_orient_angles]
     batched = device.type == "cuda" and len(records) > 1 and len({r["pose_body"].shape[0] for r in records}) == 1
     yaw_scores = yaw_scores_batched(records) if batched else [yaw_score(r) for r in records]
+    shared_red = shared_betas_reducer()
+    if shared_red is not None and shared_red.world > 1:
+        # shared betas (extension): hypothesis k was ONE joint solve over all ranks, so the ranks must agree on the winner --
+        # it is picked from the scores summed over the ranks (rank order, fp64: the same number everywhere); a rank that
+        # picked by its own score could start the final stage from the betas of a different joint solve
+        table = np.zeros((shared_red.world, len(yaw_scores)))
+        shared_red.gather_array(np.asarray(yaw_scores, dtype=np.float64), table)
+        stats["yaw_scores_local"] = yaw_scores
+        yaw_scores = [float(v) for v in table.sum(axis=0)]
     for k, (root_orient_angle, score) in enumerate(zip(root_orient_angles, yaw_scores)):
         if score < best_angle_chamfer:
             best_angle_chamfer, best_angle, best_index = score, root_orient_angle, k
