@@ -148,7 +148,7 @@ def fit_quality(smpl, seq, out, dev):
             "marker_chamfer_m2": score}
 
 
-def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals):
+def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals, cpu_quota=None):
     """Reference-faithful CPU path (oracle 'port', same dense materialisations, torch autograd) timed per closure
     type on the host cores and scaled by the closure counts of the GPU fit of the same sequence."""
     from oracle import stages_ref
@@ -198,12 +198,14 @@ def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals):
         "value": F / total if total > 0 else None,
         "unit": "frames/s",
         "cores": torch.get_num_threads(),
+        "cpu_quota": cpu_quota,
         "kind": "port",
         "sample": "oracle (reference-faithful torch-CPU port with the reference's dense materialisations) timed for %d "
                   "closure evaluations (forward+backward) per stage type at F=%d, M=%d: %s s/eval; extrapolated by the "
                   "GPU fit's closure counts %s (L-BFGS vector work and marker placement excluded -> optimistic for "
-                  "the CPU); nproc=%d" % (n_cpu_evals, F, M, {k: round(v, 3) for k, v in per_eval.items()}, n_eval,
-                                          os.cpu_count()),
+                  "the CPU); %d torch threads = the process' CPU quota (the host shows %d cores)"
+                  % (n_cpu_evals, F, M, {k: round(v, 3) for k, v in per_eval.items()}, n_eval, torch.get_num_threads(),
+                     os.cpu_count()),
         "seconds_per_eval": per_eval,
     }
 
@@ -286,9 +288,12 @@ def main():
     from uuo_mocap_amd.body_model import synthetic_smpl
     from uuo_mocap_amd.config import packaged_config
     from uuo_mocap_amd.engine import ChamferProblem
+    from uuo_mocap_amd.parallel import host_cpu_budget, limit_host_threads
     from uuo_mocap_amd.smpl import SmplInference
     from uuo_mocap_amd.synthetic import make_sequence
 
+    # torch's CPU pool follows the process' CPU quota, not the host's core count (parallel.limit_host_threads explains)
+    host_threads = limit_host_threads()
     tables = synthetic_smpl(0)
     cfg = packaged_config(args.config)
     if args.hypothesis_lockstep:
@@ -426,7 +431,9 @@ def main():
             result["other_configs"]["hmr_full"]["note"] = \
                 "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals)
+            torch.set_num_threads(host_cpu_budget())  # the CPU leg gets every CPU of the quota (nothing else runs now)
+            result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals, host_cpu_budget())
+            torch.set_num_threads(host_threads)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result))

@@ -117,3 +117,54 @@ def test_two_gloo_ranks_reproduce_the_joint_solve(tmp_path, lr):
     np.testing.assert_allclose(res[0]["st"]["final_loss"], min(losses_ref), rtol=1e-4, atol=1e-7)
     joint = torch.cat([res[0]["x"][:N_LOCAL], res[1]["x"][:N_LOCAL], res[0]["x"][N_LOCAL:]])
     np.testing.assert_allclose(joint.numpy(), x_ref.numpy(), atol=5e-5)
+
+
+def _gather_main(rank, world, port, out_dir):
+    import ctypes
+
+    import torch.distributed as dist
+
+    from uuo_mocap_amd._lib import GATHER_FN
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        red = DistReducer()
+        got = {}
+
+        # exactly the adapter engine._StageProblem.solve_shared hands to uuo_lbfgs_solve_shared, called the way the C driver
+        # calls it: raw double pointers, several message lengths, repeatedly (the buffers are cached per length)
+        def gather(user, mine, n, out):
+            red.gather_array(np.ctypeslib.as_array(mine, shape=(n,)), np.ctypeslib.as_array(out, shape=(world, n)))
+            return 0
+
+        fn = GATHER_FN(gather)
+        for rep in range(3):
+            for n in (10, 16, 627):
+                mine = (np.arange(n, dtype=np.float64) + 1000.0 * rank + 0.25 * rep)
+                out = np.full((world, n), np.nan)
+                rc = fn(None, mine.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n,
+                        out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+                assert rc == 0
+                got[(rep, n)] = out
+        torch.save(got, os.path.join(out_dir, "gather%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_hook_of_the_device_solver_over_gloo(tmp_path):
+    """The uuo_gather_fn adapter (rank-ordered all_gather of float64 vectors through torch.distributed) with two gloo
+    ranks: every rank receives every rank's vector, in rank order, for each of the message lengths the device solver sends
+    (10 betas, 16 evaluation statistics, 627 Gram-row entries).  The C driver itself needs a GPU: tests/test_gpu_multirank.py."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_gather_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "gather%d.pt" % r), weights_only=False) for r in range(world)]
+    for key, table in res[0].items():
+        rep, n = key
+        assert np.array_equal(table, res[1][key])
+        for r in range(world):
+            assert np.array_equal(table[r], np.arange(n, dtype=np.float64) + 1000.0 * r + 0.25 * rep)

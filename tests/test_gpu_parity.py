@@ -352,6 +352,36 @@ def test_rigidity_matrix_kernel_is_bit_equal_to_numpy(smpl, dev):
         assert MU.segment_rigid(torch.from_numpy(pts).to(dev)) == stages_ref.segment_rigid(pts)
 
 
+def test_stage_less_hypotheses_batched_are_bit_identical(smpl, dev):
+    """hmr_full.yaml runs no chamfer / marker stage: the four yaw hypotheses are then built by one batched expression and
+    scored by one batched forward (multimodal.hypotheses_without_stages / yaw_scores_batched) instead of four of each.
+    Against the one-by-one path (execution={'batch_trivial_hypotheses': False}): same records, same scores, same output,
+    bit for bit."""
+    import contextlib
+    import copy
+    import io
+
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
+
+    cfg = packaged_config("hmr_full")
+    seq = make_sequence(smpl.tables, seed=12, num_frames=45, num_markers=20)
+    got = []
+    for batched in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                         save_stages=True, smpl_inference=smpl,
+                                         execution={"batch_trivial_hypotheses": batched})
+        got.append((out, copy.deepcopy(dict(last_run_stats()))))
+    (a, sa), (b, sb) = got
+    assert sa["yaw_scores"] == sb["yaw_scores"] and sa["best_angle"] == sb["best_angle"]
+    for k in ("trans", "root_orient", "pose_body", "betas"):
+        assert torch.equal(a[k], b[k]), k
+    for stage in a["stages"]:
+        for k, v in a["stages"][stage].items():
+            assert np.array_equal(v, b["stages"][stage][k]), (stage, k)
+    assert np.array_equal(np.asarray(a["markers_labels"]), np.asarray(b["markers_labels"]))
+
+
 def test_device_lbfgs_with_a_host_closure_follows_torch(dev):
     """DeviceLBFGS (uuo_lbfgs_minimize: the device driver calling back a closure composed in Python) against
     torch.optim.LBFGS on the same closure: a well-scaled coupled quadratic over three parameter tensors, one of which

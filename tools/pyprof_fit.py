@@ -23,6 +23,8 @@ ap.add_argument("--markers", type=int, default=10)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--top", type=int, default=35)
 a = ap.parse_args()
+from uuo_mocap_amd.parallel import limit_host_threads  # noqa: E402
+limit_host_threads()
 dev = torch.device("cuda:0")
 tables = synthetic_smpl()
 smpl = SmplInference(dev, tables=tables)

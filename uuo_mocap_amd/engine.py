@@ -253,12 +253,17 @@ class DeviceModel:
             h = self._batches.get(key)
             if h is not None and h.shape == (int(F), int(M)) and h.capacity >= count:
                 return h
+            # small batches (the yaw hypotheses) exactly.  Candidate lists of the part stage: the count is data-dependent
+            # (89 .. 202 for a 10-marker limb) and re-creating a batch costs ~100 ms (one pinned allocation, two events and
+            # a 25-MB workspace per member), so a batch starts at 256 members and only ever grows, by halves
+            if count <= 8:
+                cap = max(int(count), 4)
+            else:
+                prev = h.capacity if h is not None and h.shape == (int(F), int(M)) else 0
+                cap = max(256, (int(count) + 63) // 64 * 64, (prev * 3 // 2 + 63) // 64 * 64 if prev else 0)
             if h is not None:
                 del self._batches[key]
                 h = None
-            # small batches (the yaw hypotheses) exactly; candidate lists in whole 32s, so that a few more candidates in
-            # the next sequence re-use the batch instead of re-creating its workspaces
-            cap = max(int(count), 4) if count <= 8 else (int(count) + 31) // 32 * 32
             ptr = c_void_p()
             with torch.cuda.device(self.device):
                 check(self.lib.uuo_batch_create(self.handle, int(stage), int(F), int(M), cap, byref(ptr)), "uuo_batch_create")

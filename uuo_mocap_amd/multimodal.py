@@ -393,6 +393,23 @@ def multimodal_video_mocap(
                 stream.synchronize()
         return local
 
+    def hypotheses_without_stages():
+        """hmr_full.yaml / hmr_part.yaml: neither the chamfer nor the marker stage runs, so a hypothesis is the part-stage
+        result with its root turned by the hypothesis' yaw and both rotations normalised (what fit_hypothesis leaves in
+        that case) -- all of them from ONE batched expression and one read-back instead of four of each.  Element-wise the
+        same operations as fit_hypothesis (tests/test_gpu_parity.py compares the records bit for bit)."""
+        H = len(root_orient_angles)
+        angles = torch.tensor(root_orient_angles, dtype=torch.float32).reshape(H, 1, 1, 1).to(device)
+        rz = compute_root_orient_z(angles.expand(H, root_orient.shape[0], 1, 1))           # [H, F, 1, 3, 3]
+        z_all = normalize_rot(rz @ root_orient.detach()[None])                                # [H, F, 1, 3, 3]
+        host = _np_dict(trans=trans.detach(), root_orient=z_all, betas=betas.detach()[0], pose_body=normalize_rot(pose_body.detach()))
+        out = []
+        for h in range(H):
+            rec = {"trans": host["trans"].copy(), "root_orient": host["root_orient"][h].copy(), "betas": host["betas"].copy(),
+                   "pose_body": host["pose_body"].copy()}
+            out.append({"chamfer": rec, "marker": {k: v.copy() for k, v in rec.items()}})
+        return out
+
     def fit_hypotheses_lockstep():
         """All yaw hypotheses stage by stage: their chamfer solves are one lock-step batch (one launch per kernel and
         round for all of them instead of one kernel stream per host thread), then the placements, then the marker solves as
@@ -487,6 +504,8 @@ def multimodal_video_mocap(
             for i in mine:
                 local[i] = fit_hypothesis(0, root_orient_angles[i], None, marker_labels)
         results = hyp_shard.exchange(local, len(root_orient_angles))
+    elif not run_chamfer and not run_marker and device.type == "cuda" and bool(exe.get("batch_trivial_hypotheses", True)):
+        results = hypotheses_without_stages()
     elif lockstep:
         results = fit_hypotheses_lockstep()
     elif n_threads > 1 and device.type == "cuda":

@@ -24,6 +24,42 @@ def world_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def host_cpu_budget() -> int:
+    """CPUs this process may actually use: the smaller of the scheduler affinity and the cgroup CPU quota (cpu.max).  A GPU
+    box hands a process a QUOTA (16 CPUs per GPU here) while `nproc` still shows every core of the host (256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) // int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, quota // int(fh2.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def limit_host_threads(reserve: int = 4) -> int:
+    """Caps torch's intra-op CPU thread pool at the process' CPU budget minus `reserve` (the fitting threads busy-poll the
+    GPU's evaluation reports; the HIP runtime has threads of its own).  Found in round 3: torch sizes its OpenMP pool by
+    the HOST's core count (256), any CPU tensor op of a fit (a dtype conversion of the marker array is enough) wakes all of
+    them, they spin, the cgroup quota of 16 CPUs is burnt within milliseconds and the kernel throttles the whole process
+    for the rest of the 100 ms period -- a 50 ms stall in every third `hmr_full` fit.  Call once from the application (the
+    runner and bench.py do); a library does not change global thread settings on import.  Returns the thread count set."""
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))  # torchrun: the ranks of this host share the quota
+    n = max(1, host_cpu_budget() // local_world - max(0, int(reserve)))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def shard_indices(num_items: int, rank: int, world: int) -> List[int]:
     """Round-robin assignment of sequence ids to ranks (balanced to within one item)."""
     return list(range(rank, num_items, world))

@@ -230,6 +230,9 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.dataset not in CAMERAS:
         raise KeyError(args.dataset)
+    from .parallel import limit_host_threads
+
+    limit_host_threads()  # torch's CPU pool follows the process' CPU quota, not the host's core count
     n = run(args)
     print("wrote", n, "sequence(s)")
 
