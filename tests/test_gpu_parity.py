@@ -602,13 +602,19 @@ def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
     if kind == 1:  # the quadratic's first interpolation is below fp32 noise (see the test above): no head comparison there
         head = min(12, len(ref["loss"]), len(got["loss"]))
         np.testing.assert_allclose(got["loss"][:head], ref["loss"][:head], rtol=1e-3)
+    print("OBS analytic lbfgs kind %d n %d lr %g: f_dev %.3g f_ref %.3g; evals dev %d ref %d; max |dx| %.3g"
+          % (kind, n, lr, f_dev, f_ref, got["n_eval"], len(ref["loss"]), np.abs(got["x_final"] - ref["x_final"]).max()))
     if kind == 0:
-        assert abs(got["n_eval"] - len(ref["loss"])) <= max(10, len(ref["loss"]) // 4), (got["n_eval"], len(ref["loss"]))
-        assert f_dev <= max(f_ref * 10, 1e-6), (f_dev, f_ref)
-        np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=2e-3)
+        # observed (round 3): evaluation counts 60 / 63 and 135 / 150, final values 7e-9 vs 2e-9 (both at the stopping
+        # tolerance), iterates 1e-5 apart; bars at about three times that
+        assert abs(got["n_eval"] - len(ref["loss"])) <= max(10, len(ref["loss"]) // 6), (got["n_eval"], len(ref["loss"]))
+        assert f_dev <= max(f_ref * 5, 3e-8), (f_dev, f_ref)
+        np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=3e-5)
     else:
-        assert f_dev <= max(5 * f_ref, 1e-3), (f_dev, f_ref)
-        assert abs(got["n_eval"] - len(ref["loss"])) <= max(10, len(ref["loss"]) // 4), (got["n_eval"], len(ref["loss"]))
+        # observed: 2.83e-10 vs 2.84e-10, 214 vs 220 evaluations, iterates 5e-6 apart
+        assert f_dev <= max(3 * f_ref, 1e-8), (f_dev, f_ref)
+        assert abs(got["n_eval"] - len(ref["loss"])) <= max(10, len(ref["loss"]) // 10), (got["n_eval"], len(ref["loss"]))
+        np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=3e-5)
 
 
 def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
@@ -643,9 +649,13 @@ def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
     # by the same amount under a 1e-6 m perturbation.
     # Yardstick (tools/reference_sensitivity.py, this fixture): the reference vs itself with +1e-6 m on the initial
     # translation ends 29 % apart in loss (0.160 vs 0.205), 378 vs 230 evaluations, median |dtrans| 1.2e-2 m.
+    print("OBS chamfer stage: final loss ours %.6g ref %.6g (rel %.3g); evals ours %d ref %d; median |dtrans| %.3g m"
+          % (st["final_loss"], g["losses"][-1], abs(st["final_loss"] - g["losses"][-1]) / g["losses"][-1], st["n_eval"],
+             len(g["losses"]), np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"]))))
     assert abs(st["final_loss"] - g["losses"][-1]) <= 0.3 * g["losses"][-1], (st["final_loss"], g["losses"][-1])
-    assert 0.3 * len(g["losses"]) <= st["n_eval"] <= 3.0 * len(g["losses"]), (st["n_eval"], len(g["losses"]))
-    assert np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"])) < 5e-2
+    # (observed: 0.2124 vs 0.1804 = 18 % -- inside the reference-vs-itself yardstick above; 484 vs 364 evaluations; 6 mm)
+    assert 0.5 * len(g["losses"]) <= st["n_eval"] <= 2.0 * len(g["losses"]), (st["n_eval"], len(g["losses"]))
+    assert np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"])) < 2e-2
     assert root.requires_grad and pose.requires_grad
 
 
@@ -665,6 +675,9 @@ def test_marker_stage_solve_tracks_reference(smpl, golden, dev):
                   one_hot, _t(g["img_mask"], dev), smpl, cfg)
     st = LAST_STATS["marker"]
     np.testing.assert_allclose(st["first_loss"], g["losses"][0], rtol=2e-5)
+    print("OBS marker stage: final loss ours %.6g ref %.6g (rel %.3g); median |dtrans| %.3g m"
+          % (st["final_loss"], g["losses"][-1], abs(st["final_loss"] - g["losses"][-1]) / g["losses"][-1],
+             np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"]))))
     assert abs(st["final_loss"] - g["losses"][-1]) <= 0.05 * g["losses"][-1], (st["final_loss"], g["losses"][-1])
     assert np.median(np.abs(trans.detach().cpu().numpy() - g["out_trans"])) < 1e-2
 
@@ -686,9 +699,13 @@ def test_find_best_part_fits_matches_reference(smpl, golden, dev, tag, cfg_name)
     np.testing.assert_array_equal(out["chain"], g["out_chain"])
     # converged solves: same labels (a marker between two body parts may flip), parameters to the stopping tolerance
     agree = (out["marker_labels"].cpu().numpy() == g["out_marker_labels"]).mean()
-    assert agree >= 0.9, agree
-    assert np.median(np.abs(out["trans"].cpu().numpy() - g["out_trans"])) < 2e-2
-    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=0.3)
+    print("OBS part stage %s: labels agree %.3f; median |dtrans| %.3g m; max |dbetas| %.3g"
+          % (tag, agree, np.median(np.abs(out["trans"].cpu().numpy() - g["out_trans"])),
+             np.abs(out["betas"].cpu().numpy() - g["out_betas"]).max()))
+    # observed: every label equal, translations 1.0 / 2.4 mm apart (median), betas 0.014 apart; bars at about 3x
+    assert agree >= 0.95, agree
+    assert np.median(np.abs(out["trans"].cpu().numpy() - g["out_trans"])) < 8e-3
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["out_betas"], atol=0.05)
     np.testing.assert_allclose(out["aabb_volume_ratio"].cpu().numpy(), g["out_aabb"], rtol=1e-4)
     assert out["marker_weights"].shape == g["out_marker_weights"].shape
 
@@ -718,12 +735,15 @@ def test_end_to_end_matches_reference(smpl, oracle_smpl, golden, dev, tag, cfg_n
     assert sorted(out["stages"].keys()) == sorted(str(s) for s in g["stage_keys"])
     for key, shape in (("trans", (F, 3)), ("root_orient", (F, 1, 3, 3)), ("pose_body", (F, 23, 3, 3)), ("betas", (F, 10))):
         assert tuple(out[key].shape) == shape and out[key].device.type == "cpu"
-    assert (out["markers_labels"] == g["out_markers_labels"]).mean() >= 0.9
+    print("OBS e2e %s: labels agree %.3f" % (tag, (out["markers_labels"] == g["out_markers_labels"]).mean()))
+    assert (out["markers_labels"] == g["out_markers_labels"]).mean() >= 0.95  # observed: all equal
     np.testing.assert_array_equal(out["chain"], g["out_chain"])
     ref_v = oracle_smpl(_t(g["out_pose_body"]), _t(g["out_betas"]), _t(g["out_root_orient"]), _t(g["out_trans"]))["vertices"]
     our_v = oracle_smpl(out["pose_body"], out["betas"], out["root_orient"], out["trans"])["vertices"]
     err = (ref_v - our_v).norm(dim=-1)
-    assert err.mean().item() < 5e-2, err.mean().item()  # two converged fits of the same inputs
+    # observed: hmr_full (a 27-parameter-per-frame rigid alignment) 4e-8 m; the full method cut off after 15 iterations per
+    # stage 8.2 mm (two fp32 trajectories of a non-convex fit: SURVEY.md section 7); bars at about three times that
+    assert err.mean().item() < (1e-6 if tag == "hmr_full" else 2.5e-2), err.mean().item()
     print("e2e %s: mean vertex distance to the reference fit %.2e m, max %.2e m" % (tag, err.mean().item(),
                                                                                    err.max().item()))
 

@@ -154,25 +154,6 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     tr[1] = a.src.trans[(size_t)f * 3 + 1];
     tr[2] = a.src.trans[(size_t)f * 3 + 2];
   }
-  // direction entries this thread will need for the fused g.d (fetched now, consumed after the item loop)
-  float dpre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (a.dir) {
-    if (tid >= 1 && tid < UUO_NUM_JOINTS && a.off_pose >= 0) {
-      const float* pd = a.dir + a.off_pose + ((size_t)f * 23 + (tid - 1)) * 9;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) dpre[e] = pd[e];
-    } else if (tid == 0) {
-      if (a.stage == UUO_STAGE_CHAMFER) dpre[0] = a.dir[a.off_z + f];
-      if (a.stage == UUO_STAGE_MARKER) {
-        const float* pd = a.dir + a.off_root + (size_t)f * 9;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) dpre[e] = pd[e];
-      }
-    } else if (tid >= 32 && tid < 35) {
-      dpre[0] = a.dir[a.off_trans + (size_t)f * 3 + (tid - 32)];
-    }
-  }
-
   {
     // Four items per wave, one per 16-lane group: the per-item scalar work (blended transform, residual, dv) used
     // to be computed redundantly by all 64 lanes for ONE item at a time; now the four DPP rows of a wave carry four
@@ -388,6 +369,26 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   // step is two LDS round trips and a few FMAs instead of hundreds of dependent instructions on one lane.
   const UuoTree* tree = a.tree;
   const int j = tid;
+  // direction entries this thread will need for the fused g.d: fetched here, AFTER the item loop (nine registers that are
+  // not live through it: at the 168-register budget they were nine spills inside the loop), their round trip overlaps the sweep
+  float dpre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.dir) {
+    if (tid >= 1 && tid < UUO_NUM_JOINTS && a.off_pose >= 0) {
+      const float* pd = a.dir + a.off_pose + ((size_t)f * 23 + (tid - 1)) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) dpre[e] = pd[e];
+    } else if (tid == 0) {
+      if (a.stage == UUO_STAGE_CHAMFER) dpre[0] = a.dir[a.off_z + f];
+      if (a.stage == UUO_STAGE_MARKER) {
+        const float* pd = a.dir + a.off_root + (size_t)f * 9;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) dpre[e] = pd[e];
+      }
+    } else if (tid >= 32 && tid < 35) {
+      dpre[0] = a.dir[a.off_trans + (size_t)f * 3 + (tid - 32)];
+    }
+  }
+
   // this thread's rotation inputs for the epilogue: issued here so their round trip overlaps the sweep
   float raw_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, po_pre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (!PART && j >= 1 && j < UUO_NUM_JOINTS && a.g_pose) {

@@ -789,6 +789,10 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
     else if (var2 == 1) SK2_LAUNCH(true, 1);
     else if (var2 == 2) SK2_LAUNCH(true, 2);
     else if (var2 == 4) SK2_LAUNCH(true, 4);
+    else if (var2 == 3) SK2_LAUNCH(true, 3);   // MFMAs only
+    else if (var2 == 5) SK2_LAUNCH(true, 5);   // B stream + LDS operand reads only
+    else if (var2 == 6) SK2_LAUNCH(true, 6);   // epilogue only
+    else if (var2 == 7) SK2_LAUNCH(true, 7);   // staging + task loop only
     else if (var2 == 16) SK2_LAUNCH(false, 0);
     else if (var2 == 8) SK2_LAUNCH(true, 8);
     else if (var2 == 9) SK2_LAUNCH(true, 9);
