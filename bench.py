@@ -305,7 +305,9 @@ def main():
     # distinct seeds for every warm-up and timed sequence of every rank (the solves stop on tolerances, so time depends on
     # the data: a timed step must not repeat a warm-up step)
     seed_base = 0 if MODE == "hypotheses" else rank * n_seq   # hypotheses mode: all ranks work on the SAME sequences
-    seqs = [make_sequence(tables, seed=seed_base + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb)
+    # shared_betas mode: step i of every rank is a different sequence of ONE subject (same ground-truth shape)
+    seqs = [make_sequence(tables, seed=seed_base + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb,
+                          subject_seed=(5000 + i) if MODE == "shared_betas" else None)
             for i in range(n_seq)]
 
     if args.roofline_only:

@@ -628,32 +628,53 @@ extern "C" int uuo_nn_argmin(void* stream, int N, int P1, int P2, const float* d
 // in f, then divide by the count; first index on ties.  Thread = vertex, marker group of 8 in registers
 // so each vertex row is read once per 8 markers.
 // ----------------------------------------------------------------------------------------------------
-#define ASSIGN_MG 8
+#define ASSIGN_MG 4    // markers per thread (a vertex row is read once per group; 13 groups x 27 vertex blocks fill the chip)
+#define ASSIGN_FC 32   // frames whose markers are staged in LDS at a time
+#define ASSIGN_U 4     // frames whose vertex loads are in flight together
+// The sum over the frames is SEQUENTIAL in f by definition (numpy's mean over axis 0 of the [F, M, V] matrix: K-E of
+// SURVEY.md section 4), one dependent add per frame and (marker, vertex); everything else of a frame -- the vertex load, the
+// distance, the square root -- is independent of it, so the loop stages the markers of 32 frames per barrier pair and keeps
+// the vertex loads of four frames in flight (round 2's loop had two barriers and one exposed L2 round trip per frame:
+// 320 us at 300 x 50; this one ~4x less).
 __global__ __launch_bounds__(256) void k_assign(int F, int M, int V, const float* __restrict__ verts,
                                                  const float* __restrict__ markers,
                                                  const unsigned char* __restrict__ valid, int count,
                                                  unsigned long long* __restrict__ out) {
-  __shared__ float sm[ASSIGN_MG * 3];
+  __shared__ float sm[ASSIGN_FC][ASSIGN_MG * 3];
+  __shared__ unsigned char sv[ASSIGN_FC];
   const int v = blockIdx.x * 256 + threadIdx.x;
+  const int vc = v < V ? v : V - 1;  // lanes past the end repeat the last vertex (their result is dropped)
   const int m0 = blockIdx.y * ASSIGN_MG;
   float acc[ASSIGN_MG];
 #pragma unroll
   for (int g = 0; g < ASSIGN_MG; ++g) acc[g] = 0.f;
-  for (int f = 0; f < F; ++f) {
-    if (!valid[f]) continue;  // uniform across the block
+  for (int f0 = 0; f0 < F; f0 += ASSIGN_FC) {
+    const int nf = min(ASSIGN_FC, F - f0);
     __syncthreads();
-    if (threadIdx.x < ASSIGN_MG * 3) {
-      const int g = threadIdx.x / 3, c = threadIdx.x % 3;
-      sm[threadIdx.x] = (m0 + g < M) ? markers[((size_t)f * M + m0 + g) * 3 + c] : 0.f;
+    for (int i = threadIdx.x; i < nf * ASSIGN_MG * 3; i += 256) {
+      const int ff = i / (ASSIGN_MG * 3), r = i - ff * (ASSIGN_MG * 3), g = r / 3, c = r - g * 3;
+      sm[ff][r] = (m0 + g < M) ? markers[((size_t)(f0 + ff) * M + m0 + g) * 3 + c] : 0.f;
     }
+    if (threadIdx.x < nf) sv[threadIdx.x] = valid[f0 + threadIdx.x];
     __syncthreads();
-    if (v < V) {
-      const float* pv = verts + ((size_t)f * V + v) * 3;
-      const float vx = pv[0], vy = pv[1], vz = pv[2];
+    for (int q0 = 0; q0 < nf; q0 += ASSIGN_U) {
+      float px[ASSIGN_U], py[ASSIGN_U], pz[ASSIGN_U];
 #pragma unroll
-      for (int g = 0; g < ASSIGN_MG; ++g) {
-        const float d2 = sqdist(vx, vy, vz, sm[g * 3], sm[g * 3 + 1], sm[g * 3 + 2]);
-        acc[g] = __fadd_rn(acc[g], uuo_sqrt_rn(d2));
+      for (int u = 0; u < ASSIGN_U; ++u) {
+        const int ff = min(q0 + u, nf - 1);
+        const float* pv = verts + ((size_t)(f0 + ff) * V + vc) * 3;
+        px[u] = pv[0]; py[u] = pv[1]; pz[u] = pv[2];
+      }
+#pragma unroll
+      for (int u = 0; u < ASSIGN_U; ++u) {
+        const int ff = q0 + u;
+        if (ff < nf && sv[ff]) {  // uniform across the block
+#pragma unroll
+          for (int g = 0; g < ASSIGN_MG; ++g) {
+            const float d2 = sqdist(px[u], py[u], pz[u], sm[ff][g * 3], sm[ff][g * 3 + 1], sm[ff][g * 3 + 2]);
+            acc[g] = __fadd_rn(acc[g], uuo_sqrt_rn(d2));
+          }
+        }
       }
     }
   }

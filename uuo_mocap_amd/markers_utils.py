@@ -263,15 +263,22 @@ def find_best_part_fits(
         if "similarity_threshold" in st:
             subtrees = remove_approximately_redundant_hierarchies(subtrees, similarity_threshold=0.9)
 
-    vertex_labels = torch.argmax(smpl_inference.get_lbs_weights(), dim=-1)
     trans0 = torch.median(markers, dim=1)[0]
     valid = torch.ones(num_frames, dtype=torch.bool, device=device)
 
     # vertices owned by each joint (dominant skin weight), in vertex order: one pass instead of 24 masked `nonzero`
-    # calls (each a device synchronisation) per candidate
-    order = torch.argsort(vertex_labels, stable=True)
-    counts = torch.bincount(vertex_labels, minlength=hierarchy.shape[0]).tolist()
-    joint_vertices = torch.split(order, counts)
+    # calls (each a device synchronisation) per candidate -- a constant of the body model, kept with it
+    cache = getattr(smpl_inference, "_part_vertex_cache", None)
+    if cache is None or cache[0] != (str(device), int(hierarchy.shape[0])):
+        vertex_labels = torch.argmax(smpl_inference.get_lbs_weights(), dim=-1)
+        order = torch.argsort(vertex_labels, stable=True)
+        counts = torch.bincount(vertex_labels, minlength=hierarchy.shape[0]).tolist()
+        cache = ((str(device), int(hierarchy.shape[0])), vertex_labels, torch.split(order, counts))
+        try:
+            smpl_inference._part_vertex_cache = cache
+        except AttributeError:  # a caller's own stand-in without attribute storage: just recompute every time
+            pass
+    _, vertex_labels, joint_vertices = cache
 
     def part_vertex_indices(subtree):
         return torch.cat([joint_vertices[j] for j in subtree], dim=0)

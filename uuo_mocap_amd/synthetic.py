@@ -112,9 +112,10 @@ class SyntheticSequence:
 
 def make_sequence(tables: SmplTables, seed: int = 0, num_frames: int = 300, num_markers: int = 50,
                   limb_only: bool = False, yaw_offset_deg: float = 100.0, dropout: float = 0.02,
-                  hmr_pose_noise: float = 0.1, hmr_beta_noise: float = 0.5) -> SyntheticSequence:
+                  hmr_pose_noise: float = 0.1, hmr_beta_noise: float = 0.5, subject_seed: int = None) -> SyntheticSequence:
     """One synthetic sequence: smooth GT motion, unlabeled-but-tracked markers 9.5 mm off the
-    surface with 1 mm noise and block dropout, and an HMR stand-in (noisy pose/shape, wrong yaw)."""
+    surface with 1 mm noise and block dropout, and an HMR stand-in (noisy pose/shape, wrong yaw).  `subject_seed` fixes the
+    ground-truth shape independently of `seed`: sequences of ONE subject (the shared-betas extension fits them together)."""
     F, M = num_frames, num_markers
     s = 7919 * (seed + 1)
     t = np.arange(F, dtype=np.float64) / max(F, 1)
@@ -140,7 +141,7 @@ def make_sequence(tables: SmplTables, seed: int = 0, num_frames: int = 300, num_
     walk = np.stack([np.convolve(np.pad(walk[:, a], 15, mode="edge"), k, mode="valid") for a in range(3)], axis=1)
     walk = np.clip(walk, -1.0, 1.0)
     trans = walk + np.array([0.0, 0.0, 0.95])[None]
-    beta_gt = np.clip(hash_normal(s + 7, 10), -2.0, 2.0)[None]
+    beta_gt = np.clip(hash_normal((s if subject_seed is None else 7919 * (int(subject_seed) + 1)) + 7, 10), -2.0, 2.0)[None]
 
     verts, joints, T_R = lbs_f64(tables, rot, beta_gt, trans)
 
