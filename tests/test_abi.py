@@ -309,3 +309,27 @@ def test_model_with_dense_skin_weights_is_refused():
     handle = ctypes.c_void_p()
     rc = lib.uuo_model_create(*[a.ctypes.data for a in arrs], V, ctypes.byref(handle))
     assert rc == -22 and b"non-zero skinning weights" in lib.uuo_last_error()
+
+
+def test_compact_solver_packing_index_map():
+    """The L-BFGS solver of the chamfer / marker stages runs on a compact packing that leaves out the third row of every
+    optimised rotation (csrc/closure.hip stage_layout: its gradient is identically zero there, so the entry never moves).
+    The map from solver coordinates to the reference's parameter packing, built on the host and evaluated inside the
+    kernels that write trial points, must be exactly: every coordinate of the reference's packing except entries 6, 7, 8
+    of each row-major 3x3 rotation, in order."""
+    dbg = _lib.load_debug()
+    for F in (1, 7, 300, 3000):
+        # chamfer: [trans 3F | z F | betas 10 | pose 23 x 9 x F]; marker: [pose | betas 10 | root 9F | trans 3F]
+        keep9 = np.arange(9) < 6
+        cham = np.concatenate([np.ones(4 * F + 10, bool), np.tile(keep9, 23 * F)])
+        mark = np.concatenate([np.tile(keep9, 23 * F), np.ones(10, bool), np.tile(keep9, F), np.ones(3 * F, bool)])
+        for stage, keep, n_full in ((_lib.UUO_STAGE_CHAMFER, cham, 211 * F + 10), (_lib.UUO_STAGE_MARKER, mark, 219 * F + 10)):
+            assert keep.size == n_full
+            out = np.full(n_full, -1, np.int32)
+            n = dbg.uuo_debug_index_map(stage, F, 1, out.ctypes.data)
+            assert n == int(keep.sum()) == (142 * F + 10 if stage == _lib.UUO_STAGE_CHAMFER else 147 * F + 10)
+            assert np.array_equal(out[:n], np.nonzero(keep)[0])
+            n = dbg.uuo_debug_index_map(stage, F, 0, out.ctypes.data)
+            assert n == n_full and np.array_equal(out, np.arange(n_full))
+    out = np.full(3 * 5 + 11, -1, np.int32)
+    assert dbg.uuo_debug_index_map(_lib.UUO_STAGE_PART, 5, 1, out.ctypes.data) == 26 and np.array_equal(out, np.arange(26))

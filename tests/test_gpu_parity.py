@@ -382,6 +382,79 @@ def test_stage_less_hypotheses_batched_are_bit_identical(smpl, dev):
     assert np.array_equal(np.asarray(a["markers_labels"]), np.asarray(b["markers_labels"]))
 
 
+@pytest.mark.parametrize("stage", ["chamfer", "marker"])
+def test_compact_solver_packing_is_exact(smpl, dev, stage):
+    """The solver drops the third rows of the optimised rotations from its vectors when they sit on their prior targets
+    (always, in the fit: csrc/closure.hip stage_layout) -- a third less L-BFGS history to stream.  (a) Against the full
+    packing (UUO_NO_COMPACT=1 in the debug flavour) the solve takes the same path: the same losses evaluation by evaluation
+    to fp64-summation-order noise, the same counts, the same iterate; the dropped parameter entries are bit-for-bit
+    untouched.  (b) A problem whose third rows do NOT sit on their targets is detected and runs on the full packing: bit
+    for bit the UUO_NO_COMPACT result."""
+    import ctypes
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd._lib import UuoLbfgsOptions, UuoLbfgsStats
+    from uuo_mocap_amd.engine import ChamferProblem, MarkerProblem, _ptr, current_stream
+
+    dbg = _lib.load_debug()
+    F, M = 37, 18
+    seq = make_sequence(smpl.tables, seed=31, num_frames=F, num_markers=M)
+    cfg = packaged_config("video_mocap")
+    markers = _t(np.nan_to_num(seq.markers.get_points()), dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    trans0 = torch.median(markers, dim=1)[0]
+    if stage == "chamfer":
+        prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, cfg)
+        pack = lambda pose: prob.pack(trans0, torch.zeros(F, 1, 1, device=dev), o_betas, pose)
+        lr, pose_slice = 0.1, slice(4 * F + 10, 211 * F + 10)
+    else:
+        prob = MarkerProblem(smpl, markers, o_pose, o_betas, torch.from_numpy(seq.gt["marker_vids"]).to(dev), cfg)
+        pack = lambda pose: prob.pack(pose, o_betas, root, trans0)
+        lr, pose_slice = 1.0, slice(0, 207 * F)
+
+    def solve(x0, no_compact):
+        x = x0.clone()
+        losses = []
+        cb = _lib.EVAL_CALLBACK(lambda user, i, loss, d_x_eval: losses.append(loss))
+        opt = UuoLbfgsOptions(60, 100, lr, 1e-7, 1e-9, 0, 0)
+        st = UuoLbfgsStats()
+        os.environ["UUO_NO_COMPACT"] = "1" if no_compact else "0"
+        try:
+            rc = dbg.uuo_lbfgs_solve(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), ctypes.byref(opt),
+                                     ctypes.byref(st), ctypes.cast(cb, ctypes.c_void_p), None)
+        finally:
+            os.environ.pop("UUO_NO_COMPACT", None)
+        assert rc == 0, dbg.uuo_last_error()
+        torch.cuda.synchronize()
+        return x, losses, (st.n_iter, st.n_eval, st.stop_reason)
+
+    # (a) third rows on their targets (the fit's situation)
+    x0 = pack(o_pose)
+    xc, lc, sc = solve(x0, False)
+    xf, lf, sf = solve(x0, True)
+    head = min(len(lc), len(lf), 40)
+    np.testing.assert_allclose(lc[:head], lf[:head], rtol=1e-6)
+    assert abs(sc[0] - sf[0]) <= 2 and abs(sc[1] - sf[1]) <= 3, (sc, sf)
+    assert float((xc - xf).abs().max()) < 1e-3
+    third = torch.zeros(F, 23, 9, dtype=torch.bool, device=dev)
+    third[..., 6:] = True
+    for x in (xc, xf):   # the entries without a solver coordinate did not move, in either packing
+        assert torch.equal(x[pose_slice].reshape(F, 23, 9)[third], x0[pose_slice].reshape(F, 23, 9)[third])
+    assert not torch.equal(xc, x0)
+    # (b) third rows off their targets: the compact packing would be wrong, the solve must not use it
+    pose_off = o_pose.clone()
+    pose_off[:, :, 2, :] += 0.01
+    x1 = pack(pose_off)
+    xa, la, sa = solve(x1, False)
+    xb, lb, sb = solve(x1, True)
+    assert torch.equal(xa, xb) and la == lb and sa == sb
+    moved = (xa[pose_slice].reshape(F, 23, 9)[third] != x1[pose_slice].reshape(F, 23, 9)[third]).float().mean().item()
+    assert moved > 0.5, moved  # the prior pulls those rows: they DO move there
+
+
 def test_device_lbfgs_with_a_host_closure_follows_torch(dev):
     """DeviceLBFGS (uuo_lbfgs_minimize: the device driver calling back a closure composed in Python) against
     torch.optim.LBFGS on the same closure: a well-scaled coupled quadratic over three parameter tensors, one of which

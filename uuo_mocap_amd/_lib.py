@@ -100,6 +100,7 @@ _DEBUG_SIGNATURES = {
     "uuo_debug_nn_flags": (c_int, [c_void_p, c_void_p]),
     "uuo_debug_small_coeffs": (c_int, [c_int, c_int, c_int, c_void_p]),
     "uuo_debug_time_small": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
+    "uuo_debug_index_map": (c_int, [c_int, c_int, c_int, c_void_p]),
     "uuo_debug_staging_script": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p]),
 }
 

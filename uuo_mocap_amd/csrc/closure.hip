@@ -41,7 +41,9 @@ struct BwdArgs {
   uuo_gptr<float> g_z;
   uuo_gptr<float> g_trans;
   uuo_gptr<const float> dir;   // optional: current search direction (same packing as the gradient) for the fused g.d
-  int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat vector (-1 = absent)
+  int off_pose, off_root, off_z, off_trans;  // section offsets inside the flat gradient / direction vector (-1 = absent)
+  int gs_pose, gs_root;  // floats per rotation in the gradient / direction vector: 9 (the reference's packing) or 6 (the
+                         // solver's compact packing: the third rows, whose gradient is identically zero, left out)
   uuo_gptr<const float> frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
   uuo_gptr<const float> C;       // part stage (k_bwd_part): the cached template + pose-corrective blend [F][V][3]
   // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
@@ -374,13 +376,13 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   float dpre[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (a.dir) {
     if (tid >= 1 && tid < UUO_NUM_JOINTS && a.off_pose >= 0) {
-      const float* pd = a.dir + a.off_pose + ((size_t)f * 23 + (tid - 1)) * 9;
+      const float* pd = a.dir + a.off_pose + ((size_t)f * 23 + (tid - 1)) * a.gs_pose;
 #pragma unroll
-      for (int e = 0; e < 9; ++e) dpre[e] = pd[e];
+      for (int e = 0; e < 9; ++e) dpre[e] = (e < 6 || a.gs_pose == 9) ? pd[e] : 0.f;
     } else if (tid == 0) {
       if (a.stage == UUO_STAGE_CHAMFER) dpre[0] = a.dir[a.off_z + f];
       if (a.stage == UUO_STAGE_MARKER) {
-        const float* pd = a.dir + a.off_root + (size_t)f * 9;
+        const float* pd = a.dir + a.off_root + (size_t)f * a.gs_root;
 #pragma unroll
         for (int e = 0; e < 6; ++e) dpre[e] = pd[e];
       }
@@ -518,11 +520,11 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
           psq = fmaf(diff, diff, psq);
         }
       }
-      float* pg = a.g_pose + ((size_t)f * 23 + (j - 1)) * 9;
+      float* pg = a.g_pose + ((size_t)f * 23 + (j - 1)) * a.gs_pose;
       float sd = 0.f, s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
-        pg[e] = gout[e];
+        if (e < 6 || a.gs_pose == 9) pg[e] = gout[e];  // (compact packing: entries 6..8 are exact zeros and have no slot)
         sd = fmaf(gout[e], dpre[e], sd);
         s1 += fabsf(gout[e]);
         s2 = fmaf(gout[e], gout[e], s2);
@@ -556,7 +558,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     } else if (a.stage == UUO_STAGE_MARKER) {
       float da[6];
       gs6d_backward(a.raw_root + (size_t)f * 9, sdR[0], da);
-      float* pg = a.g_root + (size_t)f * 9;
+      float* pg = a.g_root + (size_t)f * a.gs_root;
       float sd = 0.f, s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
@@ -566,7 +568,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
         s2 = fmaf(da[e], da[e], s2);
         sm = fmaxf(sm, fabsf(da[e]));
       }
-      pg[6] = pg[7] = pg[8] = 0.f;
+      if (a.gs_root == 9) pg[6] = pg[7] = pg[8] = 0.f;
       sstat[23][0] = sd; sstat[23][1] = s1; sstat[23][2] = s2; sstat[23][3] = sm;
     } else {
       const float* r0 = a.src.root + (size_t)f * 9;
@@ -798,22 +800,37 @@ int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int co
 // ----------------------------------------------------------------------------------------------------
 struct StageLayout {
   int n, off_trans, off_z, off_betas, off_pose, off_root;
+  int gs_pose = 9, gs_root = 9;  // floats per rotation
 };
 
-static StageLayout stage_layout(int stage, int F) {
-  StageLayout s{0, -1, -1, -1, -1, -1};
+// `compact`: the SOLVER's packing of the gradient / direction / history vectors (never of the parameters themselves): the
+// third row of every optimised rotation is left out.  Under the Gram-Schmidt (6D) normalisation the data term does not
+// depend on it, so its gradient is the prior's 2 c (raw - target) -- identically zero when the row starts on its target, as
+// it does in every stage of the fit (optim_chamfer starts the pose ON the HMR prior, optim_markers continues from there,
+// the final stage re-targets the prior at the normalised pose it starts from) -- and zero gradients mean zero search
+// directions: the entry never moves and contributes exact zeros to every dot product.  A third of the L-BFGS history
+// (69 of 211 floats per frame) is then dead weight that the two history passes of every iteration stream for nothing.
+// uuo_stage_compactable decides per solve (it checks the rows against their targets); uuo_lbfgs_solve then runs L-BFGS on
+// n_act = 142 F + 10 (chamfer) / 147 F + 10 (marker: the root's third row has no prior at all) coordinates.
+static StageLayout stage_layout(int stage, int F, bool compact = false) {
+  StageLayout s;
+  s.n = 0;
+  s.off_trans = s.off_z = s.off_betas = s.off_pose = s.off_root = -1;
+  const int gp = compact ? 6 : 9;
   if (stage == UUO_STAGE_CHAMFER) {
     s.off_trans = 0;
     s.off_z = 3 * F;
     s.off_betas = 4 * F;
     s.off_pose = 4 * F + 10;
-    s.n = 211 * F + 10;
+    s.n = 4 * F + 10 + 23 * gp * F;
+    s.gs_pose = gp;
   } else if (stage == UUO_STAGE_MARKER) {
     s.off_pose = 0;
-    s.off_betas = 207 * F;
-    s.off_root = 207 * F + 10;
-    s.off_trans = 216 * F + 10;
-    s.n = 219 * F + 10;
+    s.off_betas = 23 * gp * F;
+    s.off_root = 23 * gp * F + 10;
+    s.off_trans = 23 * gp * F + 10 + gp * F;
+    s.n = 23 * gp * F + 10 + gp * F + 3 * F;
+    s.gs_pose = s.gs_root = gp;
   } else {
     s.off_z = 0;
     s.off_trans = 1;
@@ -1022,14 +1039,80 @@ int uuo_prepare_pose_cache(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   return 0;
 }
 
+// ---- the solver's compact packing (see stage_layout) --------------------------------------------------------------------
+// third rows of the optimised body rotations against their prior targets: flag[0] |= 1 where they differ
+__global__ __launch_bounds__(256) void k_third_rows_differ(int count, const float* __restrict__ raw,
+                                                            const float* __restrict__ target, int* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // one rotation each
+  if (i >= count) return;
+  const float* a = raw + (size_t)i * 9 + 6;
+  const float* b = target + (size_t)i * 9 + 6;
+  // bit patterns: -0.0 against +0.0 or a NaN anywhere count as different (the packing must be provably exact)
+  bool diff = false;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) diff |= __float_as_uint(a[e]) != __float_as_uint(b[e]);
+  if (diff) atomicOr(flag, 1);
+}
+
+// May this solve run on the compact packing?  Synchronises `s` (one 4-byte read-back per solve).
+int uuo_stage_compactable(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, bool* compact) {
+  *compact = false;
+  const int off = UUO_ENV_INT("UUO_NO_COMPACT", 0);  // debug flavour only: the full packing, for comparison
+  if (off || p->stage == UUO_STAGE_PART) return 0;
+  if (p->w_pose == 0.f) {  // no pose prior: the third rows have no gradient whatever they hold
+    *compact = true;
+    return 0;
+  }
+  const StageLayout lay = stage_layout(p->stage, p->F);
+  int* flag = reinterpret_cast<int*>(fit->scalars + 16);
+  UUO_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+  const int count = p->F * 23;
+  hipLaunchKernelGGL(k_third_rows_differ, dim3((count + 255) / 256), dim3(256), 0, s, count, d_x + lay.off_pose, p->d_o_pose, flag);
+  UUO_HIP_CHECK(hipGetLastError());
+  int h = 1;
+  UUO_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  UUO_HIP_CHECK(hipStreamSynchronize(s));
+  *compact = (h == 0);
+  return 0;
+}
+
+// compact index -> index in the reference's packing, as up to four runs (uuo_common.h UuoIndexMap)
+UuoIndexMap uuo_stage_index_map(const uuo_problem_t* p, bool compact) {
+  UuoIndexMap m;
+  std::memset(&m, 0, sizeof(m));
+  if (!compact) return m;
+  const int F = p->F;
+  const StageLayout full = stage_layout(p->stage, F), c = stage_layout(p->stage, F, true);
+  auto add = [&](int cb, int fo, int k69) {
+    m.cb[m.nseg] = cb;
+    m.fo[m.nseg] = fo;
+    m.k69[m.nseg] = k69;
+    ++m.nseg;
+  };
+  if (p->stage == UUO_STAGE_CHAMFER) {
+    add(0, 0, 0);                          // trans | z | betas
+    add(c.off_pose, full.off_pose, 1);     // body rotations: 6 of every 9
+  } else if (p->stage == UUO_STAGE_MARKER) {
+    add(0, 0, 1);                          // body rotations
+    add(c.off_betas, full.off_betas, 0);   // betas
+    add(c.off_root, full.off_root, 1);     // root rotations
+    add(c.off_trans, full.off_trans, 0);   // trans
+  }
+  m.cb[m.nseg] = c.n;
+  m.n_act = c.n;
+  m.n_full = full.n;
+  return m;
+}
+
 // closure evaluation proper; the marker mask must be current (uuo_ensure_mask)
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
                           float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
-                          const UuoEvalReport* report) {
+                          const UuoEvalReport* report, bool compact) {
   int rc = 0;
   const uuo_model* m = fit->model;
   const int F = p->F, M = p->M;
-  const StageLayout lay = stage_layout(p->stage, F);
+  const StageLayout lay = stage_layout(p->stage, F);            // the parameters: always the reference's packing
+  const StageLayout gl = stage_layout(p->stage, F, compact);    // gradient and direction: the solver's packing
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
   rc = closure_forward(fit, s, p, src, false);
   if (rc) return rc;
@@ -1061,16 +1144,18 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.cg = (float)(2.0 * data_c);
   a.cpose = (p->stage == UUO_STAGE_PART) ? 0.f : (float)(2.0 * (double)p->w_pose / ((double)F * 207.0));
   a.d0 = p->marker_distance;
-  a.g_pose = (p->stage == UUO_STAGE_PART) ? nullptr : d_grad + lay.off_pose;
-  a.g_root = (p->stage == UUO_STAGE_MARKER) ? d_grad + lay.off_root : nullptr;
-  a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + lay.off_z : nullptr;
-  a.g_trans = d_grad + lay.off_trans;
+  a.g_pose = (p->stage == UUO_STAGE_PART) ? nullptr : d_grad + gl.off_pose;
+  a.g_root = (p->stage == UUO_STAGE_MARKER) ? d_grad + gl.off_root : nullptr;
+  a.g_z = (p->stage == UUO_STAGE_CHAMFER) ? d_grad + gl.off_z : nullptr;
+  a.g_trans = d_grad + gl.off_trans;
+  a.gs_pose = gl.gs_pose;
+  a.gs_root = gl.gs_root;
   a.frame_part = fit->frame_part;
   a.frames = (p->stage == UUO_STAGE_MARKER) ? nullptr : fit->frames;
   static const int bwd_stop = UUO_ENV_INT("UUO_BWD_STOP", 0);
   a.stop = bwd_stop;
   a.dir = d_dir;
-  a.off_pose = lay.off_pose; a.off_root = lay.off_root; a.off_z = lay.off_z; a.off_trans = lay.off_trans;
+  a.off_pose = gl.off_pose; a.off_root = gl.off_root; a.off_z = gl.off_z; a.off_trans = gl.off_trans;
   a.h.gx = F;
   a.h.gy = 1;
   const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
@@ -1097,11 +1182,11 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   fa.closs = data_c;
   fa.cpose = (p->stage == UUO_STAGE_PART) ? 0.0 : (double)p->w_pose / ((double)F * 207.0);
   fa.cbetas = (double)p->w_betas / 10.0;
-  fa.g_betas = d_grad + lay.off_betas;
-  fa.g_z = (p->stage == UUO_STAGE_PART) ? d_grad + lay.off_z : nullptr;
+  fa.g_betas = d_grad + gl.off_betas;
+  fa.g_z = (p->stage == UUO_STAGE_PART) ? d_grad + gl.off_z : nullptr;
   fa.loss = d_loss;
-  fa.dir_betas = d_dir ? d_dir + lay.off_betas : nullptr;
-  fa.dir_z = (d_dir && p->stage == UUO_STAGE_PART) ? d_dir + lay.off_z : nullptr;
+  fa.dir_betas = d_dir ? d_dir + gl.off_betas : nullptr;
+  fa.dir_z = (d_dir && p->stage == UUO_STAGE_PART) ? d_dir + gl.off_z : nullptr;
   fa.stats = d_stats;
   fa.rep_host = (report && d_stats) ? report->host : nullptr;
   fa.rep_seq = report ? report->seq : 0ull;
@@ -1173,6 +1258,20 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
 }
 
 #ifdef UUO_DEBUG_HOOKS
+// host-only debug hook: the compact -> full index map of a stage at F frames, evaluated for every solver coordinate
+// (h_out: n_act ints); returns n_act, or n_full (and fills the identity) for the full packing / the part stage
+extern "C" int uuo_debug_index_map(int stage, int F, int compact, int* h_out) {
+  UUO_REQUIRE(stage >= 0 && stage <= 2 && F > 0 && h_out, "uuo_debug_index_map: bad arguments");
+  uuo_problem_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.stage = stage;
+  p.F = F;
+  const UuoIndexMap m = uuo_stage_index_map(&p, compact != 0 && stage != UUO_STAGE_PART);
+  const int n = m.nseg ? m.n_act : stage_layout(stage, F).n;
+  for (int c = 0; c < n; ++c) h_out[c] = m.full(c);
+  return n;
+}
+
 // debug hook: shader-clock stamps left by the last k_bwd launch with UUO_BWD_STOP=9 ([4096][BWD_NSTAMP] cycles)
 extern "C" int uuo_debug_bwd_stamps(unsigned long long* h_out) {
   UUO_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * 4096 * BWD_NSTAMP));
@@ -1236,6 +1335,7 @@ extern "C" int uuo_smpl_backward(uuo_model_t* m, void* stream, int F, const floa
   a.up_joints = d_up_joints;
   a.frame_part = d_scratch;
   a.off_pose = a.off_root = a.off_z = a.off_trans = -1;
+  a.gs_pose = a.gs_root = 9;
   hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;

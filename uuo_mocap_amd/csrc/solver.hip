@@ -49,21 +49,28 @@ __global__ void k_lb_init(LbDev* st) {
 }
 
 // ---------------------------------------------------------------------------------------------------- kernels
-// first iteration: d = -g and the first trial point x + t d in one pass
+// first iteration: d = -g and the first trial point x + t d in one pass.  g, d (and the history) live in the SOLVER's index
+// space, the iterates x / xt in the reference's parameter packing; `map` takes the former to the latter (the identity unless
+// the solve runs on the compact packing of closure.hip's stage_layout, where the never-moving third rows of the rotations have
+// no solver coordinate: their entries of x are copied once when the solve starts and not touched again).
 __device__ __forceinline__ void lb_neg_body(int n, const float* __restrict__ g, float* __restrict__ d, const float* __restrict__ x,
-                         float t, float* __restrict__ xt) {
+                         float t, float* __restrict__ xt, const UuoIndexMap& map) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const float di = -g[i];
     d[i] = di;
-    xt[i] = x[i] + t * di;
+    const int fi = map.full(i);
+    xt[fi] = x[fi] + t * di;
   }
 }
 
 __device__ __forceinline__ void lb_axpy_body(int n, const float* __restrict__ x, float t, const float* __restrict__ d,
-                          float* __restrict__ o) {
+                          float* __restrict__ o, const UuoIndexMap& map) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = x[i] + t * d[i];  // p.add_(d, alpha=t): one multiply, one add (no contraction)
+  if (i < n) {
+    const int fi = map.full(i);
+    o[fi] = x[fi] + t * d[i];  // p.add_(d, alpha=t): one multiply, one add (no contraction)
+  }
 }
 
 struct LbNegArgs {
@@ -74,11 +81,12 @@ struct LbNegArgs {
   uuo_gptr<const float> x;
   float t;
   uuo_gptr<float> xt;
+  UuoIndexMap map;
 };
-__global__ void k_lb_neg(LbNegArgs a) { lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt); }
+__global__ void k_lb_neg(LbNegArgs a) { lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt, a.map); }
 __global__ void k_lb_neg_b(const LbNegArgs* __restrict__ batch) {
   UUO_BATCH_PICK(LbNegArgs, batch)
-  lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt);
+  lb_neg_body(a.n, a.g, a.d, a.x, a.t, a.xt, a.map);
 }
 struct LbAxpyArgs {
   UuoGridHdr h;
@@ -87,11 +95,12 @@ struct LbAxpyArgs {
   float t;
   uuo_gptr<const float> d;
   uuo_gptr<float> o;
+  UuoIndexMap map;
 };
-__global__ void k_lb_axpy(LbAxpyArgs a) { lb_axpy_body(a.n, a.x, a.t, a.d, a.o); }
+__global__ void k_lb_axpy(LbAxpyArgs a) { lb_axpy_body(a.n, a.x, a.t, a.d, a.o, a.map); }
 __global__ void k_lb_axpy_b(const LbAxpyArgs* __restrict__ batch) {
   UUO_BATCH_PICK(LbAxpyArgs, batch)
-  lb_axpy_body(a.n, a.x, a.t, a.d, a.o);
+  lb_axpy_body(a.n, a.x, a.t, a.d, a.o, a.map);
 }
 
 __global__ void k_lb_form(int n, const float* __restrict__ g, const float* __restrict__ gp,
@@ -1166,7 +1175,8 @@ __global__ __launch_bounds__(512) void k_lb_small_inv_b(const LbSmallArgs* __res
 __device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, const float* __restrict__ S,
                                                              const float* __restrict__ Y, const float* __restrict__ g,
                                                              LbDev* __restrict__ st, float* __restrict__ d,
-                                                             const float* __restrict__ x, float t, float* __restrict__ xt) {
+                                                             const float* __restrict__ x, float t, float* __restrict__ xt,
+                                                             const UuoIndexMap& map) {
   __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass.
   // One block per 256-column strip of the history (FOUR columns per lane: 16-byte loads -- the vector-memory pipe costs
@@ -1241,7 +1251,8 @@ __device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, cons
       const float dd = (float)v;
       if (i + e < n) {  // x may be the caller's tensor of exactly n floats: element-wise, guarded
         d[i + e] = dd;
-        xt[i + e] = x[i + e] + t * dd;
+        const int fi = map.full(i + e);  // the iterate lives in the reference's packing (see lb_neg_body)
+        xt[fi] = x[fi] + t * dd;
         mx = fmaxf(mx, fabsf(dd));
       }
     }
@@ -1255,7 +1266,10 @@ __device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, cons
 
 // -------------------------------------------------------------------------------------------------- objectives
 struct Objective {
-  int n = 0;
+  int n = 0;        // coordinates of the solver (gradient, direction, history)
+  int n_full = 0;   // floats of the parameter vector the closure is evaluated at (0: same as n)
+  UuoIndexMap map;  // solver coordinate -> parameter index (nseg = 0: the identity)
+  Objective() { std::memset(&map, 0, sizeof(map)); }
   bool fused_stats = false;  // eval() also writes {loss, g.d, max|g|, sum|g|, g.g} to stats_dev
   virtual int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev,
                    const UuoEvalReport* report) = 0;
@@ -1265,11 +1279,26 @@ struct Objective {
 struct StageObjective : Objective {
   uuo_fit* fit;
   const uuo_problem_t* p;
+  bool compact = false;  // gradient / direction in the compact packing (closure.hip stage_layout); set by stage_objective_init
   int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float* dir, double* stats_dev,
            const UuoEvalReport* report) override {
-    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr, dir, stats_dev, report);
+    return uuo_closure_eval_impl(fit, s, p, x, loss_dev, grad, nullptr, dir, stats_dev, report, compact);
   }
 };
+// decides the packing of one stage solve (one small read-back: uuo_stage_compactable) and sizes the objective accordingly
+static int stage_objective_init(StageObjective& obj, uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x) {
+  obj.fit = fit;
+  obj.p = p;
+  obj.fused_stats = true;
+  bool compact = false;
+  const int rc = uuo_stage_compactable(fit, s, p, d_x, &compact);
+  if (rc) return rc;
+  obj.compact = compact;
+  obj.map = uuo_stage_index_map(p, compact);
+  obj.n_full = uuo_problem_num_params(p);
+  obj.n = compact ? obj.map.n_act : obj.n_full;
+  return 0;
+}
 
 struct LbDirArgs {
   UuoGridHdr h;
@@ -1282,13 +1311,14 @@ struct LbDirArgs {
   uuo_gptr<const float> x;
   float t;
   uuo_gptr<float> xt;
+  UuoIndexMap map;
 };
 __global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction(LbDirArgs a) {
-  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt);
+  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt, a.map);
 }
 __global__ __launch_bounds__(64 * LB_DQ) void k_lb_direction_b(const LbDirArgs* __restrict__ batch) {
   UUO_BATCH_PICK(LbDirArgs, batch)
-  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt);
+  lb_direction_body(a.n, a.cap, a.capL, a.S, a.Y, a.g, a.st, a.d, a.x, a.t, a.xt, a.map);
 }
 
 
@@ -1499,7 +1529,8 @@ struct SharedCtx {
   uuo_gather_fn gather = nullptr;
   void* user = nullptr;
   int rank = 0, world = 1;
-  int off = 0, cnt = 0;
+  int off = 0, cnt = 0;     // the shared entries in the SOLVER's packing (gradient, direction, dot products)
+  int off_x = 0;            // and in the parameter vector
   std::vector<double> all;  // gather target
 };
 
@@ -1517,7 +1548,9 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
                      uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user, SharedCtx* sh = nullptr) {
   const bool batched = uuo_recorder != nullptr;
   const int n = obj.n;
-  UUO_REQUIRE(n > 0 && n <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
+  const int n_full = obj.n_full > 0 ? obj.n_full : obj.n;  // floats of the iterate (>= n on the compact packing)
+  const UuoIndexMap map = obj.map;
+  UUO_REQUIRE(n > 0 && n <= w->n_cap && n_full <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
   UUO_REQUIRE(hist + 1 <= w->cap, "lbfgs: history_size exceeds the workspace");
   const int cap = hist + 1;
@@ -1657,7 +1690,8 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
 
   if (sh) {
     UUO_REQUIRE(!batched && obj.fused_stats && poll_mode != 0, "lbfgs: shared solves need the fused, polled report path");
-    UUO_REQUIRE(sh->cnt > 0 && sh->cnt <= 16 && sh->off >= 0 && sh->off + sh->cnt <= n && sh->world >= 1 &&
+    UUO_REQUIRE(sh->cnt > 0 && sh->cnt <= 16 && sh->off >= 0 && sh->off + sh->cnt <= n && sh->off_x >= 0 &&
+                sh->off_x + sh->cnt <= n_full && sh->world >= 1 &&
                 sh->rank >= 0 && sh->rank < sh->world && sh->gather, "lbfgs: bad shared-parameter description");
     if (!w->h_rows) {
       UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_rows, (LB_ROWS * 3 + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1669,16 +1703,22 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     // the replicas of the shared entries must be bit-identical: every rank takes rank 0's values
     float hb[16];
     double mine[16];
-    UUO_HIP_CHECK(hipMemcpyAsync(hb, d_x + sh->off, sizeof(float) * sh->cnt, hipMemcpyDeviceToHost, s));
+    UUO_HIP_CHECK(hipMemcpyAsync(hb, d_x + sh->off_x, sizeof(float) * sh->cnt, hipMemcpyDeviceToHost, s));
     UUO_HIP_CHECK(hipStreamSynchronize(s));
     for (int l = 0; l < sh->cnt; ++l) mine[l] = (double)hb[l];
     const int grc = shared_gather(sh, mine, sh->cnt);
     if (grc) return grc;
     for (int l = 0; l < sh->cnt; ++l) hb[l] = (float)sh->all[l];
-    UUO_HIP_CHECK(hipMemcpyAsync(d_x + sh->off, hb, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
+    UUO_HIP_CHECK(hipMemcpyAsync(d_x + sh->off_x, hb, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
     UUO_HIP_CHECK(hipStreamSynchronize(s));  // (hb is a stack buffer)
   }
   if (!batched) UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
+  if (map.nseg) {
+    // compact packing: the trial points are written at the solver's coordinates only, so the other iterate buffer gets
+    // the parameter entries that have no coordinate (and never move) once, here
+    const int rc_ = lb_copy(s, xoth, xcur, (size_t)n_full * sizeof(float));
+    if (rc_) return rc_;
+  }
   hipLaunchKernelGGL(k_lb_init, dim3(1), dim3(1), 0, s, w->st);
   int ig = pool_alloc();  // gradient at the current iterate
   int ipg = -1;           // gradient at the previous iterate
@@ -1709,7 +1749,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         t = lr;
       // ---------------------------------------------------------------- direction + first trial point
       if (n_iter == 1) {
-        LbNegArgs na{{0, 0}, n, g, d, xcur, (float)t, xoth};
+        LbNegArgs na{{0, 0}, n, g, d, xcur, (float)t, xoth, map};
         lb_dispatch(UUO_OP_NEG, s, dim3(nb), dim3(256), k_lb_neg, na);
       } else {
         const int cand = (head + count) % cap;
@@ -1766,7 +1806,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           sa.rd_in = rd_in;
           lb_dispatch(UUO_OP_SMALL, s, dim3(1), dim3(512), k_lb_small_inv, sa);
         }
-        LbDirArgs ra{{0, 0}, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur, (float)t, xoth};
+        LbDirArgs ra{{0, 0}, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur, (float)t, xoth, map};
         lb_dispatch(UUO_OP_DIR, s, dim3(2 * ncb), dim3(64 * LB_DQ), k_lb_direction, ra);
       }
       UUO_HIP_CHECK(hipGetLastError());
@@ -1818,7 +1858,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       auto trial = [&](LsPoint& pt) -> int {
         pt.buf = pool_alloc();
         UUO_REQUIRE(pt.buf >= 0, "lbfgs: gradient pool exhausted");
-        LbAxpyArgs xa{{0, 0}, n, xcur, (float)pt.t, d, xoth};
+        LbAxpyArgs xa{{0, 0}, n, xcur, (float)pt.t, d, xoth, map};
         lb_dispatch(UUO_OP_AXPY, s, dim3(nb), dim3(256), k_lb_axpy, xa);
         int r = evaluate(xoth, vec(pt.buf), true);
         if (r) return r;
@@ -1941,7 +1981,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
         // line search returned the starting point (bracket low at t = 0): iterate unchanged
       } else {
         if (t_at_xoth != res.t) {
-          LbAxpyArgs xa{{0, 0}, n, xcur, (float)t, d, xoth};
+          LbAxpyArgs xa{{0, 0}, n, xcur, (float)t, d, xoth, map};
           lb_dispatch(UUO_OP_AXPY_ACCEPT, s, dim3(nb), dim3(256), k_lb_axpy, xa);
         }
         float* tmp = xcur;
@@ -1991,7 +2031,7 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
     }
   }
   if (xcur != d_x) {
-    const int rc_ = lb_copy(s, d_x, xcur, (size_t)n * sizeof(float));
+    const int rc_ = lb_copy(s, d_x, xcur, (size_t)n_full * sizeof(float));
     if (rc_) return rc_;
   }
   float ms = 0.f;
@@ -2104,10 +2144,8 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
   rc = uuo_ensure_mask(fit, s, p);
   if (rc) return rc;
   StageObjective obj;
-  obj.fit = fit;
-  obj.p = p;
-  obj.fused_stats = true;
-  obj.n = uuo_problem_num_params(p);
+  rc = stage_objective_init(obj, fit, s, p, d_x);
+  if (rc) return rc;
   std::memset(stats, 0, sizeof(*stats));
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
 }
@@ -2142,18 +2180,30 @@ extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_pr
   rc = uuo_ensure_mask(fit, s, p);
   if (rc) return rc;
   StageObjective obj;
-  obj.fit = fit;
-  obj.p = p;
-  obj.fused_stats = true;
-  obj.n = n_params;
+  rc = stage_objective_init(obj, fit, s, p, d_x);
+  if (rc) return rc;
   SharedCtx sh;
   sh.gather = shared->gather;
   sh.user = shared->user;
   sh.rank = shared->rank;
   sh.world = shared->world;
   sh.cnt = UUO_NUM_BETAS;
-  const int F = p->F;  // offset of the betas in the stage's packing (closure.hip stage_layout)
-  sh.off = (p->stage == UUO_STAGE_CHAMFER) ? 4 * F : (p->stage == UUO_STAGE_MARKER) ? 207 * F : 3 * F + 1;
+  const int F = p->F;  // offset of the betas in the parameter vector and in the solver's packing (closure.hip stage_layout)
+  sh.off_x = (p->stage == UUO_STAGE_CHAMFER) ? 4 * F : (p->stage == UUO_STAGE_MARKER) ? 207 * F : 3 * F + 1;
+  sh.off = (p->stage == UUO_STAGE_MARKER && obj.compact) ? 138 * F : sh.off_x;
+  {  // every rank must run the same packing: a rank whose third rows differ from their targets makes all of them run full
+    double mine = obj.compact ? 1.0 : 0.0;
+    rc = shared_gather(&sh, &mine, 1);
+    if (rc) return rc;
+    bool all_compact = true;
+    for (int r = 0; r < sh.world; ++r) all_compact = all_compact && sh.all[r] != 0.0;
+    if (obj.compact && !all_compact) {
+      obj.compact = false;
+      obj.map = uuo_stage_index_map(p, false);
+      obj.n = obj.n_full;
+      sh.off = sh.off_x;
+    }
+  }
   std::memset(stats, 0, sizeof(*stats));
   return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user, &sh);
 }
@@ -2458,10 +2508,10 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
   for (int i = 0; i < nb; ++i) {
     BatchCo& c = cos[i];
     UUO_REQUIRE(c.stack.alloc(), "uuo_batch_solve: could not map a coroutine stack");
-    c.obj.fit = b->fits[i];
-    c.obj.p = &problems[i];
-    c.obj.fused_stats = true;
-    c.obj.n = n_params;
+    {
+      const int orc = stage_objective_init(c.obj, b->fits[i], s, &problems[i], d_xs[i]);
+      if (orc) return orc;
+    }
     c.w = (LbWs*)b->fits[i]->lbws;
     c.d_x = d_xs[i];
     c.opt = opt;

@@ -213,9 +213,32 @@ struct UuoEvalReport {
                                        // own parameters (all but the betas), 14..23 its shape gradient (as doubles)
   unsigned long long seq = 0;
 };
+// `compact`: gradient and direction in the solver's compact packing (closure.hip stage_layout); the parameters d_x always in
+// the reference's
 int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, float* d_loss,
                           float* d_grad, int32_t* d_nn_idx, const float* d_dir, double* d_stats,
-                          const UuoEvalReport* report = nullptr);
+                          const UuoEvalReport* report = nullptr, bool compact = false);
+// compact solver index -> index in the reference's parameter packing: up to four runs, each either dense (full = fo + i) or
+// "6 of 9" (full = fo + 9 (i / 6) + i % 6: the first two rows of row-major 3x3 rotations).  nseg == 0: the identity.
+struct UuoIndexMap {
+  int nseg;
+  int cb[5];   // first compact index of each run; cb[nseg] = n_act
+  int fo[4];   // offset of the run in the full packing
+  int k69[4];  // run kind
+  int n_act, n_full;
+  __host__ __device__ int full(int c) const {
+    if (nseg == 0) return c;
+    int sg = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) sg += (q < nseg && c >= cb[q]) ? 1 : 0;
+    const int rel = c - cb[sg];
+    if (!k69[sg]) return fo[sg] + rel;
+    const int rot = (int)(((unsigned long long)(unsigned)rel * 0xAAAAAAABull) >> 34);  // rel / 6, exact for every 32-bit rel
+    return fo[sg] + 9 * rot + (rel - 6 * rot);
+  }
+};
+int uuo_stage_compactable(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, bool* compact);
+UuoIndexMap uuo_stage_index_map(const uuo_problem_t* p, bool compact);
 
 // ---- lock-step batches (uuo_batch_*: solver.hip) ------------------------------------------------------------------------
 // Every kernel of the solve path exists in two launch forms over ONE device body: k_X(XArgs) for a single problem and
