@@ -48,7 +48,7 @@ def part_flops_per_frame_eval(n_subset, n_markers):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
@@ -226,16 +226,16 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
     closure_ms = prob.time_closure(x, iters=iters, dominant_only=False)
     skin_flops = SKIN_FLOPS_PER_FRAME * F
     achieved = skin_flops / (skin_ms * 1e-3) / 1e12
-    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r2_pmc_summary.json):
-    # FETCH_SIZE 15 281 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 406 KB, at F=300.
+    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r3_pmc_summary.json):
+    # FETCH_SIZE 15 315 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 409 KB, at F=300.
     # An OFFLINE figure (a PMC pass cannot run inside this process): null at any other size.
-    traffic = int((15281.4 * 2 + 30406.4) * 1024) if (F == 300) else None
+    traffic = int((15314.6 * 2 + 30409.2) * 1024) if (F == 300) else None
     mfma_useful = SKIN_MFMA_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12
     closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                 "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel at F=300 "
-                                  "(profiles/r2_pmc_summary.json), not measured by this run",
+                                  "(profiles/r3_pmc_summary.json), not measured by this run",
                 "kernel": "k_skin2<true,0>",
                 # frac credits SURVEY 8d's dense 24-joint skinning product; the kernel does that part as <=4-weight VALU
                 # work, so the matrix pipe's own useful rate is the blend contraction alone:

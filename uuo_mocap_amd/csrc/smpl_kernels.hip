@@ -895,9 +895,18 @@ __device__ __forceinline__ void skin_cached_body(int F, int V, int ns, const int
   const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
   const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
   const int nuc = (ns + 15) >> 4;  // units of 16 candidates (compact form)
-  for (int q = 0; q < nf; ++q) {
-    const float* pc = C + ((size_t)(f0 + q) * V + vs) * 3;
-    const float px = pc[0] + sb[0], py = pc[1] + sb[1], pz = pc[2] + sb[2];
+  // the cached blend values of all the block's frames are requested before the first one is used (one L2 / HBM round trip
+  // per vertex instead of one per frame: the kernel is nothing but latency)
+  float cx[SKC_FB], cy[SKC_FB], cz[SKC_FB];
+#pragma unroll
+  for (int q = 0; q < SKC_FB; ++q) {
+    const float* pc = C + ((size_t)(f0 + (q < nf ? q : nf - 1)) * V + vs) * 3;
+    cx[q] = pc[0]; cy[q] = pc[1]; cz[q] = pc[2];
+  }
+#pragma unroll
+  for (int q = 0; q < SKC_FB; ++q) {
+    if (q >= nf) continue;  // block-uniform (the last block of frames may be short)
+    const float px = cx[q] + sb[0], py = cy[q] + sb[1], pz = cz[q] + sb[2];
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
