@@ -333,3 +333,16 @@ def test_compact_solver_packing_index_map():
             assert n == n_full and np.array_equal(out, np.arange(n_full))
     out = np.full(3 * 5 + 11, -1, np.int32)
     assert dbg.uuo_debug_index_map(_lib.UUO_STAGE_PART, 5, 1, out.ctypes.data) == 26 and np.array_equal(out, np.arange(26))
+
+
+def test_execution_options_merge():
+    """defaults < config section < argument; the same key may appear at every level; unknown keys are refused."""
+    from uuo_mocap_amd.markers_utils import EXECUTION_DEFAULTS, merge_execution
+
+    assert merge_execution({}) == EXECUTION_DEFAULTS
+    cfg = {"execution": {"hypothesis_lockstep": True, "subtree_batch": 64}}
+    out = merge_execution(cfg, {"hypothesis_lockstep": False, "subtree_threads": 2})
+    assert out["hypothesis_lockstep"] is False and out["subtree_batch"] == 64 and out["subtree_threads"] == 2
+    assert merge_execution(cfg)["hypothesis_lockstep"] is True
+    with pytest.raises(KeyError):
+        merge_execution({"execution": {"no_such_knob": 1}})

@@ -29,6 +29,17 @@ EXECUTION_DEFAULTS = {"subtree_lockstep": True, "subtree_batch": 256, "subtree_t
                       "hypothesis_lockstep": False, "hypothesis_threads": 4, "batch_trivial_hypotheses": True}
 
 
+def merge_execution(config: Dict, execution: Dict = None) -> Dict:
+    """EXECUTION_DEFAULTS, overridden by the config's `execution` section, overridden by the `execution` argument."""
+    out = dict(EXECUTION_DEFAULTS)
+    out.update(config.get("execution") or {})
+    out.update(execution or {})
+    unknown = set(out) - set(EXECUTION_DEFAULTS)
+    if unknown:
+        raise KeyError("unknown execution option(s): %s" % sorted(unknown))
+    return out
+
+
 def get_joint_name(joint_id: int) -> str:
     return SMPL_JOINT_NAMES[joint_id]
 
@@ -229,7 +240,7 @@ def find_best_part_fits(
     {"subtree_lockstep": True, "subtree_batch": 256, "subtree_threads": 4} -- one lock-step batch of up to
     `subtree_batch` candidates (default), or `subtree_threads` host threads with a stream each.  An `execution` section of
     `config` sets the same keys; the argument wins."""
-    exe = dict(EXECUTION_DEFAULTS, **(config.get("execution") or {}), **(execution or {}))
+    exe = merge_execution(config, execution)
     st = config["stages"]["part"]
     if st["mode"] != "cluster":
         raise NotImplementedError("stages.part.mode 'network' needs segmenter checkpoints the reference does not ship")

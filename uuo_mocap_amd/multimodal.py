@@ -83,7 +83,7 @@ def multimodal_video_mocap(
     independent solves are scheduled on the device, never what they compute -- markers_utils.EXECUTION_DEFAULTS):
     {"hypothesis_lockstep": False, "hypothesis_threads": 4, "subtree_lockstep": True, "subtree_batch": 256,
     "subtree_threads": 4}; an `execution` section of `config` sets the same keys, the argument wins."""
-    exe = dict(markers_utils.EXECUTION_DEFAULTS, **(config.get("execution") or {}), **(execution or {}))
+    exe = markers_utils.merge_execution(config, execution)
     if visualize_fits:
         raise NotImplementedError("visualize_fits renders with pyrender, not built")
     for key in ("reprojection_full", "root"):
