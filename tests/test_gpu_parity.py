@@ -942,7 +942,7 @@ def test_unit_boxes_bound_their_vertices_exactly(smpl, dev, F):
 
 
 def test_skin_kernel_variants_agree_bitwise(smpl, dev, tmp_path):
-    """The generic skin kernel (UUO_SKIN_V1=1: static schedule, used for dense skin weights or shapes the pipelined
+    """The generic skin kernel (UUO_SKIN_V1=1: static schedule, used for shapes the pipelined
     kernel cannot tile) and the default pipelined kernel issue the same MFMA / FMA chains per vertex: bit-equal
     vertices.  The variant is chosen per process, so the generic one runs in a child process."""
     import subprocess
