@@ -220,6 +220,41 @@ int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p,
 typedef int (*uuo_closure_fn)(void* user, void* stream, const float* d_x_eval, float* d_loss, float* d_grad);
 int uuo_lbfgs_minimize(void* stream, int n, float* d_x, const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats,
                        uuo_closure_fn closure, void* user, uuo_eval_callback_t cb, void* cb_user);
+/* ---- the 2D-prior fit as one fused closure ----------------------------------------------------------------
+ * Replaces the closure of optim_reprojection (utils/hmr_utils.py:281-365: two SMPL forwards, perspective_projection
+ * :14-52, masked key-point L2 :321 and a one-directional chamfer_distance :333 per evaluation) and, with
+ * uuo_reprojection_solve, the torch.optim.LBFGS(...).step(closure) at :367 for ONE yaw hypothesis.  Parameter vector, in the
+ * order of the reference's params list (:276-279):  x = [yaw 1 | body translation 3F (HMR axes) | camera translation 3 |
+ * betas 10 (in the list but detached, :218,292: zero gradient, never moves)]  = 3F + 14 floats.
+ * The body pose, the shape and the HMR root orientation are constants of this solve, so the caller runs ONE forward
+ * (uuo_smpl_forward: HMR pose, the solve's betas, the HMR root orientation, zero translation) and hands its joints and
+ * vertices over; the closure needs no skinning (uuo_mocap_amd/csrc/reprojection.hip). */
+typedef struct {
+  int32_t F, M, V, J;        /* frames, markers, vertices, joints per frame (SMPL + vertex joints: 45; at most 64) */
+  const float* d_markers;    /* [F,M,3] */
+  const float* d_joints0;    /* [F,J,3] joints of that forward (joint 0 = the pelvis the root rotation turns about) */
+  const float* d_verts0;     /* [F,V,3] vertices of that forward */
+  const float* d_kp_target;  /* [F,J,2] HMR key points (NaN already replaced by 0, :236) */
+  const float* d_mask;       /* [F] 1 = frame has a valid HMR camera (:240) */
+  float focal[2];            /* mean focal length / 256 (:258) */
+  float center[2];           /* camera centre (zeros in HMR 2.0, hmr_utils.py:96) */
+  float w_reprojection, w_chamfer; /* stages.reprojection_part.losses */
+} uuo_reprojection_problem_t;
+typedef struct uuo_reprojection uuo_reprojection_t;
+int uuo_reprojection_create(const uuo_reprojection_problem_t* p, uuo_reprojection_t** out);
+int uuo_reprojection_destroy(uuo_reprojection_t* h);
+int uuo_reprojection_num_params(const uuo_reprojection_problem_t* p); /* 3F + 14 */
+/* One closure evaluation at d_x: loss to d_loss[0], gradient to d_grad[3F+14]; optional outputs: d_kp [F,J,2] the projected
+ * key points (+0.5, as the reference's joints_2d), d_nn_idx [F,M] the nearest vertex of every marker.  Asynchronous. */
+int uuo_reprojection_eval(uuo_reprojection_t* h, void* stream, const float* d_x, float* d_loss, float* d_grad,
+                          float* d_kp, int32_t* d_nn_idx);
+/* uuo_lbfgs_solve for this closure.  The reference returns quantities of the LAST closure evaluation (its `nonlocal`
+ * temporaries, :296-299,383-425), which is not necessarily the accepted point: d_x_last (optional, 3F+14) and d_kp_last
+ * (optional, [F,J,2]) receive that evaluation's parameter vector and key points. */
+int uuo_reprojection_solve(uuo_reprojection_t* h, void* stream, float* d_x, const uuo_lbfgs_options_t* opt,
+                           uuo_lbfgs_stats_t* stats, float* d_x_last, float* d_kp_last, uuo_eval_callback_t cb,
+                           void* cb_user);
+
 /* device -> device copy of `bytes` bytes ordered on `stream` (closures written in Python move the evaluated point and
  * the gradient between their own tensors and the driver's vectors with it) */
 int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes);

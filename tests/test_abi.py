@@ -346,3 +346,24 @@ def test_execution_options_merge():
     assert merge_execution(cfg)["hypothesis_lockstep"] is True
     with pytest.raises(KeyError):
         merge_execution({"execution": {"no_such_knob": 1}})
+
+
+def test_reprojection_entry_points_refuse_bad_arguments():
+    """uuo_reprojection_* (the fused 2D-prior closure): argument checks that need no GPU."""
+    import ctypes
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+    p = _lib.UuoReprojectionProblem()
+    p.F, p.M, p.V, p.J = 8, 12, 6890, 45
+    assert lib.uuo_reprojection_num_params(ctypes.byref(p)) == 3 * 8 + 14
+    h = ctypes.c_void_p()
+    assert lib.uuo_reprojection_create(ctypes.byref(p), ctypes.byref(h)) == -22  # null device pointers
+    assert b"null device pointer" in lib.uuo_last_error()
+    p.J = 65
+    assert lib.uuo_reprojection_create(ctypes.byref(p), ctypes.byref(h)) == -22
+    assert b"joints" in lib.uuo_last_error()
+    assert lib.uuo_reprojection_create(None, ctypes.byref(h)) == -22
+    assert lib.uuo_reprojection_destroy(None) == 0
+    assert lib.uuo_reprojection_eval(None, None, None, None, None, None, None) == -22
+    assert lib.uuo_reprojection_solve(None, None, None, None, None, None, None, None, None) == -22

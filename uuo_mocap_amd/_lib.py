@@ -38,6 +38,15 @@ class UuoLbfgsStats(ctypes.Structure):
     ]
 
 
+class UuoReprojectionProblem(ctypes.Structure):
+    _fields_ = [
+        ("F", c_int32), ("M", c_int32), ("V", c_int32), ("J", c_int32),
+        ("d_markers", c_void_p), ("d_joints0", c_void_p), ("d_verts0", c_void_p), ("d_kp_target", c_void_p),
+        ("d_mask", c_void_p), ("focal", c_float * 2), ("center", c_float * 2),
+        ("w_reprojection", c_float), ("w_chamfer", c_float),
+    ]
+
+
 EVAL_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_float, c_void_p)
 # uuo_gather_fn (include/uuo_hip.h): int gather(user, const double* mine, int n, double* all /* [world][n] */)
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(ctypes.c_double), c_int, POINTER(ctypes.c_double))
@@ -81,6 +90,12 @@ _SIGNATURES = {
                                  POINTER(c_float)]),
     "uuo_lbfgs_minimize": (c_int, [c_void_p, c_int, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats), c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "uuo_reprojection_create": (c_int, [POINTER(UuoReprojectionProblem), POINTER(c_void_p)]),
+    "uuo_reprojection_destroy": (c_int, [c_void_p]),
+    "uuo_reprojection_num_params": (c_int, [POINTER(UuoReprojectionProblem)]),
+    "uuo_reprojection_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "uuo_reprojection_solve": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats),
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "uuo_copy_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "uuo_batch_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "uuo_batch_destroy": (c_int, [c_void_p]),

@@ -2729,6 +2729,40 @@ extern "C" int uuo_lbfgs_minimize(void* stream, int n, float* d_x, const uuo_lbf
   return rc;
 }
 
+// the 2D-prior fit (reprojection.hip) under the same driver
+struct ReprojObjective : Objective {
+  uuo_reprojection* h = nullptr;
+  float* x_last = nullptr;
+  float* kp_last = nullptr;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*, const UuoEvalReport*) override {
+    if (x_last) UUO_HIP_CHECK(hipMemcpyAsync(x_last, x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return uuo_reprojection_eval_impl(h, s, x, loss_dev, grad, kp_last, nullptr);
+  }
+};
+
+extern "C" int uuo_reprojection_solve(uuo_reprojection_t* h, void* stream, float* d_x, const uuo_lbfgs_options_t* opt,
+                                      uuo_lbfgs_stats_t* stats, float* d_x_last, float* d_kp_last, uuo_eval_callback_t cb,
+                                      void* cb_user) {
+  UUO_REQUIRE(h && d_x && opt && stats, "uuo_reprojection_solve: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_reprojection_solve: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_reprojection_solve: not inside a lock-step batch");
+  const int n = uuo_reprojection_num_params(&h->p);
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = nullptr;
+  int rc = lbws_create(n, hist, &w);
+  if (rc) return rc;
+  ReprojObjective obj;
+  obj.h = h;
+  obj.n = n;
+  obj.x_last = d_x_last;
+  obj.kp_last = d_kp_last;
+  std::memset(stats, 0, sizeof(*stats));
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, cb, cb_user);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  lbws_destroy(w);
+  return rc;
+}
+
 extern "C" int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes) {
   UUO_REQUIRE(d_dst && d_src, "uuo_copy_device: null argument");
   if (bytes) UUO_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -333,3 +333,12 @@ int uuo_batched_launch_smpl(int op, hipStream_t s, const void* d_args, int count
 int uuo_replay_skin_call(hipStream_t s, const void* h_args);
 int uuo_batched_launch_nn(int op, hipStream_t s, const void* d_args, int count, int gx, int gy);
 int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int count, int gx, int gy);
+
+// reprojection.hip: the handle of a 2D-prior fit and one evaluation of its fused closure
+struct uuo_reprojection {
+  uuo_reprojection_problem_t p;
+  float* part = nullptr;  // [F][8] per-frame partial sums of an evaluation
+};
+// one evaluation of the fused 2D-prior closure (uuo_reprojection_eval without the argument checks)
+int uuo_reprojection_eval_impl(uuo_reprojection* h, hipStream_t s, const float* d_x, float* d_loss, float* d_grad,
+                               float* d_kp, int32_t* d_nn_idx);

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import (EVAL_CALLBACK, UUO_STAGE_CHAMFER, UUO_STAGE_MARKER, UUO_STAGE_PART, UuoLbfgsOptions,
-                   UuoLbfgsStats, UuoProblem, check)
+                   UuoLbfgsStats, UuoProblem, UuoReprojectionProblem, check)
 from .body_model import SmplTables
 
 MARKER_DISTANCE = 0.0095  # reference utils/settings.py:1
@@ -656,3 +656,87 @@ class PartProblem(_StageProblem):
     def unpack(self, x):
         F = self.F
         return x[:1].reshape(1, 1, 1), x[1:3 * F + 1].reshape(F, 3), x[3 * F + 1:].reshape(1, 10)
+
+
+class ReprojectionProblem:
+    """One yaw hypothesis of the 2D-prior fit (reference utils/hmr_utils.py:170-425) as the library's fused closure
+    (uuo_reprojection_*, csrc/reprojection.hip).  x = [yaw 1 | body translation 3F (HMR axes) | camera translation 3 |
+    betas 10 (detached in the reference: they never move)].  `joints0` [F,J,3] / `verts0` [F,V,3] come from ONE forward of
+    the HMR pose with the solve's betas, the HMR root orientation and zero translation: nothing else of the body changes
+    while this stage runs."""
+
+    def __init__(self, markers: torch.Tensor, joints0: torch.Tensor, verts0: torch.Tensor, kp_target: torch.Tensor,
+                 mask: torch.Tensor, focal, center, w_reprojection: float, w_chamfer: float):
+        self.lib = _lib.load()
+        self.device = markers.device
+        # the handle stores raw pointers: the tensors live as long as the problem does
+        self._keep = [_f32(t, n) for t, n in ((markers, "markers"), (joints0, "joints0"), (verts0, "verts0"),
+                                               (kp_target, "kp_target"), (mask, "mask"))]
+        mk, j0, v0, kp, ms = self._keep
+        self.F, self.M, self.V, self.J = int(mk.shape[0]), int(mk.shape[1]), int(v0.shape[1]), int(j0.shape[1])
+        if j0.shape != (self.F, self.J, 3) or v0.shape != (self.F, self.V, 3) or kp.shape != (self.F, self.J, 2) \
+                or ms.shape != (self.F,) or mk.shape != (self.F, self.M, 3):
+            raise ValueError("ReprojectionProblem: inconsistent shapes")
+        p = UuoReprojectionProblem()
+        p.F, p.M, p.V, p.J = self.F, self.M, self.V, self.J
+        p.d_markers, p.d_joints0, p.d_verts0 = mk.data_ptr(), j0.data_ptr(), v0.data_ptr()
+        p.d_kp_target, p.d_mask = kp.data_ptr(), ms.data_ptr()
+        p.focal[0], p.focal[1] = float(focal[0]), float(focal[1])
+        p.center[0], p.center[1] = float(center[0]), float(center[1])
+        p.w_reprojection, p.w_chamfer = float(w_reprojection), float(w_chamfer)
+        self.problem = p
+        self.n = int(self.lib.uuo_reprojection_num_params(byref(p)))
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_reprojection_create(byref(p), byref(h)), "uuo_reprojection_create")
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.uuo_reprojection_destroy(h)
+
+    def evaluate(self, x: torch.Tensor, want_kp: bool = False, want_nn: bool = False):
+        """One closure evaluation: (loss, flat gradient [3F+14], key points [F,J,2] | None, nearest vertex [F,M] | None)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        loss = torch.empty((1,), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.n,), dtype=torch.float32, device=self.device)
+        kp = torch.empty((self.F, self.J, 2), dtype=torch.float32, device=self.device) if want_kp else None
+        nn = torch.empty((self.F, self.M), dtype=torch.int32, device=self.device) if want_nn else None
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_reprojection_eval(self.handle, current_stream(self.device), _ptr(x), _ptr(loss), _ptr(grad),
+                                                 _ptr(kp), _ptr(nn)), "uuo_reprojection_eval")
+        return float(loss.item()), grad, kp, nn
+
+    def solve(self, x: torch.Tensor, max_iter: int, lr: float = 1.0, tolerance_grad: float = 1e-7,
+              tolerance_change: float = 1e-9, history_size: int = 100,
+              callback: Optional[Callable[[int, float], None]] = None,
+              point_callback: Optional[Callable[[int, float, torch.Tensor], None]] = None) -> Dict:
+        """torch.optim.LBFGS(..., line_search_fn="strong_wolfe").step(closure) at hmr_utils.py:367 on the device; x updated
+        in place.  Returns the solver statistics plus `x_last` / `kp_last`: the parameter vector and the key points of the
+        LAST closure evaluation (what the reference's outputs are derived from, :383-425)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.numel() == self.n and x.is_contiguous()
+        opt = UuoLbfgsOptions(int(max_iter), int(history_size), float(lr), float(tolerance_grad),
+                              float(tolerance_change), 0, 0)
+        stats = UuoLbfgsStats()
+        x_last = x.clone()
+        kp_last = torch.zeros((self.F, self.J, 2), dtype=torch.float32, device=self.device)
+        stream = current_stream(self.device)
+
+        def on_eval(user, i, loss, d_x_eval):
+            if callback is not None:
+                callback(i, loss)
+            if point_callback is not None:
+                host = torch.empty((self.n,), dtype=torch.float32)
+                check(self.lib.uuo_copy_to_host(stream, d_x_eval, host.data_ptr(), self.n), "uuo_copy_to_host")
+                point_callback(i, loss, host)
+
+        cb = EVAL_CALLBACK(on_eval) if (callback is not None or point_callback is not None) else None
+        with torch.cuda.device(self.device):
+            check(self.lib.uuo_reprojection_solve(self.handle, stream, _ptr(x), byref(opt), byref(stats), _ptr(x_last),
+                                                  _ptr(kp_last), ctypes.cast(cb, c_void_p) if cb else None, None),
+                  "uuo_reprojection_solve")
+        return {"n_iter": stats.n_iter, "n_eval": stats.n_eval, "first_loss": stats.first_loss,
+                "final_loss": stats.final_loss, "stop_reason": STOP_REASONS[stats.stop_reason],
+                "device_ms": stats.device_ms, "driver": "device-lbfgs(fused reprojection closure)",
+                "x_last": x_last, "kp_last": kp_last}

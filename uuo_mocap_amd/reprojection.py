@@ -2,17 +2,22 @@
 camera-consistent placement -- the HMR body is rotated about the camera's vertical axis and translated so that its 45
 joints reproject onto the HMR 2D key points while its surface stays on the markers.
 
-Disabled in every shipped configuration (`stages.reprojection_part.num_iters: 0`), so it is not fused into the device
-solver: the closure is composed from the differentiable operators of this package -- `SmplInference` (HIP forward,
-`uuo_smpl_backward`) and `chamfer_distance` (HIP nearest neighbour) -- and driven by `torch.optim.LBFGS` exactly as the
-reference drives it (3F + 14 parameters).  The camera algebra is a handful of element-wise tensor expressions."""
+Disabled in every shipped configuration (`stages.reprojection_part.num_iters: 0`).  Since round 3 the closure is ONE fused
+evaluation of the library (`uuo_reprojection_solve`, csrc/reprojection.hip; `engine.ReprojectionProblem`): pose, shape and
+HMR root orientation are constants of this solve, so one SMPL forward before it replaces the two per closure, and the
+chamfer search runs against a constant cloud.  `driver="operators"` keeps the closure composed from the differentiable
+operators of this package -- `SmplInference` (HIP forward, `uuo_smpl_backward`) and `chamfer_distance` (HIP nearest
+neighbour) under `DeviceLBFGS` (3F + 14 parameters) -- as the cross-check of the fused one (tests/test_gpu_parity.py).
+The camera algebra around the solve is a handful of element-wise tensor expressions."""
 from __future__ import annotations
 
+from types import SimpleNamespace
 from typing import Dict, Optional
 
 import torch
 
 from .device_lbfgs import DeviceLBFGS
+from .engine import ReprojectionProblem
 from .losses import chamfer_distance
 from .smpl import SmplInference
 from .transforms import compute_root_orient_y
@@ -76,13 +81,10 @@ def get_3d_parameters(smpl_inference: SmplInference, pred_smpl_betas, pred_smpl_
             "pred_joints": joints, "pred_keypoints_2d_smpl": kp / HMR_IMG_SIZE, "rotation": rotation}
 
 
-def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size,
-                       cam_scale, angle, img_mask, smpl_inference: SmplInference, num_iters: int, config: Dict,
-                       verbose: bool = False, iter_fn=None) -> Dict:
-    """One yaw hypothesis `angle` (0-d tensor) of the reprojection fit (hmr_utils.py:170-425).  Optimises the yaw
-    about the camera's vertical axis [1], the per-frame body translation [F,3] (HMR axes), one camera translation
-    [3] and the shape [10] on  mean((kp - kp_hmr)^2 * mask) * w_reprojection + chamfer(markers -> vertices) * w_chamfer.
-    Returns the reference's dictionary (leading hypothesis axis of size 1 kept)."""
+def _prepare(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size, cam_scale, angle,
+             smpl_inference: SmplInference, config: Dict) -> SimpleNamespace:
+    """Everything optim_reprojection sets up before its solve (hmr_utils.py:196-279): the HMR camera, the target key
+    points and frame mask, and the starting values of the optimised leaves."""
     device = markers.device
     F = pose_body.shape[0]
     w = config["stages"]["reprojection_part"]["losses"]
@@ -107,11 +109,48 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
     cam_single = torch.mean(cam_translation - offset, dim=0, keepdim=True).clone().requires_grad_(True)  # [1, 3]
     yaw = (torch.ones(1, 1, 1, 1, device=device) * angle).to(device).requires_grad_(True)
     focal = torch.mean(cam["focal_length"], dim=0, keepdim=True)                           # [1, 2]
-    # `betas` is in the parameter list but detached (hmr_utils.py:218,292): it receives no gradient and stays put
-    optimizer = DeviceLBFGS([yaw, body_t, cam_single, betas], max_iter=num_iters,
-                                  tolerance_grad=config["optimizer"]["tolerance_grad"],
-                                  tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
-                                  line_search_fn="strong_wolfe")
+    return SimpleNamespace(device=device, F=F, w=w, pose_body=pose_body, betas=betas, root_orient=root_orient,
+                           correction=correction, cam=cam, kp_target=kp_target, mask=mask, body_t=body_t,
+                           cam_single=cam_single, yaw=yaw, focal=focal)
+
+
+def _fused_problem(pr: SimpleNamespace, markers, smpl_inference: SmplInference):
+    """(engine.ReprojectionProblem, x0) of a prepared hypothesis.  Pose, shape (detached: hmr_utils.py:218,292) and HMR root
+    orientation never change in this solve, so ONE forward here stands for the two of every closure evaluation.
+    x = [yaw | body_t | cam_single | betas]: the order of the reference's params list (:276-279)."""
+    with torch.no_grad():
+        fwd0 = smpl_inference(pr.pose_body, pr.betas.expand(pr.F, 10), pr.root_orient,
+                              torch.zeros((pr.F, 3), device=pr.device))
+        x0 = torch.cat([pr.yaw.detach().reshape(-1), pr.body_t.detach().reshape(-1), pr.cam_single.detach().reshape(-1),
+                        pr.betas.reshape(-1)]).contiguous()
+        problem = ReprojectionProblem(markers, fwd0["joints"], fwd0["vertices"], pr.kp_target[0], pr.mask,
+                                      pr.focal[0].tolist(), pr.cam["camera_center"][0].tolist(), pr.w["reprojection"],
+                                      pr.w["chamfer"])
+    return problem, x0
+
+
+def reprojection_problem(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size,
+                         cam_scale, angle, smpl_inference: SmplInference, config: Dict):
+    """The fused closure of one yaw hypothesis and its starting point, without solving: (engine.ReprojectionProblem, x0)."""
+    pr = _prepare(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size, cam_scale, angle,
+                  smpl_inference, config)
+    return _fused_problem(pr, markers, smpl_inference)
+
+
+def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size,
+                       cam_scale, angle, img_mask, smpl_inference: SmplInference, num_iters: int, config: Dict,
+                       verbose: bool = False, iter_fn=None, driver: str = "fused") -> Dict:
+    """One yaw hypothesis `angle` (0-d tensor) of the reprojection fit (hmr_utils.py:170-425).  Optimises the yaw
+    about the camera's vertical axis [1], the per-frame body translation [F,3] (HMR axes), one camera translation
+    [3] and the shape [10] on  mean((kp - kp_hmr)^2 * mask) * w_reprojection + chamfer(markers -> vertices) * w_chamfer.
+    Returns the reference's dictionary (leading hypothesis axis of size 1 kept).  `driver`: "fused" (the library's fused
+    closure) or "operators" (the closure composed from this package's differentiable operators; the cross-check)."""
+    if driver not in ("fused", "operators"):
+        raise ValueError("optim_reprojection: driver must be 'fused' or 'operators'")
+    pr = _prepare(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size, cam_scale,
+                  angle, smpl_inference, config)
+    device, F, w, pose_body, betas, root_orient, correction = pr.device, pr.F, pr.w, pr.pose_body, pr.betas, pr.root_orient, pr.correction
+    cam, kp_target, mask, body_t, cam_single, yaw, focal = pr.cam, pr.kp_target, pr.mask, pr.body_t, pr.cam_single, pr.yaw, pr.focal
     eye = torch.eye(3, device=device).unsqueeze(0).expand(F, -1, -1)
     state = {}
     n_eval = [0]
@@ -128,24 +167,61 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
         state.update(cam_tr=cam_tr, y_root=y_root, inv_t=inv_t, kp=kp)
         return kp, y_root, betas_f
 
-    def closure():
-        optimizer.zero_grad()
-        kp, y_root, betas_f = forward_terms()
-        loss = torch.mean((kp - kp_target) ** 2 * mask[None, :, None, None]) * w["reprojection"]
-        verts = smpl_inference(pose_body, betas_f, (correction @ y_root)[0], convert_hmr_pos_to_mocap_pos(body_t)[0])["vertices"]
-        loss = loss + chamfer_distance(markers, verts, single_directional=True)[0] * w["chamfer"]
-        loss.backward()
+    def report(loss_value, kp, y_root):
         if verbose:
-            print("Reprojection", float(loss))
+            print("Reprojection", float(loss_value))
         if iter_fn is not None:  # hmr_utils.py:350-362
             iter_fn(stage="reprojection", iteration=n_eval[0], pose_body=pose_body.detach().cpu().numpy(),
                     betas=betas.detach().cpu().numpy(), trans=convert_hmr_pos_to_mocap_pos(body_t)[0].detach().cpu().numpy(),
                     root_orient=(correction @ y_root)[0].detach().cpu().numpy(), pred_angle=yaw.item(), initial_angle=angle,
                     pred_2d_joints=kp[0].detach().cpu().numpy(), gt_2d_joints=kp_target[0].detach().cpu().numpy())
         n_eval[0] += 1
-        return loss
 
-    optimizer.step(closure)
+    if driver == "fused":
+        problem, x = _fused_problem(pr, markers, smpl_inference)
+        with torch.no_grad():
+            sizes = (1, 3 * F, 3, betas.numel())
+
+            def unpack(vec):
+                a, b, c, _ = torch.split(vec, sizes)
+                yaw.copy_(a.view_as(yaw)); body_t.copy_(b.view_as(body_t)); cam_single.copy_(c.view_as(cam_single))
+
+            def on_point(i, loss_value, host_x):
+                unpack(host_x.to(device))
+                kp, y_root, _ = forward_terms()
+                report(loss_value, kp, y_root)
+
+            want_points = iter_fn is not None
+            stats = problem.solve(x, num_iters, lr=1.0, tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                  tolerance_change=config["optimizer"]["tolerance_change"],
+                                  callback=(lambda i, l: report(l, None, None)) if (verbose and not want_points) else None,
+                                  point_callback=on_point if want_points else None)
+            # the derived quantities of the LAST closure evaluation (below), then the accepted parameters
+            unpack(stats["x_last"])
+            forward_terms()
+            state["kp"] = stats["kp_last"][None]
+            unpack(x)
+        state["solver"] = {k: v for k, v in stats.items() if k not in ("x_last", "kp_last")}
+    else:
+        # `betas` is in the parameter list but detached (hmr_utils.py:218,292): it receives no gradient and stays put
+        optimizer = DeviceLBFGS([yaw, body_t, cam_single, betas], max_iter=num_iters,
+                                tolerance_grad=config["optimizer"]["tolerance_grad"],
+                                tolerance_change=config["optimizer"]["tolerance_change"], lr=1.0,
+                                line_search_fn="strong_wolfe")
+
+        def closure():
+            optimizer.zero_grad()
+            kp, y_root, betas_f = forward_terms()
+            loss = torch.mean((kp - kp_target) ** 2 * mask[None, :, None, None]) * w["reprojection"]
+            verts = smpl_inference(pose_body, betas_f, (correction @ y_root)[0],
+                                   convert_hmr_pos_to_mocap_pos(body_t)[0])["vertices"]
+            loss = loss + chamfer_distance(markers, verts, single_directional=True)[0] * w["chamfer"]
+            loss.backward()
+            report(loss, kp, y_root)
+            return loss
+
+        optimizer.step(closure)
+        state["solver"] = dict(optimizer.stats)
     # Like the reference (its `nonlocal` temporaries), the derived quantities below are those of the LAST closure
     # evaluation, which is not necessarily the accepted point of the line search; the parameters themselves
     # (`trans`, `output_angle`) are the accepted ones.
@@ -164,4 +240,5 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
         "camera_center": cam["camera_center"].clone(), "focal_length": focal.clone(), "reproject_mask": mask.clone(),
         "input_angle": float(angle), "output_angle": yaw.item(),
         "metrics": {"chamfer": chamfer_error, "reproject": reproject_error},
+        "solver": state["solver"],
     }
