@@ -796,9 +796,11 @@ def get_3d_parameters(smpl_inference, betas, body_pose, global_orient, pred_cam,
 
 
 def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans, pred_cam, cam_center, cam_size,
-                       cam_scale, angle, img_mask, smpl_inference, num_iters, config, trace: Optional[list] = None):
+                       cam_scale, angle, img_mask, smpl_inference, num_iters, config, trace: Optional[list] = None,
+                       capture: Optional[dict] = None):
     """hmr_utils.py:170-425 (A = 1 hypothesis axis kept).  Derived outputs are those of the last closure evaluation,
-    as the reference's nonlocal temporaries leave them."""
+    as the reference's nonlocal temporaries leave them.  `trace` collects the loss of every closure evaluation, `capture`
+    the flat parameter vector and gradient of the FIRST one (the order of the params list: yaw, body_t, cam, betas)."""
     F_ = pose_body.shape[0]
     w = config["stages"]["reprojection_part"]["losses"]
     pose_body, root_orient, trans = pose_body.clone(), root_orient.clone(), trans.clone()
@@ -844,6 +846,12 @@ def optim_reprojection(markers, pose_body, betas, hmr_betas, root_orient, trans,
         loss.backward()
         if trace is not None:
             trace.append(float(loss))
+        if capture is not None and "grad" not in capture:
+            leaves = [yaw, body_t, cam_single, betas]
+            capture["params"] = torch.cat([p.detach().reshape(-1) for p in leaves]).clone()
+            capture["grad"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                         for p in leaves]).clone()
+            capture["loss"] = float(loss)
         last.update(cam_tr=cam_tr.detach(), y_root=y_root.detach(), inv_t=inv_t.detach(), kp=kp.detach())
         return loss
 

@@ -201,6 +201,37 @@ def test_marker_placement_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M,
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[0]
+@pytest.mark.parametrize("F,M,seed", SIZES)
+def test_reprojection_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, seed):
+    """The fused 2D-prior closure (uuo_reprojection_eval) against the oracle's restatement of the reference closure
+    (hmr_utils.py:281-365: two dense SMPL forwards + autograd) at the BASELINE sizes, both yaw hypotheses of the fixture
+    set-up: same starting point, loss rtol 2e-5, flat gradient relative L2 < 2e-4."""
+    from uuo_mocap_amd.reprojection import reprojection_problem
+    from uuo_mocap_amd.synthetic import synthetic_hmr_camera
+
+    seq, markers, o_pose, o_betas, _, trans = _inputs(tables, F, M, seed)
+    img = seq.img_smpl
+    pred_cam, center, size, scale = synthetic_hmr_camera(F)
+    cfg = packaged_config("video_mocap")
+    for angle in (0.0, float(np.pi / 2)):
+        args = dict(markers=markers, pose_body=o_pose, betas=o_betas, hmr_betas=img.betas.clone(),
+                    root_orient=img.hmr_root_orient.clone(), trans=trans, pred_cam=pred_cam, cam_center=center,
+                    cam_size=size, cam_scale=scale, angle=torch.tensor(angle))
+        cap = {}
+        stages_ref.optim_reprojection(img_mask=img.img_mask, smpl_inference=oracle_smpl, num_iters=1, config=cfg,
+                                      capture=cap, **args)
+        prob, x0 = reprojection_problem(smpl_inference=smpl, config=cfg,
+                                        **{k: (v.to(dev) if isinstance(v, torch.Tensor) and v.dim() > 0 else v)
+                                           for k, v in args.items()})
+        np.testing.assert_allclose(x0.cpu().numpy(), cap["params"].numpy(), atol=3e-5)
+        loss, grad, _, _ = prob.evaluate(cap["params"].to(dev).contiguous())
+        rel = _rel_err(grad.cpu().numpy(), cap["grad"].numpy())
+        print("OBS reprojection closure %dx%d yaw %.2f: loss %.6f (oracle %.6f), gradient rel-L2 %.2e"
+              % (F, M, angle, loss, cap["loss"], rel))
+        assert loss == pytest.approx(cap["loss"], rel=2e-5)
+        assert rel < 2e-4
+
+
 def test_end_to_end_config0_against_the_reference_fit(smpl, oracle_smpl, golden, dev, record_property):
     """BASELINE ``configs[0]``: 30 frames x 41 markers, ``video_mocap.yaml`` as shipped (10000-iteration budgets, 4 yaw
     hypotheses).  tests/golden/e2e_config0.npz holds the reference's OWN ``multimodal_video_mocap`` run on these inputs

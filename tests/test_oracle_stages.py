@@ -152,12 +152,16 @@ def test_reprojection_stage_matches_reference(oracle_smpl, golden):
     cfg["stages"]["reprojection_part"]["num_iters"] = 200
     t = lambda k: torch.from_numpy(np.asarray(g[k])).float()
     for name, angle in (("a0", 0.0), ("a1", float(np.pi / 2))):
-        trace = []
+        trace, cap = [], {}
         out = stages_ref.optim_reprojection(
             markers=t("markers"), pose_body=t("hmr_pose_body"), betas=t("betas"), hmr_betas=t("hmr_betas"),
             root_orient=t("hmr_root_orient"), trans=t("trans"), pred_cam=t("pred_cam"), cam_center=t("center"),
             cam_size=t("size"), cam_scale=t("scale"), angle=torch.tensor(angle), img_mask=t("img_mask"),
-            smpl_inference=oracle_smpl, num_iters=200, config=cfg, trace=trace)
+            smpl_inference=oracle_smpl, num_iters=200, config=cfg, trace=trace, capture=cap)
+        # the first closure evaluation: same point, same gradient as the reference's own torch.optim.LBFGS saw
+        np.testing.assert_allclose(cap["params"].numpy(), g[name + "_first_params"], atol=1e-5)
+        gref = g[name + "_first_grad"]
+        assert np.linalg.norm(cap["grad"].numpy() - gref) / np.linalg.norm(gref) < 1e-4
         ref = g[name + "_losses"]
         n = min(len(trace), len(ref), 20)
         np.testing.assert_allclose(trace[:n], ref[:n], rtol=2e-4)

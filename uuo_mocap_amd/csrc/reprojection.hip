@@ -9,13 +9,16 @@
 //     vertex(f,i)  = C (Ry(yaw) W(f,i) + b_f) + j0(f),     W = verts0 - j0,  j0 = joints0(f,0)      (hmr_utils.py:325-333)
 // (the root rotation C Ry(yaw) R0 turns the posed body about its pelvis j0; C = HMR -> mocap axes), and the nearest-vertex
 // search of the chamfer term becomes a search of M moving query points u = Ry(yaw)^T (C^T (m - j0) - b_f) against the
-// CONSTANT cloud W -- no skinning at all inside the closure.  One block per frame does the search (every lane keeps the
-// best of its vertex slice for 32 markers in registers, packed 64-bit minima across the block), the projection, both
-// gradients and the frame's partial sums; a one-block kernel adds the partials in double.  Two launches per evaluation.
+// CONSTANT cloud W -- no skinning at all inside the closure.  Three launches per evaluation: k_reproj_search (grid
+// F x 4 vertex slices: every lane keeps the running minimum of its vertices for 16 markers per pass, the markers in scalar
+// registers and two per packed-fp32 instruction; a transposing butterfly merges the wave, packed 64-bit (distance, index)
+// keys = pytorch3d's first-index tie order), k_reproj_terms (one wave per frame: the matched pairs' residuals, the 45
+// joints through the pinhole camera, both gradients, the frame's partial sums) and k_reproj_sum (one block: double sums).
 #include "uuo_common.h"
 
-#define RPJ_T 512    // threads of a frame block (8 waves: 64 registers of running minima per lane need the room)
-#define RPJ_MC 32    // markers per register pass
+#define RPJ_T 256    // threads of a search block (4 waves)
+#define RPJ_S 4      // vertex slices per frame (grid = F x RPJ_S search blocks: 1 200 at F = 300, all resident at once)
+#define RPJ_MC 16    // markers per register pass (their coordinates live in scalar registers, the running minima in 32 VGPRs)
 #define RPJ_NJ 64    // joints a frame may have (SMPL + the extra vertex joints: 45)
 #define RPJ_PW 8     // floats of a frame's partial sums: sum of squared key-point residuals (masked), sum of squared
                      // nearest distances, d/d yaw, d/d camera xyz, 2 unused
@@ -32,29 +35,138 @@ struct ReprojArgs {
   float coef_rep, coef_ch;  // 2 w_reprojection / (F J 2), 2 w_chamfer / (F M)
   float* grad;
   float* part;
+  unsigned long long* keys;  // [F][RPJ_S][M] packed (distance bits, vertex) minima of the slices
   float* kp_out;
   int32_t* nn_idx;
 };
 
-__device__ __forceinline__ unsigned long long rpj_wave_min(unsigned long long k) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(k, off, 64);
-    k = o < k ? o : k;
-  }
-  return k;
+typedef float rpj2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rpj_uniform(float v) {  // a wave-uniform value, kept in a scalar register
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ __forceinline__ float rpj_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// minima of N keys per lane over the wave's 64 lanes: a transposing butterfly -- at every step a lane keeps the half of its
+// keys that its side of the exchange owns and receives the partner's copy of them (N/2 + N/4 + .. exchanges instead of
+// 6 N).  Returns the minimum of key (lane >> 2) & (N - 1)... of marker index rpj_owned(lane), valid in every lane.
+template <int N>
+__device__ __forceinline__ unsigned long long rpj_transpose_min(unsigned long long (&key)[N], int lane) {
+  static_assert(N == 16, "16 keys per lane: four halving steps (lane bits 5..2), then two plain steps (bits 1, 0)");
+  unsigned long long k8[8], k4[4], k2[2];
+  {
+    const bool up = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned long long mine = up ? key[i + 8] : key[i], give = up ? key[i] : key[i + 8];
+      const unsigned long long got = __shfl_xor(give, 32, 64);
+      k8[i] = got < mine ? got : mine;
+    }
+  }
+  {
+    const bool up = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long mine = up ? k8[i + 4] : k8[i], give = up ? k8[i] : k8[i + 4];
+      const unsigned long long got = __shfl_xor(give, 16, 64);
+      k4[i] = got < mine ? got : mine;
+    }
+  }
+  {
+    const bool up = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned long long mine = up ? k4[i + 2] : k4[i], give = up ? k4[i] : k4[i + 2];
+      const unsigned long long got = __shfl_xor(give, 8, 64);
+      k2[i] = got < mine ? got : mine;
+    }
+  }
+  unsigned long long k1;
+  {
+    const bool up = lane & 4;
+    const unsigned long long mine = up ? k2[1] : k2[0], give = up ? k2[0] : k2[1];
+    const unsigned long long got = __shfl_xor(give, 4, 64);
+    k1 = got < mine ? got : mine;
+  }
+#pragma unroll
+  for (int off = 2; off >= 1; off >>= 1) {
+    const unsigned long long got = __shfl_xor(k1, off, 64);
+    k1 = got < k1 ? got : k1;
+  }
+  return k1;
+}
+// the key index a lane holds after rpj_transpose_min<16>: bit 5 chose +8, bit 4 +4, bit 3 +2, bit 2 +1
+__device__ __forceinline__ int rpj_owned(int lane) {
+  return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
 
-__global__ __launch_bounds__(RPJ_T) void k_reproj_frame(ReprojArgs a) {
-  __shared__ float4 sU[RPJ_MC];                             // query points of the pass (w unused)
-  __shared__ unsigned long long sK[RPJ_T / 64][RPJ_MC];     // per-wave minima
-  __shared__ float sAcc[8];                                 // chamfer part of the frame: loss, d yaw, d b xyz
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// search: block (f, s) finds, for every marker of frame f, the nearest vertex among slice s of the frame's vertices
+__global__ __launch_bounds__(RPJ_T) void k_reproj_search(ReprojArgs a) {
+  __shared__ unsigned long long sK[RPJ_T / 64][RPJ_MC];
+  const int f = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.M, V = a.V;
+  const float yaw = rpj_uniform(a.x[0]);
+  const float sn = sinf(yaw), cs = cosf(yaw);
+  const float bx = rpj_uniform(a.x[1 + 3 * f]), by = rpj_uniform(a.x[2 + 3 * f]), bz = rpj_uniform(a.x[3 + 3 * f]);
+  const float* j0p = a.joints0 + (size_t)f * a.J * 3;
+  const float j0x = rpj_uniform(j0p[0]), j0y = rpj_uniform(j0p[1]), j0z = rpj_uniform(j0p[2]);
+  const float* vf = a.verts0 + (size_t)f * V * 3;
+  const int per = (V + RPJ_S - 1) / RPJ_S, i0 = sl * per, i1 = min(V, i0 + per);
+  for (int m0 = 0; m0 < M; m0 += RPJ_MC) {
+    // the pass' query points  u = Ry(yaw)^T (C^T (m - j0) - b):  mocap axes -> HMR axes (x, -z, y), then into the body's
+    // un-yawed frame; pairs of markers share the packed-fp32 instructions (same IEEE operations, element by element); a pass
+    // past the end repeats the last marker (its minima are simply not stored)
+    rpj2 ux[RPJ_MC / 2], uy[RPJ_MC / 2], uz[RPJ_MC / 2];
+#pragma unroll
+    for (int k = 0; k < RPJ_MC; ++k) {
+      const float* mp = a.markers + ((size_t)f * M + min(m0 + k, M - 1)) * 3;
+      const float qx = (rpj_uniform(mp[0]) - j0x) - bx, qy = -(rpj_uniform(mp[2]) - j0z) - by, qz = (rpj_uniform(mp[1]) - j0y) - bz;
+      const float vx = rpj_uniform(cs * qx - sn * qz), vy = qy, vz = rpj_uniform(sn * qx + cs * qz);
+      if (k & 1) { ux[k / 2].y = vx; uy[k / 2].y = vy; uz[k / 2].y = vz; }
+      else { ux[k / 2].x = vx; uy[k / 2].x = vy; uz[k / 2].x = vz; }
+    }
+    unsigned bd[RPJ_MC], bi[RPJ_MC];
+#pragma unroll
+    for (int k = 0; k < RPJ_MC; ++k) { bd[k] = 0x7F800000u; bi[k] = 0x7FFFFFFFu; }  // +inf, no vertex
+    for (int i = i0 + tid; i < i1; i += RPJ_T) {
+      const float wx = vf[3 * i] - j0x, wy = vf[3 * i + 1] - j0y, wz = vf[3 * i + 2] - j0z;
+      const rpj2 wx2 = rpj2{wx, wx}, wy2 = rpj2{wy, wy}, wz2 = rpj2{wz, wz};
+#pragma unroll
+      for (int k = 0; k < RPJ_MC / 2; ++k) {
+        const rpj2 dx = ux[k] - wx2, dy = uy[k] - wy2, dz = uz[k] - wz2;
+        const rpj2 d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // the bits of a non-negative distance order as unsigned exactly as the value does (a NaN orders above +inf and is
+          // never taken); a lane visits its vertices in rising order, so strict '<' keeps the first minimum
+          const unsigned d = __float_as_uint(h ? d2.y : d2.x);
+          const bool better = d < bd[2 * k + h];
+          bd[2 * k + h] = better ? d : bd[2 * k + h];
+          bi[2 * k + h] = better ? (unsigned)i : bi[2 * k + h];
+        }
+      }
+    }
+    unsigned long long key[RPJ_MC];
+#pragma unroll
+    for (int k = 0; k < RPJ_MC; ++k) key[k] = ((unsigned long long)bd[k] << 32) | bi[k];
+    const unsigned long long kmin = rpj_transpose_min<RPJ_MC>(key, lane);
+    __syncthreads();  // (the previous pass' sK has been consumed)
+    if ((lane & 3) == 0) sK[wave][rpj_owned(lane)] = kmin;
+    __syncthreads();
+    if (tid < RPJ_MC && m0 + tid < M) {
+      unsigned long long k0 = sK[0][tid];
+#pragma unroll
+      for (int w = 1; w < RPJ_T / 64; ++w) { const unsigned long long o = sK[w][tid]; k0 = o < k0 ? o : k0; }
+      a.keys[((size_t)f * RPJ_S + sl) * M + m0 + tid] = k0;
+    }
+  }
+}
+
+// terms: one wave per frame merges the slices' minima and evaluates both terms with their gradients
+__global__ __launch_bounds__(64) void k_reproj_terms(ReprojArgs a) {
+  const int f = blockIdx.x, lane = threadIdx.x;
   const int F = a.F, M = a.M, V = a.V;
   const float yaw = a.x[0];
   const float sn = sinf(yaw), cs = cosf(yaw);
@@ -62,107 +174,63 @@ __global__ __launch_bounds__(RPJ_T) void k_reproj_frame(ReprojArgs a) {
   const float* j0p = a.joints0 + (size_t)f * a.J * 3;
   const float j0x = j0p[0], j0y = j0p[1], j0z = j0p[2];
   const float* vf = a.verts0 + (size_t)f * V * 3;
-  if (tid < 8) sAcc[tid] = 0.f;
-
-  // ---- chamfer term: nearest vertex of every marker, 32 markers per pass over the frame's vertices
-  for (int m0 = 0; m0 < M; m0 += RPJ_MC) {
-    const int mc = min(RPJ_MC, M - m0);
-    __syncthreads();  // (previous pass has consumed sU / sK)
-    if (tid < mc) {
-      const float* mp = a.markers + ((size_t)f * M + m0 + tid) * 3;
-      // C^T (m - j0) - b : mocap axes -> HMR axes (x, -z, y), then into the body's un-yawed frame
-      const float qx = (mp[0] - j0x) - bx, qy = -(mp[2] - j0z) - by, qz = (mp[1] - j0y) - bz;
-      sU[tid] = make_float4(cs * qx - sn * qz, qy, sn * qx + cs * qz, 0.f);
-    }
-    __syncthreads();
-    float best[RPJ_MC];
-    int bidx[RPJ_MC];
+  // ---- chamfer term
+  float cl = 0.f, cyaw = 0.f, cbx = 0.f, cby = 0.f, cbz = 0.f;
+  for (int m = lane; m < M; m += 64) {
+    unsigned long long key = a.keys[((size_t)f * RPJ_S) * M + m];
 #pragma unroll
-    for (int k = 0; k < RPJ_MC; ++k) { best[k] = __builtin_inff(); bidx[k] = 0x7FFFFFFF; }
-    for (int i = tid; i < V; i += RPJ_T) {
+    for (int sl = 1; sl < RPJ_S; ++sl) { const unsigned long long o = a.keys[((size_t)f * RPJ_S + sl) * M + m]; key = o < key ? o : key; }
+    const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
+    if (i < V) {  // (a NaN marker has no minimum: it contributes nothing, where the reference would propagate the NaN)
+      if (a.nn_idx) a.nn_idx[(size_t)f * M + m] = i;
       const float wx = vf[3 * i] - j0x, wy = vf[3 * i + 1] - j0y, wz = vf[3 * i + 2] - j0z;
-#pragma unroll
-      for (int k = 0; k < RPJ_MC; ++k) {
-        if (k < mc) {  // block-uniform
-          const float4 u = sU[k];
-          const float dx = u.x - wx, dy = u.y - wy, dz = u.z - wz;
-          const float d = dx * dx + dy * dy + dz * dz;
-          if (d < best[k]) { best[k] = d; bidx[k] = i; }  // a lane visits its vertices in rising order: first minimum kept
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < RPJ_MC; ++k) {
-      if (k < mc) {
-        const unsigned long long key =
-            rpj_wave_min(((unsigned long long)__float_as_uint(best[k]) << 32) | (unsigned)bidx[k]);
-        if (lane == 0) sK[wave][k] = key;
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float l = 0.f, gy_ = 0.f, gbx = 0.f, gby = 0.f, gbz = 0.f;
-      if (lane < mc) {
-        unsigned long long key = sK[0][lane];
-#pragma unroll
-        for (int w = 1; w < RPJ_T / 64; ++w) { const unsigned long long o = sK[w][lane]; key = o < key ? o : key; }
-        const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
-        if (i < V) {  // (a NaN marker has no minimum: it contributes nothing, where the reference would propagate the NaN)
-          if (a.nn_idx) a.nn_idx[(size_t)f * M + m0 + lane] = i;
-          const float wx = vf[3 * i] - j0x, wy = vf[3 * i + 1] - j0y, wz = vf[3 * i + 2] - j0z;
-          const float* mp = a.markers + ((size_t)f * M + m0 + lane) * 3;
-          // d = Ry(yaw) W + b - C^T (m - j0): the residual vertex - marker in HMR axes
-          const float rx = cs * wx + sn * wz, rz = -sn * wx + cs * wz;
-          const float dx = rx + bx - (mp[0] - j0x), dy = wy + by + (mp[2] - j0z), dz = rz + bz - (mp[1] - j0y);
-          l = dx * dx + dy * dy + dz * dz;
-          gbx = a.coef_ch * dx; gby = a.coef_ch * dy; gbz = a.coef_ch * dz;
-          gy_ = gbx * rz - gbz * rx;  // d . (d Ry / d yaw) W,  (d Ry / d yaw) W = (rz, 0, -rx)
-        }
-      }
-      l = rpj_wave_sum(l); gy_ = rpj_wave_sum(gy_); gbx = rpj_wave_sum(gbx); gby = rpj_wave_sum(gby); gbz = rpj_wave_sum(gbz);
-      if (lane == 0) { sAcc[0] += l; sAcc[1] += gy_; sAcc[2] += gbx; sAcc[3] += gby; sAcc[4] += gbz; }
+      const float* mp = a.markers + ((size_t)f * M + m) * 3;
+      // d = Ry(yaw) W + b - C^T (m - j0): the residual vertex - marker in HMR axes
+      const float rx = cs * wx + sn * wz, rz = -sn * wx + cs * wz;
+      const float dx = rx + bx - (mp[0] - j0x), dy = wy + by + (mp[2] - j0z), dz = rz + bz - (mp[1] - j0y);
+      cl += dx * dx + dy * dy + dz * dz;
+      const float gx_ = a.coef_ch * dx, gy_ = a.coef_ch * dy, gz_ = a.coef_ch * dz;
+      cbx += gx_; cby += gy_; cbz += gz_;
+      cyaw += gx_ * rz - gz_ * rx;  // d . (d Ry / d yaw) W,  (d Ry / d yaw) W = (rz, 0, -rx)
     }
   }
-  __syncthreads();
-
-  // ---- key-point term: the frame's joints through the pinhole camera (wave 0)
-  if (wave == 0) {
-    const float ccx = a.x[1 + 3 * F], ccy = a.x[2 + 3 * F], ccz = a.x[3 + 3 * F];
-    const float ex = bx - ccx, ey = by - ccy, ez = bz - ccz;
-    // inv_t = Ry(-yaw) (b - c) + c
-    const float tx = (cs * ex - sn * ez) + ccx, ty = ey + ccy, tz = (sn * ex + cs * ez) + ccz;
-    const float mk = a.mask[f];
-    float l = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    if (lane < a.J) {
-      const float* jp = j0p + 3 * lane;
-      const float px = (jp[0] + tx) + ccx, py = (jp[1] + ty) + ccy, pz = (jp[2] + tz) + ccz;
-      const float kx = ((px / pz) * a.fx + a.cx) + 0.5f, ky = ((py / pz) * a.fy + a.cy) + 0.5f;
-      if (a.kp_out) {
-        a.kp_out[((size_t)f * a.J + lane) * 2] = kx;
-        a.kp_out[((size_t)f * a.J + lane) * 2 + 1] = ky;
-      }
-      const float* tp = a.kp_target + ((size_t)f * a.J + lane) * 2;
-      const float r0 = kx - tp[0], r1 = ky - tp[1];
-      l = (r0 * r0 + r1 * r1) * mk;
-      gx = a.coef_rep * mk * r0 * a.fx / pz;
-      gy = a.coef_rep * mk * r1 * a.fy / pz;
-      gz = -(gx * px + gy * py) / pz;
+  cl = rpj_wave_sum(cl); cyaw = rpj_wave_sum(cyaw); cbx = rpj_wave_sum(cbx); cby = rpj_wave_sum(cby); cbz = rpj_wave_sum(cbz);
+  // ---- key-point term: the frame's joints through the pinhole camera
+  const float ccx = a.x[1 + 3 * F], ccy = a.x[2 + 3 * F], ccz = a.x[3 + 3 * F];
+  const float ex = bx - ccx, ey = by - ccy, ez = bz - ccz;
+  // inv_t = Ry(-yaw) (b - c) + c
+  const float tx = (cs * ex - sn * ez) + ccx, ty = ey + ccy, tz = (sn * ex + cs * ez) + ccz;
+  const float mk = a.mask[f];
+  float l = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  if (lane < a.J) {
+    const float* jp = j0p + 3 * lane;
+    const float px = (jp[0] + tx) + ccx, py = (jp[1] + ty) + ccy, pz = (jp[2] + tz) + ccz;
+    const float kx = ((px / pz) * a.fx + a.cx) + 0.5f, ky = ((py / pz) * a.fy + a.cy) + 0.5f;
+    if (a.kp_out) {
+      a.kp_out[((size_t)f * a.J + lane) * 2] = kx;
+      a.kp_out[((size_t)f * a.J + lane) * 2 + 1] = ky;
     }
-    l = rpj_wave_sum(l); gx = rpj_wave_sum(gx); gy = rpj_wave_sum(gy); gz = rpj_wave_sum(gz);
-    if (lane == 0) {
-      const float rgx = cs * gx + sn * gz, rgz = -sn * gx + cs * gz;  // Ry(yaw) G = (d inv_t / d b)^T G
-      a.grad[1 + 3 * f] = sAcc[2] + rgx;
-      a.grad[2 + 3 * f] = sAcc[3] + gy;
-      a.grad[3 + 3 * f] = sAcc[4] + rgz;
-      float* pp = a.part + (size_t)f * RPJ_PW;
-      pp[0] = l;
-      pp[1] = sAcc[0];
-      // d inv_t / d yaw = (d Ry(-yaw) / d yaw) (b - c) = (-sn ex - cs ez, 0, cs ex - sn ez)
-      pp[2] = sAcc[1] + gx * (-sn * ex - cs * ez) + gz * (cs * ex - sn * ez);
-      pp[3] = 2.f * gx - rgx;  // the camera translation enters twice: p = joints0 + Ry(-yaw)(b - c) + c + c
-      pp[4] = gy;             // (2 G - Ry(yaw) G)_y
-      pp[5] = 2.f * gz - rgz;
-    }
+    const float* tp = a.kp_target + ((size_t)f * a.J + lane) * 2;
+    const float r0 = kx - tp[0], r1 = ky - tp[1];
+    l = (r0 * r0 + r1 * r1) * mk;
+    gx = a.coef_rep * mk * r0 * a.fx / pz;
+    gy = a.coef_rep * mk * r1 * a.fy / pz;
+    gz = -(gx * px + gy * py) / pz;
+  }
+  l = rpj_wave_sum(l); gx = rpj_wave_sum(gx); gy = rpj_wave_sum(gy); gz = rpj_wave_sum(gz);
+  if (lane == 0) {
+    const float rgx = cs * gx + sn * gz, rgz = -sn * gx + cs * gz;  // Ry(yaw) G = (d inv_t / d b)^T G
+    a.grad[1 + 3 * f] = cbx + rgx;
+    a.grad[2 + 3 * f] = cby + gy;
+    a.grad[3 + 3 * f] = cbz + rgz;
+    float* pp = a.part + (size_t)f * RPJ_PW;
+    pp[0] = l;
+    pp[1] = cl;
+    // d inv_t / d yaw = (d Ry(-yaw) / d yaw) (b - c) = (-sn ex - cs ez, 0, cs ex - sn ez)
+    pp[2] = cyaw + gx * (-sn * ex - cs * ez) + gz * (cs * ex - sn * ez);
+    pp[3] = 2.f * gx - rgx;  // the camera translation enters twice: p = joints0 + Ry(-yaw)(b - c) + c + c
+    pp[4] = gy;             // (2 G - Ry(yaw) G)_y
+    pp[5] = 2.f * gz - rgz;
   }
 }
 
@@ -216,11 +284,13 @@ extern "C" int uuo_reprojection_create(const uuo_reprojection_problem_t* p, uuo_
   UUO_REQUIRE((long long)p->F * p->V * 3 < 0x7FFFFFFFll, "uuo_reprojection_create: F * V too large");
   uuo_reprojection* h = new uuo_reprojection();
   h->p = *p;
-  if (hipMalloc((void**)&h->part, (size_t)p->F * RPJ_PW * sizeof(float)) != hipSuccess) {
+  const size_t part_bytes = ((size_t)p->F * RPJ_PW * sizeof(float) + 255) / 256 * 256;
+  if (hipMalloc((void**)&h->part, part_bytes + (size_t)p->F * RPJ_S * p->M * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     uuo_set_error("uuo_reprojection_create: out of device memory");
     return -12;
   }
+  h->keys = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->part) + part_bytes);
   *out = h;
   return 0;
 }
@@ -243,8 +313,9 @@ int uuo_reprojection_eval_impl(uuo_reprojection* h, hipStream_t s, const float* 
   const double n_rep = (double)p.F * p.J * 2.0, n_ch = (double)p.F * p.M;
   a.coef_rep = (float)(2.0 * (double)p.w_reprojection / n_rep);
   a.coef_ch = (float)(2.0 * (double)p.w_chamfer / n_ch);
-  a.grad = d_grad; a.part = h->part; a.kp_out = d_kp; a.nn_idx = d_nn_idx;
-  hipLaunchKernelGGL(k_reproj_frame, dim3(p.F), dim3(RPJ_T), 0, s, a);
+  a.grad = d_grad; a.part = h->part; a.keys = h->keys; a.kp_out = d_kp; a.nn_idx = d_nn_idx;
+  hipLaunchKernelGGL(k_reproj_search, dim3(p.F, RPJ_S), dim3(RPJ_T), 0, s, a);
+  hipLaunchKernelGGL(k_reproj_terms, dim3(p.F), dim3(64), 0, s, a);
   ReprojSumArgs r;
   r.F = p.F; r.part = h->part;
   r.scale_rep = (float)((double)p.w_reprojection / n_rep);
