@@ -421,8 +421,26 @@ def main():
                     dt = time.perf_counter() - t1
                 q_o = [fit_quality(smpl, sq, out, dev) for sq, (out, _) in zip(seqs_o[1:], fits_o)]
                 st_o = [st for _, st in fits_o]
+                # ... and as a dataset is run (parallel.fit_many, the headline's `--inflight`): throughput, not latency
+                flight = None
+                if args.inflight > 1:
+                    n_fl = 2 * args.inflight
+                    seqs_f = [make_sequence(tables, seed=2000 + i, num_frames=F, num_markers=10 if limb_o else M,
+                                            limb_only=limb_o) for i in range(args.inflight + n_fl)]
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        fit_many(seqs_f[:args.inflight], lambda sq: fit_once(smpl, sq, cfg_o, dev), inflight=args.inflight,
+                                 device=dev)  # (the workspaces of the other workspace groups)
+                        torch.cuda.synchronize(dev)
+                        t2 = time.perf_counter()
+                        fit_many(seqs_f[args.inflight:], lambda sq: fit_once(smpl, sq, cfg_o, dev), inflight=args.inflight,
+                                 device=dev)
+                        torch.cuda.synchronize(dev)
+                        dt2 = time.perf_counter() - t2
+                    flight = {"sequences_in_flight": args.inflight, "steps": n_fl, "value": n_fl * F / dt2,
+                              "unit": "frames/s", "ms_per_step": 1e3 * dt2 / n_fl}
                 result["other_configs"][name] = {
                     "value": n_other * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n_other, "steps": n_other,
+                    "sequences_in_flight": 1, "in_flight": flight,
                     "markers": 10 if limb_o else M,
                     "closure_evals_per_step": sum(sum(eval_counts(s_).values()) for s_ in st_o) / max(n_other, 1),
                     "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
