@@ -232,6 +232,47 @@ def test_reprojection_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, F
         assert rel < 2e-4
 
 
+def test_reprojection_stage_at_baseline_size_against_the_reference(smpl, tables, golden, dev):
+    """The fused 2D-prior closure and its solve at 300 x 50 against what the REFERENCE's own optim_reprojection produced
+    there (fixture reprojection_stage_300x50.npz, oracle/make_golden_reprojection_full.py: the first parameter vector, the
+    first gradient and the losses of a 20-iteration solve as its torch.optim.LBFGS saw them), both yaw hypotheses."""
+    from uuo_mocap_amd.reprojection import reprojection_problem
+    from uuo_mocap_amd.synthetic import synthetic_hmr_camera
+
+    g = golden("reprojection_stage_300x50.npz")
+    F, M, seed = int(g["F"]), int(g["M"]), int(g["seed"])
+    seq, markers, o_pose, o_betas, _, trans = _inputs(tables, F, M, seed)
+    assert float(np.abs(markers.double().numpy()).sum()) == pytest.approx(float(g["markers_checksum"]), rel=1e-12)
+    img = seq.img_smpl
+    pred_cam, center, size, scale = synthetic_hmr_camera(F)
+    cfg = packaged_config("video_mocap")
+    for name, angle in (("a0", 0.0), ("a1", float(np.pi / 2))):
+        d = lambda t: t.to(dev)
+        prob, x0 = reprojection_problem(
+            markers=d(markers), pose_body=d(o_pose), betas=d(o_betas), hmr_betas=d(img.betas.clone()),
+            root_orient=d(img.hmr_root_orient.clone()), trans=d(trans), pred_cam=d(pred_cam), cam_center=d(center),
+            cam_size=d(size), cam_scale=d(scale), angle=torch.tensor(angle), smpl_inference=smpl, config=cfg)
+        np.testing.assert_allclose(x0.cpu().numpy(), g[name + "_first_params"], atol=3e-5)
+        x_ref = torch.from_numpy(g[name + "_first_params"]).to(dev).contiguous()
+        loss, grad, _, _ = prob.evaluate(x_ref)
+        ref_l = g[name + "_losses"]
+        rel = _rel_err(grad.cpu().numpy(), g[name + "_first_grad"])
+        print("OBS reprojection 300x50 %s vs reference: loss %.6f (ref %.6f), gradient rel-L2 %.2e" % (name, loss, ref_l[0], rel))
+        assert loss == pytest.approx(float(ref_l[0]), rel=2e-5)
+        assert rel < 2e-4
+        losses = []
+        st = prob.solve(x_ref.clone(), int(g["num_iters"]), lr=1.0, tolerance_grad=cfg["optimizer"]["tolerance_grad"],
+                        tolerance_change=cfg["optimizer"]["tolerance_change"], callback=lambda i, l: losses.append(l))
+        print("OBS reprojection 300x50 %s: %d evaluations (ref %d), final loss %.5f (ref %.5f)"
+              % (name, len(losses), len(ref_l), losses[-1], ref_l[-1]))
+        # the line search of the first iteration follows the reference evaluation by evaluation; from the second iteration
+        # on the first curvature pair y = g1 - g0 of a tiny first step amplifies the last bits of the two gradients (the yaw
+        # entry is a nearly cancelling sum of 15 000 terms), so the paths are compared by where they arrive
+        np.testing.assert_allclose(losses[:4], ref_l[:4], rtol=2e-4)
+        assert abs(len(losses) - len(ref_l)) <= 3 and st["n_eval"] == len(losses)  # (both stop on max_eval = 25)
+        assert losses[-1] == pytest.approx(float(ref_l[-1]), rel=0.25)
+
+
 def test_end_to_end_config0_against_the_reference_fit(smpl, oracle_smpl, golden, dev, record_property):
     """BASELINE ``configs[0]``: 30 frames x 41 markers, ``video_mocap.yaml`` as shipped (10000-iteration budgets, 4 yaw
     hypotheses).  tests/golden/e2e_config0.npz holds the reference's OWN ``multimodal_video_mocap`` run on these inputs

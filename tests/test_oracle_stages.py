@@ -176,6 +176,33 @@ def test_reprojection_stage_matches_reference(oracle_smpl, golden):
         assert trace[-1] == pytest.approx(float(ref[-1]), rel=0.05)
 
 
+def test_reprojection_closure_at_baseline_size_matches_reference(oracle_smpl, tables, golden):
+    """The oracle's reprojection closure at 300 x 50 against the reference's own first evaluation there
+    (reprojection_stage_300x50.npz): same starting point, loss and gradient."""
+    from uuo_mocap_amd.synthetic import make_sequence, synthetic_hmr_camera
+
+    g = golden("reprojection_stage_300x50.npz")
+    F, M = int(g["F"]), int(g["M"])
+    seq = make_sequence(tables, seed=int(g["seed"]), num_frames=F, num_markers=M)
+    markers = torch.from_numpy(seq.markers.get_points()).float()
+    assert float(np.abs(markers.double().numpy()).sum()) == pytest.approx(float(g["markers_checksum"]), rel=1e-12)
+    img = seq.img_smpl
+    betas = (img.betas.sum(0, keepdim=True) / img.img_mask.sum()).clone()
+    trans = torch.median(markers, dim=1)[0].clone()
+    pred_cam, center, size, scale = synthetic_hmr_camera(F)
+    cfg = packaged_config("video_mocap")
+    cap = {}
+    stages_ref.optim_reprojection(
+        markers=markers, pose_body=img.pose_body.clone(), betas=betas, hmr_betas=img.betas.clone(),
+        root_orient=img.hmr_root_orient.clone(), trans=trans, pred_cam=pred_cam, cam_center=center, cam_size=size,
+        cam_scale=scale, angle=torch.tensor(0.0), img_mask=img.img_mask, smpl_inference=oracle_smpl, num_iters=1, config=cfg,
+        capture=cap)
+    np.testing.assert_allclose(cap["params"].numpy(), g["a0_first_params"], atol=1e-5)
+    assert cap["loss"] == pytest.approx(float(g["a0_losses"][0]), rel=1e-5)
+    gref = g["a0_first_grad"]
+    assert np.linalg.norm(cap["grad"].numpy() - gref) / np.linalg.norm(gref) < 1e-4
+
+
 def _part_losses_case(g):
     cfg = _cfg("hmr_part", g["num_iters"], 25, 25)
     cfg["stages"]["part"]["losses"] = {str(k): float(v) for k, v in zip(g["loss_names"], g["loss_weights"])}

@@ -20,7 +20,7 @@
 #define RPJ_S 4      // vertex slices per frame (grid = F x RPJ_S search blocks: 1 200 at F = 300, all resident at once)
 #define RPJ_MC 16    // markers per register pass (their coordinates live in scalar registers, the running minima in 32 VGPRs)
 #define RPJ_NJ 64    // joints a frame may have (SMPL + the extra vertex joints: 45)
-#define RPJ_PW 8     // floats of a frame's partial sums: sum of squared key-point residuals (masked), sum of squared
+#define RPJ_PW 8     // doubles of a frame's partial sums: sum of squared key-point residuals (masked), sum of squared
                      // nearest distances, d/d yaw, d/d camera xyz, 2 unused
 
 struct ReprojArgs {
@@ -34,7 +34,7 @@ struct ReprojArgs {
   float fx, fy, cx, cy;
   float coef_rep, coef_ch;  // 2 w_reprojection / (F J 2), 2 w_chamfer / (F M)
   float* grad;
-  float* part;
+  double* part;
   unsigned long long* keys;  // [F][RPJ_S][M] packed (distance bits, vertex) minima of the slices
   float* kp_out;
   int32_t* nn_idx;
@@ -44,7 +44,7 @@ typedef float rpj2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float rpj_uniform(float v) {  // a wave-uniform value, kept in a scalar register
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
-__device__ __forceinline__ float rpj_wave_sum(float v) {
+__device__ __forceinline__ double rpj_wave_sum(double v) {  // (sums of many signed fp32 terms: the yaw gradient nearly cancels)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_reproj_terms(ReprojArgs a) {
   const float j0x = j0p[0], j0y = j0p[1], j0z = j0p[2];
   const float* vf = a.verts0 + (size_t)f * V * 3;
   // ---- chamfer term
-  float cl = 0.f, cyaw = 0.f, cbx = 0.f, cby = 0.f, cbz = 0.f;
+  double cl = 0.0, cyaw = 0.0, cbx = 0.0, cby = 0.0, cbz = 0.0;  // the terms are fp32 products, their sums double
   for (int m = lane; m < M; m += 64) {
     unsigned long long key = a.keys[((size_t)f * RPJ_S) * M + m];
 #pragma unroll
@@ -188,10 +188,10 @@ __global__ __launch_bounds__(64) void k_reproj_terms(ReprojArgs a) {
       // d = Ry(yaw) W + b - C^T (m - j0): the residual vertex - marker in HMR axes
       const float rx = cs * wx + sn * wz, rz = -sn * wx + cs * wz;
       const float dx = rx + bx - (mp[0] - j0x), dy = wy + by + (mp[2] - j0z), dz = rz + bz - (mp[1] - j0y);
-      cl += dx * dx + dy * dy + dz * dz;
+      cl += (double)(dx * dx + dy * dy + dz * dz);
       const float gx_ = a.coef_ch * dx, gy_ = a.coef_ch * dy, gz_ = a.coef_ch * dz;
-      cbx += gx_; cby += gy_; cbz += gz_;
-      cyaw += gx_ * rz - gz_ * rx;  // d . (d Ry / d yaw) W,  (d Ry / d yaw) W = (rz, 0, -rx)
+      cbx += (double)gx_; cby += (double)gy_; cbz += (double)gz_;
+      cyaw += (double)(gx_ * rz) - (double)(gz_ * rx);  // d . (d Ry / d yaw) W,  (d Ry / d yaw) W = (rz, 0, -rx)
     }
   }
   cl = rpj_wave_sum(cl); cyaw = rpj_wave_sum(cyaw); cbx = rpj_wave_sum(cbx); cby = rpj_wave_sum(cby); cbz = rpj_wave_sum(cbz);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_reproj_terms(ReprojArgs a) {
   // inv_t = Ry(-yaw) (b - c) + c
   const float tx = (cs * ex - sn * ez) + ccx, ty = ey + ccy, tz = (sn * ex + cs * ez) + ccz;
   const float mk = a.mask[f];
-  float l = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  double l = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
   if (lane < a.J) {
     const float* jp = j0p + 3 * lane;
     const float px = (jp[0] + tx) + ccx, py = (jp[1] + ty) + ccy, pz = (jp[2] + tz) + ccz;
@@ -212,31 +212,32 @@ __global__ __launch_bounds__(64) void k_reproj_terms(ReprojArgs a) {
     }
     const float* tp = a.kp_target + ((size_t)f * a.J + lane) * 2;
     const float r0 = kx - tp[0], r1 = ky - tp[1];
-    l = (r0 * r0 + r1 * r1) * mk;
-    gx = a.coef_rep * mk * r0 * a.fx / pz;
-    gy = a.coef_rep * mk * r1 * a.fy / pz;
-    gz = -(gx * px + gy * py) / pz;
+    l = (double)((r0 * r0 + r1 * r1) * mk);
+    const float jx = a.coef_rep * mk * r0 * a.fx / pz, jy = a.coef_rep * mk * r1 * a.fy / pz;
+    gx = (double)jx;
+    gy = (double)jy;
+    gz = (double)(-(jx * px + jy * py) / pz);
   }
   l = rpj_wave_sum(l); gx = rpj_wave_sum(gx); gy = rpj_wave_sum(gy); gz = rpj_wave_sum(gz);
   if (lane == 0) {
-    const float rgx = cs * gx + sn * gz, rgz = -sn * gx + cs * gz;  // Ry(yaw) G = (d inv_t / d b)^T G
-    a.grad[1 + 3 * f] = cbx + rgx;
-    a.grad[2 + 3 * f] = cby + gy;
-    a.grad[3 + 3 * f] = cbz + rgz;
-    float* pp = a.part + (size_t)f * RPJ_PW;
+    const double rgx = cs * gx + sn * gz, rgz = -sn * gx + cs * gz;  // Ry(yaw) G = (d inv_t / d b)^T G
+    a.grad[1 + 3 * f] = (float)(cbx + rgx);
+    a.grad[2 + 3 * f] = (float)(cby + gy);
+    a.grad[3 + 3 * f] = (float)(cbz + rgz);
+    double* pp = a.part + (size_t)f * RPJ_PW;
     pp[0] = l;
     pp[1] = cl;
     // d inv_t / d yaw = (d Ry(-yaw) / d yaw) (b - c) = (-sn ex - cs ez, 0, cs ex - sn ez)
-    pp[2] = cyaw + gx * (-sn * ex - cs * ez) + gz * (cs * ex - sn * ez);
-    pp[3] = 2.f * gx - rgx;  // the camera translation enters twice: p = joints0 + Ry(-yaw)(b - c) + c + c
+    pp[2] = cyaw + gx * (double)(-sn * ex - cs * ez) + gz * (double)(cs * ex - sn * ez);
+    pp[3] = 2.0 * gx - rgx;  // the camera translation enters twice: p = joints0 + Ry(-yaw)(b - c) + c + c
     pp[4] = gy;             // (2 G - Ry(yaw) G)_y
-    pp[5] = 2.f * gz - rgz;
+    pp[5] = 2.0 * gz - rgz;
   }
 }
 
 struct ReprojSumArgs {
   int F;
-  const float* part;
+  const double* part;
   float scale_rep, scale_ch;  // w_reprojection / (F J 2), w_chamfer / (F M)
   float* grad;
   float* loss;
@@ -248,9 +249,9 @@ __global__ __launch_bounds__(256) void k_reproj_sum(ReprojSumArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int f = tid; f < a.F; f += 256) {
-    const float* pp = a.part + (size_t)f * RPJ_PW;
+    const double* pp = a.part + (size_t)f * RPJ_PW;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] += (double)pp[k];
+    for (int k = 0; k < 6; ++k) acc[k] += pp[k];
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -284,7 +285,7 @@ extern "C" int uuo_reprojection_create(const uuo_reprojection_problem_t* p, uuo_
   UUO_REQUIRE((long long)p->F * p->V * 3 < 0x7FFFFFFFll, "uuo_reprojection_create: F * V too large");
   uuo_reprojection* h = new uuo_reprojection();
   h->p = *p;
-  const size_t part_bytes = ((size_t)p->F * RPJ_PW * sizeof(float) + 255) / 256 * 256;
+  const size_t part_bytes = ((size_t)p->F * RPJ_PW * sizeof(double) + 255) / 256 * 256;
   if (hipMalloc((void**)&h->part, part_bytes + (size_t)p->F * RPJ_S * p->M * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     uuo_set_error("uuo_reprojection_create: out of device memory");

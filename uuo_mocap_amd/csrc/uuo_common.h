@@ -337,7 +337,7 @@ int uuo_batched_launch_closure(int op, hipStream_t s, const void* d_args, int co
 // reprojection.hip: the handle of a 2D-prior fit and one evaluation of its fused closure
 struct uuo_reprojection {
   uuo_reprojection_problem_t p;
-  float* part = nullptr;               // [F][8] per-frame partial sums of an evaluation
+  double* part = nullptr;              // [F][8] per-frame partial sums of an evaluation
   unsigned long long* keys = nullptr;  // [F][4][M] the vertex slices' nearest-vertex keys (same allocation as `part`)
 };
 // one evaluation of the fused 2D-prior closure (uuo_reprojection_eval without the argument checks)
