@@ -57,6 +57,11 @@ def parse():
                     help="sequences fitted concurrently per GPU (parallel.fit_many): independent sequences overlap on one "
                          "device -- each on its own host thread, stream and workspaces -- which is how a dataset is run; "
                          "1 = one sequence at a time (latency of a single fit)")
+    ap.add_argument("--wait-sleep-us", type=float, default=-1.0,
+                    help="-1 (default): parallel.fit_many's own policy (sleeping waits while several sequences are in "
+                         "flight); 0: the solver's host threads always spin while they wait for the GPU's reports; > 0: they "
+                         "spin --wait-spin-us and then sleep this long at a time (parallel.set_wait_policy)")
+    ap.add_argument("--wait-spin-us", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the timing loops of the roofline section (one warm-up fit): the command profiled into "
@@ -210,6 +215,15 @@ def cpu_baseline(tables, seq, cfg, n_eval, n_cpu_evals, cpu_quota=None):
     }
 
 
+def cgroup_cpu_stat():
+    """cpu.stat of this process' cgroup (v2) as a dict of integers, {} where there is none."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            return {k: int(v) for k, v in (line.split() for line in fh if len(line.split()) == 2)}
+    except (OSError, ValueError):
+        return {}
+
+
 def measure_roofline(smpl, seq, dev, F, iters=200):
     from uuo_mocap_amd.config import packaged_config
     from uuo_mocap_amd.engine import ChamferProblem
@@ -294,6 +308,12 @@ def main():
 
     # torch's CPU pool follows the process' CPU quota, not the host's core count (parallel.limit_host_threads explains)
     host_threads = limit_host_threads()
+    from uuo_mocap_amd.parallel import set_wait_policy
+    fit_wait = "auto"  # parallel.fit_many: sleeping waits while several sequences are in flight, spinning otherwise
+    if args.wait_sleep_us >= 0:
+        fit_wait = "keep"
+        if args.wait_sleep_us > 0:
+            set_wait_policy(spin_us=args.wait_spin_us, sleep_us=args.wait_sleep_us)
     tables = synthetic_smpl(0)
     cfg = packaged_config(args.config)
     if args.hypothesis_lockstep:
@@ -338,13 +358,16 @@ def main():
             if cfg_init["stages"][k]["num_iters"] > 0:
                 cfg_init["stages"][k]["num_iters"] = 3
         fit_once(smpl, seqs[0], cfg_init, dev)
-        fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev)
+        fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev,
+                 wait_policy=fit_wait)
         barrier()
+        cg0 = cgroup_cpu_stat()
         t0 = time.perf_counter()
         fits = fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight,
-                        device=dev)
+                        device=dev, wait_policy=fit_wait)
         barrier()
         elapsed = time.perf_counter() - t0
+        cg1 = cgroup_cpu_stat()
     all_stats = [st for _, st in fits]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -399,6 +422,16 @@ def main():
             "stage_ms_last": {l: round(1e3 * (t - p_), 2) for (l, t), p_ in
                               zip(all_stats[-1]["timeline"], [0.0] + [t for _, t in all_stats[-1]["timeline"][:-1]])},
             "roofline": roofline,
+            # host side of the timed region (this process' cgroup): CPU seconds burnt by the polling / orchestrating threads
+            # and whether the CPU quota throttled them (parallel.limit_host_threads explains why that matters)
+            "host": {"cpu_quota": host_cpu_budget(), "torch_threads": host_threads,
+                     "wait_policy": ("sleep 20 us after 10 us of spinning while sequences are in flight (parallel.fit_many)"
+                                     if fit_wait == "auto" and args.inflight > 1 else
+                                     "spin" if args.wait_sleep_us <= 0 else "sleep %g us" % args.wait_sleep_us),
+                     "cpu_seconds_timed": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 if cg0 else None,
+                     "nr_throttled_timed": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 else None,
+                     "throttled_seconds_timed": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6
+                     if cg0 else None},
         }
         if world == 1 and args.config == "video_mocap" and not args.no_other_configs:
             # the other shipped configurations on sequences of the same size, beside the headline (not the metric's
@@ -429,11 +462,11 @@ def main():
                                             limb_only=limb_o) for i in range(args.inflight + n_fl)]
                     with contextlib.redirect_stdout(io.StringIO()):
                         fit_many(seqs_f[:args.inflight], lambda sq: fit_once(smpl, sq, cfg_o, dev), inflight=args.inflight,
-                                 device=dev)  # (the workspaces of the other workspace groups)
+                                 device=dev, wait_policy=fit_wait)  # (the workspaces of the other workspace groups)
                         torch.cuda.synchronize(dev)
                         t2 = time.perf_counter()
                         fit_many(seqs_f[args.inflight:], lambda sq: fit_once(smpl, sq, cfg_o, dev), inflight=args.inflight,
-                                 device=dev)
+                                 device=dev, wait_policy=fit_wait)
                         torch.cuda.synchronize(dev)
                         dt2 = time.perf_counter() - t2
                     flight = {"sequences_in_flight": args.inflight, "steps": n_fl, "value": n_fl * F / dt2,

@@ -255,6 +255,12 @@ int uuo_reprojection_solve(uuo_reprojection_t* h, void* stream, float* d_x, cons
                            uuo_lbfgs_stats_t* stats, float* d_x_last, float* d_kp_last, uuo_eval_callback_t cb,
                            void* cb_user);
 
+/* How the solver's host threads wait for the device's reports (one 192-byte block in pinned memory per closure evaluation).
+ * Default: they spin -- lowest latency, one CPU per solve in flight.  spin_polls >= 0: after that many polls a wait sleeps
+ * sleep_ns nanoseconds at a time (for hosts whose CPU quota is smaller than the number of solves in flight: a throttled
+ * cgroup stalls every thread of the process); spin_polls < 0 restores pure spinning.  Process-wide. */
+int uuo_set_wait_policy(int spin_polls, int sleep_ns);
+
 /* device -> device copy of `bytes` bytes ordered on `stream` (closures written in Python move the evaluated point and
  * the gradient between their own tensors and the driver's vectors with it) */
 int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes);

@@ -367,3 +367,14 @@ def test_reprojection_entry_points_refuse_bad_arguments():
     assert lib.uuo_reprojection_destroy(None) == 0
     assert lib.uuo_reprojection_eval(None, None, None, None, None, None, None) == -22
     assert lib.uuo_reprojection_solve(None, None, None, None, None, None, None, None, None) == -22
+
+
+def test_wait_policy_argument_checks():
+    """uuo_set_wait_policy: host-only state, no GPU needed."""
+    from uuo_mocap_amd import _lib
+
+    lib = _lib.load()
+    assert lib.uuo_set_wait_policy(250, 20000) == 0
+    assert lib.uuo_set_wait_policy(0, -1) == -22 and b"sleep_ns" in lib.uuo_last_error()
+    assert lib.uuo_set_wait_policy(0, 20000000) == -22
+    assert lib.uuo_set_wait_policy(-1, 0) == 0  # back to spinning

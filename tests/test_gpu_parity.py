@@ -690,6 +690,34 @@ def test_lbfgs_matches_torch_on_analytic_objectives(dev, kind, n, lr):
         np.testing.assert_allclose(got["x_final"], ref["x_final"], atol=3e-5)
 
 
+def test_wait_policy_changes_no_result(smpl, golden, dev):
+    """parallel.set_wait_policy (uuo_set_wait_policy): sleeping instead of spinning while a solve waits for the device's reports
+    is a property of the HOST threads only -- the chamfer stage solve of the golden inputs is bit-identical either way."""
+    from uuo_mocap_amd.optimization import LAST_STATS, optim_chamfer
+    from uuo_mocap_amd.parallel import set_wait_policy
+
+    g = golden("chamfer_stage.npz")
+    cfg = packaged_config("video_mocap")
+    cfg["stages"]["chamfer"]["num_iters"] = 30
+    runs = []
+    try:
+        for spin_us in (None, 0.0, 10.0):
+            set_wait_policy(spin_us=spin_us, sleep_us=20.0)
+            pose = _t(g["hmr_pose_body"], dev).requires_grad_(True)
+            betas = _t(g["o_betas"], dev).requires_grad_(True)
+            root = _t(g["hmr_root_orient"], dev).requires_grad_(True)
+            trans = _t(g["trans0"], dev).requires_grad_(True)
+            optim_chamfer(_t(g["markers"], dev), pose, _t(g["hmr_pose_body"], dev), betas, _t(g["o_betas"], dev), root, trans,
+                          None, None, smpl, cfg, verbose=False)
+            st = LAST_STATS["chamfer"]
+            runs.append((st["n_eval"], st["final_loss"], pose.detach().cpu().clone(), trans.detach().cpu().clone()))
+    finally:
+        set_wait_policy(spin_us=None)
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1]
+        assert torch.equal(r[2], runs[0][2]) and torch.equal(r[3], runs[0][3])
+
+
 def test_chamfer_stage_solve_tracks_reference(smpl, golden, dev):
     """optim_chamfer on the golden inputs: the first iterations follow the reference's recorded trajectory and the
     loss after the same number of iterations is at least as low (up to fp32 round-off)."""

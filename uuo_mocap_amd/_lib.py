@@ -96,6 +96,7 @@ _SIGNATURES = {
     "uuo_reprojection_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "uuo_reprojection_solve": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats),
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "uuo_set_wait_policy": (c_int, [c_int, c_int]),
     "uuo_copy_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "uuo_batch_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "uuo_batch_destroy": (c_int, [c_void_p]),

@@ -15,6 +15,41 @@
 
 #include "frame_math.h"
 
+// How a host thread waits for a report word in pinned memory (closure evaluations, Gram rows, lock-step rounds).  Default:
+// spin (pause) -- lowest latency, one CPU per waiting thread.  uuo_set_wait_policy(spin_polls, sleep_ns) makes every wait
+// sleep `sleep_ns` at a time once it has polled `spin_polls` times: for hosts whose CPU quota is smaller than the number
+// of solves in flight (a throttled cgroup stalls ALL threads of the process for the rest of the scheduler period).
+#include <sys/prctl.h>
+#include <atomic>
+static std::atomic<int> g_wait_spin_polls{-1};  // < 0: never sleep
+static std::atomic<int> g_wait_sleep_ns{20000};
+extern "C" int uuo_set_wait_policy(int spin_polls, int sleep_ns) {
+  UUO_REQUIRE(sleep_ns >= 0 && sleep_ns <= 10000000, "uuo_set_wait_policy: sleep_ns must be within [0, 10 ms]");
+  g_wait_sleep_ns.store(sleep_ns > 0 ? sleep_ns : 1, std::memory_order_relaxed);
+  g_wait_spin_polls.store(spin_polls, std::memory_order_relaxed);
+  return 0;
+}
+struct UuoWaiter {
+  unsigned long polls = 0, slow = 0;
+  // one relaxation step of a polling loop; true when it is time for the loop's slow checks (stream query, wall clock)
+  bool tick() {
+    const int sp = g_wait_spin_polls.load(std::memory_order_relaxed);
+    ++polls;
+    if (sp >= 0 && polls > (unsigned long)sp) {
+      static thread_local bool slack_set = false;
+      if (!slack_set) {  // the default timer slack (50 us) would round every short sleep up
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+        slack_set = true;
+      }
+      timespec ts{0, (long)g_wait_sleep_ns.load(std::memory_order_relaxed)};
+      nanosleep(&ts, nullptr);
+      return (++slow & 0xFFF) == 0;
+    }
+    __builtin_ia32_pause();
+    return (polls & 0xFFFFF) == 0;
+  }
+};
+
 #define LB_MAXH 104                 // history capacity (slots); history_size <= LB_MAXH - 4
 #define LB_ROWS (2 * LB_MAXH + 1)   // S slots, Y slots, g
 #define LB_MAXCHUNK 32              // element chunks of the history dot kernel (partials reduced unrolled)
@@ -1617,12 +1652,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
       // Bounded wait: the report word is polled; every ~1M polls the stream is queried (a failed or drained stream that
       // never reported is an error) and the wall clock is checked against eval_timeout_s -- a kernel that never finishes
       // must not pin this host thread for ever.
-      unsigned long spins = 0;
+      UuoWaiter waiter;
       timespec t_start;
       clock_gettime(CLOCK_MONOTONIC, &t_start);
       while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xFFFFF) == 0) {
+        if (waiter.tick()) {
           const hipError_t q = hipStreamQuery(s);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
             uuo_set_error(std::string("lbfgs: closure evaluation did not report: ") + hipGetErrorString(q));
@@ -1766,12 +1800,11 @@ static int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const u
           hipLaunchKernelGGL(k_lb_rows, dim3(1), dim3(512), 0, s, nchunks, cap, cand, w->part, w->st, w->h_rows, rseq);
           UUO_HIP_CHECK(hipGetLastError());
           unsigned long long* rw = reinterpret_cast<unsigned long long*>(w->h_rows + LB_ROWS * 3);
-          unsigned long spins = 0;
+          UuoWaiter waiter;
           timespec t_start;
           clock_gettime(CLOCK_MONOTONIC, &t_start);
           while (__atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0) {
+            if (waiter.tick()) {
               const hipError_t q = hipStreamQuery(s);
               timespec t_now;
               clock_gettime(CLOCK_MONOTONIC, &t_now);
@@ -2571,10 +2604,9 @@ extern "C" int uuo_batch_solve(uuo_batch_t* b, void* stream, const uuo_problem_t
       if (c.done || !c.waiting) continue;
       waited_any = true;
       unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(c.w->h_out);
-      unsigned long spins = 0;
+      UuoWaiter waiter;
       while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xFFFFF) == 0) {
+        if (waiter.tick()) {
           const hipError_t q = hipStreamQuery(gs[g]);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != c.w->seq) {
             uuo_set_error(std::string("batch: an evaluation did not report: ") + hipGetErrorString(q));
