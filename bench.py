@@ -241,9 +241,9 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
     skin_flops = SKIN_FLOPS_PER_FRAME * F
     achieved = skin_flops / (skin_ms * 1e-3) / 1e12
     # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r3_pmc_summary.json):
-    # FETCH_SIZE 15 315 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 409 KB, at F=300.
+    # FETCH_SIZE 15 080 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 413 KB, at F=300.
     # An OFFLINE figure (a PMC pass cannot run inside this process): null at any other size.
-    traffic = int((15314.6 * 2 + 30409.2) * 1024) if (F == 300) else None
+    traffic = int((15079.6 * 2 + 30412.6) * 1024) if (F == 300) else None
     mfma_useful = SKIN_MFMA_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12
     closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
