@@ -210,7 +210,7 @@ int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p,
                            uuo_eval_callback_t cb, void* cb_user);
 
 /* The same driver for a closure composed on the host (the reference's optional objectives: the 2D reprojection fit,
- * utils/hmr_utils.py:170-425 (step at :367); the chamfer / marker / part stages with velocity, ground, foot-contact,
+ * utils/hmr_utils.py:170-425 (step at :367) -- which also has a fused closure of its own, uuo_reprojection_* above; the chamfer / marker / part stages with velocity, ground, foot-contact,
  * per-part or reprojection terms, optimization.py:187-275,329-394, markers/markers_utils.py:454-562): replaces
  * torch.optim.LBFGS(params, ..., line_search_fn="strong_wolfe").step(closure) over the flat parameter vector d_x
  * (n floats, torch's order = the order of the params list).  `closure(user, stream, d_x_eval, d_loss, d_grad)` must

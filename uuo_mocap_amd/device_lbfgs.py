@@ -5,7 +5,8 @@ mirror of torch 2.10's L-BFGS (the one that drives the fused stage closures) -- 
 evaluation with the parameters set to the evaluated point.
 
 Used by the reference's optional objectives, whose terms are composed from the differentiable HIP operators rather than
-fused into one kernel: the 2D reprojection fit (reference utils/hmr_utils.py:170-425, step at :367), the chamfer / marker
+fused into one kernel: the 2D reprojection fit (reference utils/hmr_utils.py:170-425, step at :367; since round 3 only as
+the cross-check of its fused closure, reprojection.optim_reprojection(driver="operators")), the chamfer / marker
 stages with velocity, ground or per-part terms (optimization.py:187-275,329-394) and the part stage with reprojection /
 foot-contact / velocity terms (markers/markers_utils.py:454-562).  Same constructor arguments, same `step(closure)`
 contract (the closure zeroes the gradients, runs backward and returns the loss), same final state of the parameters."""
