@@ -68,12 +68,14 @@ def parse():
                          "profiles/r1_roofline_kernel_stats.csv")
     ap.add_argument("--cpu-evals", type=int, default=20, help="closure evaluations per stage type timed on the CPU")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the hmr_full / hmr_part / mht_rotation legs")
-    ap.add_argument("--mode", default="sequences", choices=["sequences", "hypotheses", "shared_betas"],
+    ap.add_argument("--mode", default="sequences", choices=["sequences", "hypotheses", "shared_betas", "frames"],
                     help="how N ranks share the work (SURVEY.md 8e): sequences = independent sequences per rank, no data-path "
                          "collective (default; weak scaling); hypotheses = every step is ONE sequence whose yaw hypotheses "
                          "are spread over the ranks (strong scaling, useful up to num_root_orient_angles ranks); "
                          "shared_betas = one sequence per rank, one shape vector for all of them (extension: joint L-BFGS, "
-                         "one small all_gather per evaluation)")
+                         "one small all_gather per evaluation); frames = every step is ONE sequence whose chamfer / marker solves "
+                         "are spread over the ranks by frame blocks (SURVEY 8e.3: the joint problem of shared_betas with global "
+                         "normalisers; strong scaling)")
     ap.add_argument("--hypothesis-lockstep", action="store_true",
                     help="step the yaw hypotheses as one lock-step batch instead of one host thread + stream each "
                          "(multimodal_video_mocap(execution={'hypothesis_lockstep': True}); same results)")
@@ -94,6 +96,8 @@ def fit_once(smpl, seq, cfg, dev):
         ctx = parallel.shard_hypotheses()
     elif MODE == "shared_betas":
         ctx = parallel.shared_betas(device=dev)
+    elif MODE == "frames":
+        ctx = parallel.shard_frames(device=dev)
     with ctx:
         out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
                                      save_stages=False, smpl_inference=smpl)
@@ -324,7 +328,7 @@ def main():
     limb = args.config == "hmr_part"
     # distinct seeds for every warm-up and timed sequence of every rank (the solves stop on tolerances, so time depends on
     # the data: a timed step must not repeat a warm-up step)
-    seed_base = 0 if MODE == "hypotheses" else rank * n_seq   # hypotheses mode: all ranks work on the SAME sequences
+    seed_base = 0 if MODE in ("hypotheses", "frames") else rank * n_seq   # these modes: all ranks work on the SAME sequences
     # shared_betas mode: step i of every rank is a different sequence of ONE subject (same ground-truth shape)
     seqs = [make_sequence(tables, seed=seed_base + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb,
                           subject_seed=(5000 + i) if MODE == "shared_betas" else None)
@@ -388,7 +392,7 @@ def main():
     if rank == 0:
         n_eval = eval_counts(all_stats[-1])
         total_evals = sum(sum(eval_counts(s).values()) for s in all_stats)
-        frames = (1 if MODE == "hypotheses" else world) * args.steps * F
+        frames = (1 if MODE in ("hypotheses", "frames") else world) * args.steps * F
         value = frames / elapsed
         roofline = measure_roofline(smpl, seqs[-1], dev, F)
         # whole-fit arithmetic rate: SURVEY 8d's algorithmic FLOPs of every closure evaluation the timed fits executed
@@ -407,7 +411,7 @@ def main():
             "metric": "mocap frames/sec fitted (300-frame seq, 50 markers)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if MODE == "hypotheses" else "weak",
+            "scaling": "strong" if MODE in ("hypotheses", "frames") else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.yaml full fit, F=%d frames x M=%d markers, synthetic SMPL-shaped model, one "
                                    "sequence per step per GPU" % (args.config, F, M if not limb else 10),

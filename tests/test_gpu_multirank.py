@@ -43,6 +43,10 @@ def _fit(smpl, seq, cfg, dev):
     res = {k: np.asarray(out[k]) for k in ("trans", "pose_body", "betas", "root_orient")}
     res["yaw_scores"] = np.asarray(last_run_stats()["yaw_scores"])
     res["n_chamfer"] = len(last_run_stats()["chamfer"])
+    for key in ("chamfer", "marker", "marker_final"):
+        res[key + "_first"] = [float(s_["first_loss"]) for s_ in last_run_stats().get(key, [])]
+        res[key + "_final"] = [float(s_["final_loss"]) for s_ in last_run_stats().get(key, [])]
+        res[key + "_driver"] = [str(s_.get("driver", "")) for s_ in last_run_stats().get(key, [])]
     return res
 
 
@@ -92,6 +96,10 @@ def _rank_main(rank, world, port, out_dir):
             out["joint"] = {"device": sa, "checker": sb, "losses": losses, "betas_device": xa[4 * F:4 * F + 10].cpu().numpy(),
                             "betas_checker": xb[4 * F:4 * F + 10].cpu().numpy(),
                             "x_diff": float((xa - xb).abs().max()), "start_betas": x0[4 * F:4 * F + 10].cpu().numpy()}
+        # (5) frame blocks per rank (8e.3): ONE sequence, every chamfer / marker solve is a joint problem over the ranks' blocks
+        with parallel.shard_frames(device=dev) as fs:
+            out["frames"] = _fit(smpl, seqs[0], cfg, dev)
+            out["frames_block"] = fs.block(F)
         torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
     except BaseException:
         import traceback
@@ -164,6 +172,23 @@ def test_two_ranks_sequences_hypotheses_and_shared_betas(tmp_path):
         assert abs(d_["n_iter"] - c_["n_iter"]) <= 1 and abs(d_["n_eval"] - c_["n_eval"]) <= 3
         assert np.abs(j["betas_device"] - j["betas_checker"]).max() < 2e-2
     assert j0["device"]["final_loss"] < 0.7 * j0["device"]["first_loss"]
+
+    # (5) frame blocks per rank: both ranks hold the whole result, identical; every solve ran as a joint problem whose FIRST
+    # evaluation is the one-process objective (global normalisers; only the summation order differs); after 25 iterations the
+    # fit is where the one-process fit is, up to the drift of two fp32 trajectories
+    assert res[0]["frames_block"] == (0, F // 2) and res[1]["frames_block"] == (F // 2, F)
+    for k in ("trans", "pose_body", "betas", "root_orient", "yaw_scores"):
+        assert np.array_equal(res[0]["frames"][k], res[1]["frames"][k]), k
+    fr = res[0]["frames"]
+    assert all("frame blocks, world=2" in d for d in fr["chamfer_driver"] + fr["marker_driver"] + fr["marker_final_driver"])
+    np.testing.assert_allclose(fr["chamfer_first"], alone[0]["chamfer_first"], rtol=2e-5)
+    # (the marker stages start from the chamfer stages' results, which have drifted apart by then: compared loosely)
+    np.testing.assert_allclose(fr["chamfer_final"], alone[0]["chamfer_final"], rtol=0.15)
+    np.testing.assert_allclose(fr["marker_final_final"], alone[0]["marker_final_final"], rtol=0.5)
+    print("OBS frame blocks: chamfer first", fr["chamfer_first"], "vs", alone[0]["chamfer_first"], "final", fr["chamfer_final"],
+          "vs", alone[0]["chamfer_final"], "| final marker", fr["marker_final_final"], "vs", alone[0]["marker_final_final"],
+          "| median |dtrans| %.3g" % np.median(np.abs(fr["trans"] - alone[0]["trans"])))
+    assert np.median(np.abs(fr["trans"] - alone[0]["trans"])) < 2e-2
 
 
 @pytest.mark.parametrize("stage", ["chamfer", "marker"])

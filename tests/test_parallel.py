@@ -92,3 +92,53 @@ def test_hypothesis_shard_exchange_two_gloo_ranks(tmp_path):
     for r in range(2):
         assert [h["angle"] for h in res[r]["all"]] == [0, 1, 2, 3]
         assert [h["by"] for h in res[r]["all"]] == [0, 1, 0, 1]
+
+
+def _frames_rank(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from uuo_mocap_amd import parallel
+
+        with parallel.shard_frames() as fs:
+            F = 7
+            lo, hi = fs.block(F)
+            full = torch.arange(F * 2 * 3, dtype=torch.float32).reshape(F, 2, 3) * 0.25 + 1e-3
+            got = fs.gather_frames(full[lo:hi].clone(), F)
+            flat = fs.gather_frames(full[lo:hi, 0, 0].clone(), F)
+            torch.save({"bounds": fs.bounds(F), "block": (lo, hi), "equal": bool(torch.equal(got, full)),
+                        "flat_equal": bool(torch.equal(flat, full[:, 0, 0])), "inside": parallel.frame_shard() is fs},
+                       os.path.join(out_dir, "rank%d.pt" % rank))
+        assert parallel.frame_shard() is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_shard_blocks_and_exchange_two_gloo_ranks(tmp_path):
+    """contiguous frame blocks (sizes differ by at most one), and the exchange that gives every rank the full
+    per-frame tensors again -- bit for bit."""
+    from uuo_mocap_amd.dist_lbfgs import LocalReducer
+    from uuo_mocap_amd.parallel import FrameShard
+
+    class _R:  # a reducer's (rank, world) is all `bounds` needs
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+
+    for F in (1, 7, 8, 300):
+        for world in (1, 2, 3, 8):
+            if F < world:
+                continue
+            e = FrameShard(_R(0, world)).bounds(F)
+            sizes = [e[r + 1] - e[r] for r in range(world)]
+            assert e[0] == 0 and e[-1] == F and max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    one = FrameShard(LocalReducer())
+    t = torch.randn(5, 3)
+    assert torch.equal(one.gather_frames(t, 5), t) and one.block(5) == (0, 5)
+
+    port = 29500 + (os.getpid() % 2000) + 2
+    mp.spawn(_frames_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    assert res[0]["bounds"] == [0, 4, 7] and res[0]["block"] == (0, 4) and res[1]["block"] == (4, 7)
+    for r in range(2):
+        assert res[r]["equal"] and res[r]["flat_equal"] and res[r]["inside"]

@@ -475,9 +475,14 @@ def multimodal_video_mocap(
         # the reference's hypotheses run one after the other and each placement reads the labels the previous one
         # recomputed (only the "part" granularity looks at them): keep that order
         n_threads = 1
-    from .parallel import hypothesis_shard, shared_betas_reducer
+    from .parallel import frame_shard, hypothesis_shard, shared_betas_reducer
 
     hyp_shard = hypothesis_shard()
+    if frame_shard() is not None and frame_shard().world > 1:
+        # frame blocks across ranks: every solve is a collective, so all ranks issue them in one order
+        lockstep, n_threads = False, 1
+        if hyp_shard is not None or shared_betas_reducer() is not None:
+            raise NotImplementedError("frame sharding, hypothesis sharding and shared betas are different uses of the ranks")
     if shared_betas_reducer() is not None:
         # shared betas across ranks (extension): every solve is a collective, so all ranks must issue them in one order
         lockstep, n_threads = False, 1

@@ -62,6 +62,12 @@ def optim_chamfer(
     if (set(st["losses"]) - _CHAMFER_FUSED_LOSSES) or not st["yaw_lock"]:
         return _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, marker_labels,
                                       smpl_inference, config, initial_angle, repeat, verbose, iter_fn)
+    from .parallel import frame_shard
+
+    fs = frame_shard()
+    if fs is not None and fs.world > 1:
+        return _optim_chamfer_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
+                                            smpl_inference, config, iter_fn)
     prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, root_orient, config)
     z_angle = torch.zeros((root_orient.shape[0], root_orient.shape[1], 1), device=root_orient.device)
     x = prob.pack(trans, z_angle, betas, pose_body)
@@ -86,6 +92,71 @@ def optim_chamfer(
     root_orient.requires_grad_(True)
     LAST_STATS["chamfer"] = stats
     _tls_stats.chamfer = stats
+    return None
+
+
+def _frame_sharded_solve(fs, prob, x, config, stage: str, lr: float, frames_here: int, frames_all: int, data_share: float):
+    """One stage problem on this rank's frame block as a member of the joint problem over `fs`'s ranks.  The
+    weights of the block carry the GLOBAL normalisers: the data term's share of the global denominator (`data_share`), the
+    pose prior's F_r / F, the shape prior once in total."""
+    opt = config["optimizer"]
+    if str(opt.get("type", "lbfgs")).lower() != "lbfgs":
+        raise NotImplementedError("frame sharding: L-BFGS driver only")
+    prob.problem.w_data = float(prob.problem.w_data) * float(data_share)
+    prob.problem.w_pose = float(prob.problem.w_pose) * float(frames_here) / float(frames_all)
+    prob.problem.w_betas = float(prob.problem.w_betas) / float(fs.world)
+    stats = prob.solve_shared(x, fs.reducer, max_iter=config["stages"][stage]["num_iters"], lr=lr,
+                              tolerance_grad=opt["tolerance_grad"], tolerance_change=opt["tolerance_change"])
+    stats["driver"] = "device-lbfgs(frame blocks, world=%d)" % fs.world
+    return stats
+
+
+def _optim_chamfer_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, smpl_inference,
+                                 config, iter_fn):
+    """optim_chamfer's fused solve spread over ranks by frame blocks (parallel.shard_frames); same in-place contract, every
+    rank ends with the full result."""
+    if iter_fn is not None:
+        raise NotImplementedError("frame sharding: no per-evaluation iter_fn")
+    F = int(markers.shape[0])
+    lo, hi = fs.block(F)
+    prob = ChamferProblem(smpl_inference, markers[lo:hi], o_pose_body[lo:hi], o_betas, root_orient[lo:hi], config)
+    mask = get_marker_mask(markers)                      # full_chamfer is normalised by the number of present markers
+    share = float(mask[lo:hi].sum().item()) / float(mask.sum().item())
+    z_angle = torch.zeros((hi - lo, root_orient.shape[1], 1), device=root_orient.device)
+    x = prob.pack(trans[lo:hi], z_angle, betas, pose_body[lo:hi])
+    stats = _frame_sharded_solve(fs, prob, x, config, "chamfer", 0.1, hi - lo, F, share)
+    new_trans, new_z, new_betas, new_pose = prob.unpack(x)
+    with torch.no_grad():
+        trans.copy_(fs.gather_frames(new_trans, F))
+        betas.copy_(new_betas)
+        pose_body.copy_(fs.gather_frames(new_pose, F))
+        root_orient.requires_grad_(False)
+        root_orient[:] = compute_root_orient_z(fs.gather_frames(new_z, F)) @ root_orient
+    root_orient.requires_grad_(True)
+    LAST_STATS["chamfer"] = stats
+    _tls_stats.chamfer = stats
+    return None
+
+
+def _optim_markers_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, assign,
+                                 smpl_inference, config, iter_fn):
+    """optim_markers' fused solve (one-hot placement) spread over ranks by frame blocks; same in-place contract."""
+    if iter_fn is not None:
+        raise NotImplementedError("frame sharding: no per-evaluation iter_fn")
+    F = int(markers.shape[0])
+    lo, hi = fs.block(F)
+    prob = MarkerProblem(smpl_inference, markers[lo:hi], o_pose_body[lo:hi], o_betas, assign, config)
+    x = prob.pack(pose_body[lo:hi], betas, root_orient[lo:hi], trans[lo:hi])
+    # the marker term is a mean over all F x M entries: the block's share of the denominator is F_r / F
+    stats = _frame_sharded_solve(fs, prob, x, config, "marker", 1.0, hi - lo, F, float(hi - lo) / float(F))
+    new_pose, new_betas, new_root, new_trans = prob.unpack(x)
+    with torch.no_grad():
+        pose_body.copy_(fs.gather_frames(new_pose, F))
+        betas.copy_(new_betas)
+        root_orient.copy_(fs.gather_frames(new_root, F))
+        trans.copy_(fs.gather_frames(new_trans, F))
+    LAST_STATS["marker"] = stats
+    _tls_stats.marker = stats
     return None
 
 
@@ -297,6 +368,12 @@ def optim_markers(
         return _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
                                       smpl_inference, config, verbose, iter_fn, initial_angle, repeat)
     assign = torch.argmax(one_hot, dim=-1)
+    from .parallel import frame_shard
+
+    fs = frame_shard()
+    if fs is not None and fs.world > 1:
+        return _optim_markers_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, assign,
+                                            smpl_inference, config, iter_fn)
     prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config)
     x = prob.pack(pose_body, betas, root_orient, trans)
     point_cb = None

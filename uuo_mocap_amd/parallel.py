@@ -261,3 +261,70 @@ def shard_hypotheses(group=None, shard: HypothesisShard = None):
         yield _ctx.hyp
     finally:
         _ctx.hyp = prev
+
+
+class FrameShard:
+    """ONE solve spread over the ranks by contiguous blocks of frames.  Every stage problem is separable over
+    frames except for the shape vector, so rank r solves the frames of its block with their own per-frame parameters, the 10
+    betas are the shared tail of the joint problem (engine.solve_shared -> uuo_lbfgs_solve_shared: one all_gather of 16
+    doubles per closure evaluation, one of 627 per iteration) and the per-rank loss weights carry the GLOBAL normalisers, so the
+    joint objective is the one-GPU objective term by term (the fp32 summation order differs: converged quantities agree,
+    trajectories need not).  After a solve the per-frame results of all blocks are exchanged and every rank holds the full
+    tensors, so everything around the solves (segmentation, candidate search, placement, scoring) runs replicated and
+    unchanged."""
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+        self.rank, self.world = int(reducer.rank), int(reducer.world)
+
+    def bounds(self, num_frames: int) -> List[int]:
+        base, rem = divmod(int(num_frames), self.world)
+        edges = [0]
+        for r in range(self.world):
+            edges.append(edges[-1] + base + (1 if r < rem else 0))
+        return edges
+
+    def block(self, num_frames: int):
+        e = self.bounds(num_frames)
+        if e[self.rank + 1] == e[self.rank]:
+            raise ValueError("frame sharding: %d frames leave rank %d of %d without any" % (num_frames, self.rank, self.world))
+        return e[self.rank], e[self.rank + 1]
+
+    def gather_frames(self, local: torch.Tensor, num_frames: int) -> torch.Tensor:
+        """[F_r, ...] blocks of all ranks -> [F, ...] on the caller's device, identical on every rank."""
+        import numpy as np
+
+        e = self.bounds(num_frames)
+        per = int(np.prod(local.shape[1:])) if local.dim() > 1 else 1
+        longest = max(e[r + 1] - e[r] for r in range(self.world))
+        mine = np.zeros(longest * per, dtype=np.float64)
+        mine[:local.numel()] = local.detach().reshape(-1).double().cpu().numpy()
+        table = np.zeros((self.world, longest * per), dtype=np.float64)
+        self.reducer.gather_array(mine, table)
+        parts = [torch.from_numpy(table[r, :(e[r + 1] - e[r]) * per].copy()).to(device=local.device, dtype=local.dtype)
+                 .reshape((e[r + 1] - e[r],) + tuple(local.shape[1:])) for r in range(self.world)]
+        return torch.cat(parts, dim=0)
+
+
+def frame_shard():
+    """The FrameShard of the active `shard_frames(...)` context of this thread, or None."""
+    return getattr(_ctx, "frames", None)
+
+
+@contextlib.contextmanager
+def shard_frames(group=None, device=None, reducer=None):
+    """Inside this context the chamfer and marker stage solves of a fit (optim_chamfer / optim_markers on their fused
+    closures) are spread over the ranks of `group` by frame blocks (FrameShard): one sequence uses all the
+    GPUs of the group.  All ranks must call the fit with the same inputs; every rank returns the full, identical result.  The
+    yaw hypotheses run one after the other (every solve is a collective).  Without an initialised process group the context
+    is the one-rank case."""
+    from .dist_lbfgs import DistReducer, LocalReducer
+
+    if reducer is None:
+        reducer = DistReducer(group, device) if _dist() is not None else LocalReducer()
+    prev = getattr(_ctx, "frames", None)
+    _ctx.frames = FrameShard(reducer)
+    try:
+        yield _ctx.frames
+    finally:
+        _ctx.frames = prev
