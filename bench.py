@@ -76,6 +76,10 @@ def parse():
                          "one small all_gather per evaluation); frames = every step is ONE sequence whose chamfer / marker solves "
                          "are spread over the ranks by frame blocks (SURVEY 8e.3: the joint problem of shared_betas with global "
                          "normalisers; strong scaling)")
+    ap.add_argument("--collective-lanes", type=int, default=4,
+                    help="modes shared_betas / frames: process groups (gloo) for the yaw hypotheses, so that the hypotheses of a "
+                         "fit run concurrently although every solve is a collective (one lane per hypothesis index); 0 = one "
+                         "hypothesis after the other on the default group")
     ap.add_argument("--hypothesis-lockstep", action="store_true",
                     help="step the yaw hypotheses as one lock-step batch instead of one host thread + stream each "
                          "(multimodal_video_mocap(execution={'hypothesis_lockstep': True}); same results)")
@@ -83,6 +87,7 @@ def parse():
 
 
 MODE = "sequences"
+LANES = 0
 
 
 def fit_once(smpl, seq, cfg, dev):
@@ -95,9 +100,9 @@ def fit_once(smpl, seq, cfg, dev):
     if MODE == "hypotheses":
         ctx = parallel.shard_hypotheses()
     elif MODE == "shared_betas":
-        ctx = parallel.shared_betas(device=dev)
+        ctx = parallel.shared_betas(device=dev, lanes=LANES)
     elif MODE == "frames":
-        ctx = parallel.shard_frames(device=dev)
+        ctx = parallel.shard_frames(device=dev, lanes=LANES)
     with ctx:
         out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
                                      save_stages=False, smpl_inference=smpl)
@@ -279,9 +284,10 @@ def packaged_cfg_full():
 
 
 def main():
-    global MODE
+    global MODE, LANES
     args = parse()
     MODE = args.mode
+    LANES = args.collective_lanes
     if MODE != "sequences":
         args.inflight = 1  # both modes issue collectives from the fitting thread: one sequence at a time per rank
     world = int(os.environ.get("WORLD_SIZE", "1"))

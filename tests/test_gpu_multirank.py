@@ -100,6 +100,12 @@ def _rank_main(rank, world, port, out_dir):
         with parallel.shard_frames(device=dev) as fs:
             out["frames"] = _fit(smpl, seqs[0], cfg, dev)
             out["frames_block"] = fs.block(F)
+        # (6) the same two collective modes with one process group (lane) per yaw hypothesis: the hypotheses run concurrently
+        # on their threads, every lane ordered by its own thread -- the same solves, so the same results bit for bit
+        with parallel.shard_frames(device=dev, lanes=4):
+            out["frames_lanes"] = _fit(smpl, seqs[0], cfg, dev)
+        with parallel.shared_betas(device=dev, lanes=4):
+            out["shared_lanes"] = _fit(smpl, same_subject[rank], cfg, dev)
         torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
     except BaseException:
         import traceback
@@ -189,6 +195,13 @@ def test_two_ranks_sequences_hypotheses_and_shared_betas(tmp_path):
           "vs", alone[0]["chamfer_final"], "| final marker", fr["marker_final_final"], "vs", alone[0]["marker_final_final"],
           "| median |dtrans| %.3g" % np.median(np.abs(fr["trans"] - alone[0]["trans"])))
     assert np.median(np.abs(fr["trans"] - alone[0]["trans"])) < 2e-2
+
+
+    # (6) lanes: concurrent hypotheses give the serial results
+    for r in range(world):
+        for k in ("trans", "pose_body", "betas", "root_orient", "yaw_scores"):
+            assert np.array_equal(res[r]["frames_lanes"][k], res[r]["frames"][k]), ("frames", r, k)
+            assert np.array_equal(res[r]["shared_lanes"][k], res[r]["shared"][k]), ("shared", r, k)
 
 
 @pytest.mark.parametrize("stage", ["chamfer", "marker"])

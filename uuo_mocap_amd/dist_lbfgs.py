@@ -48,6 +48,9 @@ class LocalReducer:
     def gather_array(self, mine: np.ndarray, out: np.ndarray) -> None:
         out[0, :] = mine
 
+    def fork(self, n: int):
+        return [self] * int(n)
+
 
 class DistReducer:
     """Partials of every rank through ONE all_gather on a torch.distributed process group ("nccl" = RCCL on ROCm, "gloo" in
@@ -63,6 +66,20 @@ class DistReducer:
         self.device = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
 
         self._bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._lanes: list = []
+
+    def fork(self, n: int):
+        """`n` reducers over the same ranks, each on a process group of its own, so that `n` host threads (the yaw hypotheses
+        of one fit) can run their collectives concurrently: a group's collectives are ordered by ONE thread on every rank.
+        COLLECTIVE on first use (every rank of the group must call it, with the same n).  The lanes use gloo whatever the
+        default backend is: what crosses the ranks is 128-byte .. 5-KB blocks of doubles that already sit in host memory
+        (the solver's pinned report words), and several communicators driven from several threads are the one thing an
+        RCCL process should not do."""
+        while len(self._lanes) < int(n):
+            ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else \
+                list(range(self.dist.get_world_size()))
+            self._lanes.append(DistReducer(self.dist.new_group(ranks=ranks, backend="gloo"), torch.device("cpu")))
+        return self._lanes[:int(n)]
 
     def gather(self, values: Sequence[float]) -> np.ndarray:
         local = torch.tensor(list(values), dtype=torch.float64, device=self.device)

@@ -475,19 +475,25 @@ def multimodal_video_mocap(
         # the reference's hypotheses run one after the other and each placement reads the labels the previous one
         # recomputed (only the "part" granularity looks at them): keep that order
         n_threads = 1
-    from .parallel import frame_shard, hypothesis_shard, shared_betas_reducer
+    from .parallel import collective_lanes, frame_shard, hypothesis_shard, shared_betas_reducer
 
     hyp_shard = hypothesis_shard()
-    if frame_shard() is not None and frame_shard().world > 1:
-        # frame blocks across ranks: every solve is a collective, so all ranks issue them in one order
-        lockstep, n_threads = False, 1
-        if hyp_shard is not None or shared_betas_reducer() is not None:
+    lanes = None
+    if (frame_shard() is not None and frame_shard().world > 1) or shared_betas_reducer() is not None:
+        # frame blocks across ranks / shared betas (extension): every solve is a collective, so all ranks must
+        # issue them in one order -- one hypothesis after the other, or every hypothesis on a lane (process group) of its own
+        if hyp_shard is not None or (frame_shard() is not None and shared_betas_reducer() is not None):
             raise NotImplementedError("frame sharding, hypothesis sharding and shared betas are different uses of the ranks")
-    if shared_betas_reducer() is not None:
-        # shared betas across ranks (extension): every solve is a collective, so all ranks must issue them in one order
-        lockstep, n_threads = False, 1
-        if hyp_shard is not None:
-            raise NotImplementedError("shared betas and hypothesis sharding are two different uses of the ranks")
+        lockstep = False
+        lanes = collective_lanes(len(root_orient_angles))
+        if lanes is None or n_threads < len(root_orient_angles) or device.type != "cuda":
+            lanes, n_threads = None, 1
+    if lanes is not None:
+        _fit_plain = fit_hypothesis
+
+        def fit_hypothesis(index, root_orient_angle, stream, marker_labels=marker_labels):  # noqa: F811
+            with lanes[index]():
+                return _fit_plain(index, root_orient_angle, stream, marker_labels)
     if hyp_shard is not None and hyp_shard.world > 1:
         # this rank fits hypotheses rank, rank + world, ...; one all_gather_object brings every rank all results
         if recompute_labels:

@@ -195,24 +195,67 @@ def shared_betas_reducer():
     return getattr(_ctx, "shared", None)
 
 
+_reducer_cache: Dict = {}
+
+
+def _default_reducer(group, device):
+    """One DistReducer per (group, device) and process: its lanes are process groups, which are not to be created per fit."""
+    from .dist_lbfgs import DistReducer, LocalReducer
+
+    if _dist() is None:
+        return LocalReducer()
+    key = (id(group) if group is not None else 0, str(device))
+    if key not in _reducer_cache:
+        _reducer_cache[key] = DistReducer(group, device)
+    return _reducer_cache[key]
+
+
+def collective_lanes(count: int):
+    """For multimodal_video_mocap: how the `count` yaw hypotheses of a fit may run CONCURRENTLY inside a `shared_betas` /
+    `shard_frames` context -- a list of `count` context managers (one per hypothesis index, to be entered on the thread that
+    fits it), or None when the context was opened without lanes (then the hypotheses run one after the other)."""
+    lanes = getattr(_ctx, "lanes", None)
+    if not lanes or len(lanes) < count:
+        return None
+    kind = getattr(_ctx, "lanes_kind", None)
+
+    def enter(i):
+        @contextlib.contextmanager
+        def cm():
+            prev_s, prev_f = getattr(_ctx, "shared", None), getattr(_ctx, "frames", None)
+            if kind == "shared":
+                _ctx.shared = lanes[i]
+            else:
+                _ctx.frames = FrameShard(lanes[i])
+            try:
+                yield
+            finally:
+                _ctx.shared, _ctx.frames = prev_s, prev_f
+        return cm()
+
+    return [lambda i=i: enter(i) for i in range(count)]
+
+
 @contextlib.contextmanager
-def shared_betas(group=None, device=None, reducer=None):
+def shared_betas(group=None, device=None, reducer=None, lanes: int = 0):
     """EXTENSION (BASELINE configs[3]; not reference behaviour -- the reference fits every sequence with its own betas,
     SURVEY.md F12): inside this context every chamfer / marker stage solve is ONE joint L-BFGS problem over the ranks of
     `group`, the sequences of the ranks (same subject) sharing a single shape vector.  All ranks must run the same stages in
     the same order (they do: the iteration counts follow from all-reduced scalars only); the yaw hypotheses therefore run
-    one after the other instead of on concurrent threads.  Without an initialised process group the context is the
-    one-rank case of the same driver."""
-    from .dist_lbfgs import DistReducer, LocalReducer
-
+    one after the other instead of on concurrent threads -- unless `lanes` >= their number: then every hypothesis index gets
+    a process group of its own (DistReducer.fork; created once per process, COLLECTIVELY at the first entry) and the
+    hypotheses run on their threads as usual, each ordering only its own lane.  Without an initialised process group the
+    context is the one-rank case of the same driver."""
     if reducer is None:
-        reducer = DistReducer(group, device) if _dist() is not None else LocalReducer()
-    prev = getattr(_ctx, "shared", None)
+        reducer = _default_reducer(group, device)
+    prev = getattr(_ctx, "shared", None), getattr(_ctx, "lanes", None), getattr(_ctx, "lanes_kind", None)
     _ctx.shared = reducer
+    _ctx.lanes = reducer.fork(lanes) if lanes > 0 else None
+    _ctx.lanes_kind = "shared"
     try:
         yield reducer
     finally:
-        _ctx.shared = prev
+        _ctx.shared, _ctx.lanes, _ctx.lanes_kind = prev
 
 
 class HypothesisShard:
@@ -312,19 +355,19 @@ def frame_shard():
 
 
 @contextlib.contextmanager
-def shard_frames(group=None, device=None, reducer=None):
+def shard_frames(group=None, device=None, reducer=None, lanes: int = 0):
     """Inside this context the chamfer and marker stage solves of a fit (optim_chamfer / optim_markers on their fused
     closures) are spread over the ranks of `group` by frame blocks (FrameShard): one sequence uses all the
     GPUs of the group.  All ranks must call the fit with the same inputs; every rank returns the full, identical result.  The
-    yaw hypotheses run one after the other (every solve is a collective).  Without an initialised process group the context
-    is the one-rank case."""
-    from .dist_lbfgs import DistReducer, LocalReducer
-
+    yaw hypotheses run one after the other (every solve is a collective) unless `lanes` >= their number (see
+    shared_betas).  Without an initialised process group the context is the one-rank case."""
     if reducer is None:
-        reducer = DistReducer(group, device) if _dist() is not None else LocalReducer()
-    prev = getattr(_ctx, "frames", None)
+        reducer = _default_reducer(group, device)
+    prev = getattr(_ctx, "frames", None), getattr(_ctx, "lanes", None), getattr(_ctx, "lanes_kind", None)
     _ctx.frames = FrameShard(reducer)
+    _ctx.lanes = reducer.fork(lanes) if lanes > 0 else None
+    _ctx.lanes_kind = "frames"
     try:
         yield _ctx.frames
     finally:
-        _ctx.frames = prev
+        _ctx.frames, _ctx.lanes, _ctx.lanes_kind = prev
