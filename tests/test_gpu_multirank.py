@@ -106,6 +106,30 @@ def _rank_main(rank, world, port, out_dir):
             out["frames_lanes"] = _fit(smpl, seqs[0], cfg, dev)
         with parallel.shared_betas(device=dev, lanes=4):
             out["shared_lanes"] = _fit(smpl, same_subject[rank], cfg, dev)
+        # (7) the batch runner with all ranks on every sequence (--rank_mode frames): rank 0 writes, both take part
+        from uuo_mocap_amd import runner
+        from uuo_mocap_amd.config import CONFIG_DIR
+
+        root = os.path.join(out_dir, "data")
+        d = os.path.join(root, "moyo_val", "mocap", "subj")
+        if rank == 0:
+            os.makedirs(d, exist_ok=True)
+            runner.write_sequence_npz(os.path.join(d, "seq0.npz"), seqs[1].markers.get_points(), 30.0,
+                                      seqs[1].img_smpl.pose_body, seqs[1].img_smpl.root_orient, seqs[1].img_smpl.betas)
+            with open(os.path.join(out_dir, "cfg.yaml"), "w") as fh:
+                fh.write("parent: %s\nname: unit\nstages:\n  part:\n    num_iters: 6\n  chamfer:\n    num_iters: 6\n"
+                         "  marker:\n    num_iters: 6\n" % os.path.join(CONFIG_DIR, "video_mocap.yaml"))
+        dist.barrier()
+        args = runner.build_parser().parse_args(["--config", os.path.join(out_dir, "cfg.yaml"), "--dataset", "moyo_val",
+                                                 "--input_dir", root, "--gpu", "0", "--rank_mode", "frames",
+                                                 "--print_options"])
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            out["runner_written"] = runner.run(args)
+        dist.barrier()
+        out["runner_file"] = os.path.isfile(os.path.join(root, "moyo_val", "results", "unit", "subj", "seq0_stageii.npz"))
         torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
     except BaseException:
         import traceback
@@ -196,6 +220,10 @@ def test_two_ranks_sequences_hypotheses_and_shared_betas(tmp_path):
           "| median |dtrans| %.3g" % np.median(np.abs(fr["trans"] - alone[0]["trans"])))
     assert np.median(np.abs(fr["trans"] - alone[0]["trans"])) < 2e-2
 
+
+    # (7) the runner: one output file, written by rank 0, both ranks went through the fit
+    assert res[0]["runner_written"] == 1 and res[1]["runner_written"] == 0
+    assert res[0]["runner_file"] and res[1]["runner_file"]
 
     # (6) lanes: concurrent hypotheses give the serial results
     for r in range(world):

@@ -13,7 +13,8 @@ in place of ezc3d), the 4D-Humans `demo_<sequence>.pkl` (ingest.ImgSmpl: gap fil
 (`write_sequence_npz` writes one).
 
 One process per GPU: with `torchrun` (WORLD_SIZE > 1) the sequences are sharded round-robin over the ranks
-(`parallel.shard_indices`), no collective on the data path; `--inflight N` overlaps N sequences per GPU."""
+(`parallel.shard_indices`), no collective on the data path; `--inflight N` overlaps N sequences per GPU; `--rank_mode
+hypotheses | frames` puts ALL ranks on every sequence instead (its yaw hypotheses / the frame blocks of its solves)."""
 from __future__ import annotations
 
 import argparse
@@ -50,6 +51,11 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--parts_list", nargs="+", default=[])
     parser.add_argument("--print_options", type=str, nargs="*", default=["loss", "progress"])
     parser.add_argument("--inflight", type=int, default=1, help="sequences fitted concurrently per GPU (not in the reference)")
+    parser.add_argument("--rank_mode", choices=["sequences", "hypotheses", "frames"], default="sequences",
+                        help="under torchrun (not in the reference): sequences = every rank fits its own share of the "
+                             "sequences (default, no data-path collective); hypotheses / frames = all ranks work on every "
+                             "sequence together, its yaw hypotheses or the frame blocks of its solves spread over them "
+                             "(parallel.shard_hypotheses / parallel.shard_frames); rank 0 writes the outputs")
     parser.add_argument("--video_fps", type=float, default=None,
                         help="video frame rate when the .avi is absent or not an AVI container (not in the reference: it asks OpenCV)")
     return parser
@@ -210,7 +216,9 @@ def run(args, fit_fn: Optional[Callable] = None) -> int:
         jobs = list_jobs(args.input_dir, output_dir, args.dataset, part, synthetic, args.sequences, args.subjects)
         if args.num_files is not None:
             jobs = jobs[:args.num_files + 1]  # the reference stops after file_count > num_files (test.py:145-147)
-        mine = [jobs[i] for i in shard_indices(len(jobs), rank, world)]
+        rank_mode = getattr(args, "rank_mode", "sequences")
+        together = rank_mode != "sequences" and world > 1
+        mine = jobs if together else [jobs[i] for i in shard_indices(len(jobs), rank, world)]
 
         def one(job):
             base, out = job
@@ -218,11 +226,22 @@ def run(args, fit_fn: Optional[Callable] = None) -> int:
             if loaded is None:
                 return None
             img_smpl, markers = loaded
-            result = fit_fn(img_smpl, markers)
+            if together:  # every rank takes part in every fit and ends with the same result; one of them writes it
+                from . import parallel
+
+                ctx = parallel.shard_hypotheses() if rank_mode == "hypotheses" else \
+                    parallel.shard_frames(device=device, lanes=int(config.get("num_root_orient_angles", 4)))
+                with ctx:
+                    result = fit_fn(img_smpl, markers)
+                if rank != 0:
+                    return None
+            else:
+                result = fit_fn(img_smpl, markers)
             save_outputs(out, result)
             return out
 
-        written += sum(1 for r in fit_many(mine, one, inflight=args.inflight, device=device) if r is not None)
+        written += sum(1 for r in fit_many(mine, one, inflight=1 if together else args.inflight, device=device)
+                       if r is not None)
     return written
 
 
