@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--markers", type=int, default=50)
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--out", default="")
+    ap.add_argument("--fused-only", action="store_true", help="skip the operator-composed solve (tens of thousands of tiny "
+                                                              "launches: too slow under a PMC pass)")
     a = ap.parse_args()
     limit_host_threads()
     dev = torch.device("cuda:0")
@@ -61,7 +63,7 @@ def main():
     torch.cuda.synchronize()
     us_eval = e0.elapsed_time(e1) / n * 1e3
     res = {"F": F, "M": M, "fused_closure_us": us_eval}
-    for driver in ("fused", "operators"):
+    for driver in (("fused",) if a.fused_only else ("fused", "operators")):
         for rep in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
