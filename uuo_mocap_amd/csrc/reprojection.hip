@@ -105,6 +105,7 @@ __device__ __forceinline__ int rpj_owned(int lane) {
 // search: block (f, s) finds, for every marker of frame f, the nearest vertex among slice s of the frame's vertices
 __global__ __launch_bounds__(RPJ_T) void k_reproj_search(ReprojArgs a) {
   __shared__ unsigned long long sK[RPJ_T / 64][RPJ_MC];
+  __shared__ float sU[RPJ_MC][3];
   const int f = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.M, V = a.V;
   const float yaw = rpj_uniform(a.x[0]);
@@ -118,12 +119,20 @@ __global__ __launch_bounds__(RPJ_T) void k_reproj_search(ReprojArgs a) {
     // the pass' query points  u = Ry(yaw)^T (C^T (m - j0) - b):  mocap axes -> HMR axes (x, -z, y), then into the body's
     // un-yawed frame; pairs of markers share the packed-fp32 instructions (same IEEE operations, element by element); a pass
     // past the end repeats the last marker (its minima are simply not stored)
+    // (computed once per block by 16 lanes and broadcast through LDS: done by every wave it was a quarter of the kernel's
+    // vector instructions)
+    if (tid < RPJ_MC) {
+      const float* mp = a.markers + ((size_t)f * M + min(m0 + tid, M - 1)) * 3;
+      const float qx = (mp[0] - j0x) - bx, qy = -(mp[2] - j0z) - by, qz = (mp[1] - j0y) - bz;
+      sU[tid][0] = cs * qx - sn * qz;
+      sU[tid][1] = qy;
+      sU[tid][2] = sn * qx + cs * qz;
+    }
+    __syncthreads();  // (the previous pass' readers of sU are past its two barriers below)
     rpj2 ux[RPJ_MC / 2], uy[RPJ_MC / 2], uz[RPJ_MC / 2];
 #pragma unroll
     for (int k = 0; k < RPJ_MC; ++k) {
-      const float* mp = a.markers + ((size_t)f * M + min(m0 + k, M - 1)) * 3;
-      const float qx = (rpj_uniform(mp[0]) - j0x) - bx, qy = -(rpj_uniform(mp[2]) - j0z) - by, qz = (rpj_uniform(mp[1]) - j0y) - bz;
-      const float vx = rpj_uniform(cs * qx - sn * qz), vy = qy, vz = rpj_uniform(sn * qx + cs * qz);
+      const float vx = rpj_uniform(sU[k][0]), vy = rpj_uniform(sU[k][1]), vz = rpj_uniform(sU[k][2]);
       if (k & 1) { ux[k / 2].y = vx; uy[k / 2].y = vy; uz[k / 2].y = vz; }
       else { ux[k / 2].x = vx; uy[k / 2].x = vy; uz[k / 2].x = vz; }
     }
