@@ -20,6 +20,7 @@
 #ifndef UUO_HIP_H
 #define UUO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

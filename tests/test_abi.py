@@ -378,3 +378,13 @@ def test_wait_policy_argument_checks():
     assert lib.uuo_set_wait_policy(0, -1) == -22 and b"sleep_ns" in lib.uuo_last_error()
     assert lib.uuo_set_wait_policy(0, 20000000) == -22
     assert lib.uuo_set_wait_policy(-1, 0) == 0  # back to spinning
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/uuo_hip.h is the C ABI: it must compile on its own as C99 and as C++ (no torch / HIP types, nothing missing)."""
+    import subprocess
+
+    from uuo_mocap_amd import _lib
+
+    for lang, std, cc in (("c", "-std=c99", "gcc"), ("c++", "-std=c++11", "g++")):
+        subprocess.check_call([cc, "-x", lang, std, "-Wall", "-Werror", "-fsyntax-only", _lib.HEADER_PATH])
