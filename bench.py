@@ -33,6 +33,12 @@ NN_FLOPS_PER_FRAME_MARKER = 6890 * 8
 # what the kernel's matrix pipe usefully executes per frame: the [pose feature | betas] x [posedirs | shapedirs] blend
 # (the <=4-weight skinning runs on the VALU, not as the dense 24-joint product SURVEY 8d's figure credits)
 SKIN_MFMA_FLOPS_PER_FRAME = 2 * 217 * 20670
+# what k_skin2 EXECUTES per frame: the 217-row blend on the matrix pipe + the <=4-weight skinning (4 weights x 12 matrix
+# entries x 6890 vertices, multiply-add) + applying the blended 3x4 to the posed vertex: 9.80 MFLOP -- the roofline's `frac`
+# (the SURVEY 8d figure above credits a dense 24-joint skinning product the kernel rightly does not do: `frac_survey_flops`)
+SKIN_EXECUTED_FLOPS_PER_FRAME = 2 * 217 * 20670 + 2 * 4 * 12 * 6890 + 6890 * 24
+# fused algorithmic bytes of one chamfer closure: tables once (18 688 848 B) + 2.75 KB per frame
+FUSED_ALGORITHMIC_BYTES = lambda F: 18688848 + F * 2750  # noqa: E731
 # algorithmic FLOPs of one frame through one closure (forward + backward)
 CHAMFER_FLOPS_PER_FRAME_EVAL = 15.5e6
 MARKER_FLOPS_PER_FRAME_EVAL = 0.28e6
@@ -247,8 +253,9 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
                   seq.img_smpl.pose_body.to(dev))
     skin_ms = prob.time_closure(x, iters=iters, dominant_only=True)
     closure_ms = prob.time_closure(x, iters=iters, dominant_only=False)
-    skin_flops = SKIN_FLOPS_PER_FRAME * F
-    achieved = skin_flops / (skin_ms * 1e-3) / 1e12
+    skin_flops = SKIN_EXECUTED_FLOPS_PER_FRAME * F
+    achieved = skin_flops / (skin_ms * 1e-3) / 1e12                       # executed useful FLOPs: what `frac` is made of
+    survey = SKIN_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12           # SURVEY 8d's count (dense skinning credited)
     # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r3_pmc_summary.json):
     # FETCH_SIZE 15 080 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 413 KB, at F=300.
     # An OFFLINE figure (a PMC pass cannot run inside this process): null at any other size.
@@ -257,6 +264,15 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
     closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "frac_basis": "executed useful FLOPs of k_skin2: 9.80 MFLOP per frame (217 x 20670 blend on the matrix pipe, "
+                              "<=4-weight skinning and the 3x4 apply on the VALU)",
+                "frac_survey_flops": survey / PEAK_FP32_TFLOPS, "achieved_survey_flops": survey,
+                "flops_per_launch_survey": SKIN_FLOPS_PER_FRAME * F,
+                # PMC bytes of a launch against what a fully fused closure would have to move (tables once +
+                # 2.75 KB per frame = 19.5 MB at F = 300) and against this design's own budget (vertices and unit boxes are
+                # materialised for the pruned search: 46.6 MB)
+                "traffic_vs_algorithmic": (traffic / FUSED_ALGORITHMIC_BYTES(F)) if traffic else None,
+                "traffic_vs_unfused_budget": (traffic / (18688848 + F * (6890 * 12 + 431 * 24))) if traffic else None,
                 "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel at F=300 "
                                   "(profiles/r3_pmc_summary.json), not measured by this run",
                 "kernel": "k_skin2<true,0>",
@@ -443,6 +459,21 @@ def main():
                      "throttled_seconds_timed": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6
                      if cg0 else None},
         }
+        if world == 1 and MODE == "sequences":
+            # latency of ONE sequence alone on the GPU (--inflight 1) beside the throughput headline (three in flight)
+            n_lat = min(3, args.steps)
+            seqs_l = [make_sequence(tables, seed=3000 + i, num_frames=F, num_markers=10 if limb else M, limb_only=limb)
+                      for i in range(n_lat)]
+            with contextlib.redirect_stdout(io.StringIO()):
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+                fits_l = [fit_once(smpl, sq, cfg, dev) for sq in seqs_l]
+                torch.cuda.synchronize(dev)
+                dt3 = time.perf_counter() - t3
+            result["latency_one_sequence"] = {
+                "sequences_in_flight": 1, "steps": n_lat, "ms_per_fit": 1e3 * dt3 / n_lat, "value": n_lat * F / dt3,
+                "unit": "frames/s",
+                "closure_evals_per_step": sum(sum(eval_counts(st_).values()) for _, st_ in fits_l) / n_lat}
         if world == 1 and args.config == "video_mocap" and not args.no_other_configs:
             # the other shipped configurations on sequences of the same size, beside the headline (not the metric's
             # workload): hmr_full.yaml = BASELINE configs[1] as written (part stage on the full skeleton only: SURVEY F9),

@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab_${v}_$r.json").read().strip().splitlines()[-1])
-print("$v round $r: %.1f frames/s  %.1f ms/step" % (d["value"], d["ms_per_step"]))
+print("$v round $r: %.1f frames/s  %.1f ms/step  %.0f evals/step  %.3f M frame-evals/s" % (d["value"], d["ms_per_step"], d["closure_evals_per_step"], d["frame_evals_per_s"] / 1e6))
 PY
   done
 done

@@ -1,0 +1,897 @@
+// L-BFGS with strong-Wolfe line search on device-resident vectors.
+// Mirrors torch.optim.LBFGS.step / _strong_wolfe / _cubic_interpolate (torch 2.10 semantics; the reference
+// constructs it at optimization.py:176-183,319-326 and markers/markers_utils.py:428-435): same direction
+// update rule (history push iff y.s > 1e-10, H_diag = y.s / y.y), same first-step length, bracket / zoom
+// logic, termination tests and their order.  What differs is the arithmetic route, not the algorithm:
+//  * the two-loop recursion is evaluated in coefficient space from Gram matrices of the (s, y) history
+//    (two passes over the history per iteration instead of 4*k dependent dot/axpy launches),
+//  * dot products accumulate in fp64, line-search scalars are fp64 on the host,
+//  * one small read-back per closure evaluation is the only host synchronisation.
+#include "lbfgs.h"
+#include "frame_math.h"
+
+// How a host thread waits for a report word in pinned memory (closure evaluations, Gram rows, lock-step rounds).  Default:
+// spin (pause) -- lowest latency, one CPU per waiting thread.  uuo_set_wait_policy(spin_polls, sleep_ns) makes every wait
+// sleep `sleep_ns` at a time once it has polled `spin_polls` times: for hosts whose CPU quota is smaller than the number
+// of solves in flight (a throttled cgroup stalls ALL threads of the process for the rest of the scheduler period).
+std::atomic<int> g_wait_spin_polls{-1};  // < 0: never sleep
+std::atomic<int> g_wait_sleep_ns{20000};
+extern "C" int uuo_set_wait_policy(int spin_polls, int sleep_ns) {
+  UUO_REQUIRE(sleep_ns >= 0 && sleep_ns <= 10000000, "uuo_set_wait_policy: sleep_ns must be within [0, 10 ms]");
+  g_wait_sleep_ns.store(sleep_ns > 0 ? sleep_ns : 1, std::memory_order_relaxed);
+  g_wait_spin_polls.store(spin_polls, std::memory_order_relaxed);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- workspace
+int lbws_destroy(LbWs* w) {
+  if (!w) return 0;
+  if (w->slab) (void)hipFree(w->slab);
+  if (w->h_out) (void)hipHostFree(w->h_out);
+  if (w->h_rows) (void)hipHostFree(w->h_rows);
+  if (w->h_joint) (void)hipHostFree(w->h_joint);
+  if (w->h_gb) (void)hipHostFree(w->h_gb);
+  if (w->rd_joint) (void)hipFree(w->rd_joint);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  delete w;
+  return 0;
+}
+
+int lbws_create(int n, int hist, LbWs** out, bool sync) {
+  UUO_REQUIRE(hist >= 1 && hist <= LB_MAXH - 4, "lbfgs: history_size must be in [1,100]");
+  LbWs* w = new LbWs();
+  n = (n + LB_CW - 1) / LB_CW * LB_CW;  // whole column blocks: 16-byte loads of the work vectors stay in bounds
+  w->n_cap = n;
+  w->cap = hist + 1;
+  w->nchunks = LB_MAXCHUNK;
+  hipError_t e = hipSuccess;
+  struct Piece { void** p; size_t bytes; };
+  std::vector<Piece> pieces;
+  auto A = [&](void** p, size_t bytes) { pieces.push_back({p, (bytes + 255) / 256 * 256}); };
+  const size_t hist_floats = (size_t)(n / LB_CW) * LB_CBSTRIDE(w->cap);
+  A((void**)&w->S, hist_floats * sizeof(float));
+  A((void**)&w->Y, hist_floats * sizeof(float));
+  A((void**)&w->vecs, (size_t)LB_NVEC * n * sizeof(float));
+  const size_t part_dots = (size_t)w->nchunks * LB_ROWS * 3;
+  A((void**)&w->part, (part_dots > 1024 ? part_dots : 1024) * sizeof(double));
+  A((void**)&w->st, sizeof(LbDev));
+  A((void**)&w->loss_dev, 16 * sizeof(float));
+  {  // one allocation, one zero fill
+    size_t total = 0;
+    for (const Piece& q : pieces) total += q.bytes;
+    e = hipMalloc(&w->slab, total);
+    if (e == hipSuccess) e = hipMemset(w->slab, 0, total);
+    size_t off = 0;
+    if (e == hipSuccess)
+      for (const Piece& q : pieces) {
+        *q.p = (char*)w->slab + off;
+        off += q.bytes;
+      }
+  }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_out, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) std::memset(w->h_out, 0, 32 * sizeof(double));
+  if (e == hipSuccess) e = hipEventCreate(&w->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&w->ev1);
+  // null-stream memsets are not ordered with the (non-blocking) stream the first solve runs on
+  if (e == hipSuccess && sync) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    lbws_destroy(w);
+    uuo_set_error(std::string("lbfgs workspace: ") + hipGetErrorString(e));
+    return -12;
+  }
+  *out = w;
+  return 0;
+}
+
+// issue now, or record for the lock-step batch that is stepping this problem (uuo_common.h)
+template <class A, class L>
+static inline void lb_dispatch(int op, hipStream_t s, dim3 grid, L launch, A& a) {
+  a.h.gx = (int)grid.x;
+  a.h.gy = (int)grid.y;
+  if (uuo_record(op, (int)grid.x, (int)grid.y, a)) return;
+  launch(s, grid, a);
+}
+static inline int lb_copy(hipStream_t s, float* dst, const float* src, size_t bytes) {
+  LbCopyArgs c{{1, 1}, dst, src, bytes};
+  if (uuo_record(UUO_OP_COPY, 1, 1, c)) return 0;
+  UUO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- driver
+static double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2, bool has_bounds,
+                                double lo, double hi) {
+  double xmin_bound, xmax_bound;
+  if (has_bounds) {
+    xmin_bound = lo;
+    xmax_bound = hi;
+  } else if (x1 <= x2) {
+    xmin_bound = x1;
+    xmax_bound = x2;
+  } else {
+    xmin_bound = x2;
+    xmax_bound = x1;
+  }
+  const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
+  const double d2_square = d1 * d1 - g1 * g2;
+  if (d2_square >= 0.0) {
+    const double d2 = std::sqrt(d2_square);
+    double min_pos;
+    if (x1 <= x2)
+      min_pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2.0 * d2));
+    else
+      min_pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2.0 * d2));
+    return std::fmin(std::fmax(min_pos, xmin_bound), xmax_bound);
+  }
+  return (xmin_bound + xmax_bound) / 2.0;
+}
+
+struct LsPoint {
+  double t = 0, f = 0, gtd = 0;
+  double gmax = 0;
+  int buf = -1;  // index of the work vector holding the gradient
+};
+
+struct LbHostOut {  // mirror of the tail of LbDev read back after every closure evaluation
+  unsigned dmax_bits;
+  int pad;
+  LbOut out;
+};
+
+thread_local void (*g_batch_yield)(void) = nullptr;
+
+static int shared_gather(SharedCtx* sh, const double* mine, int n) {
+  sh->all.resize((size_t)sh->world * n);
+  const int rc = sh->gather(sh->user, mine, n, sh->all.data());
+  if (rc) {
+    uuo_set_error("uuo_lbfgs_solve_shared: the gather hook returned " + std::to_string(rc));
+    return rc < 0 ? rc : -rc;
+  }
+  return 0;
+}
+
+int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
+              uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb, void* cb_user, SharedCtx* sh) {
+  const bool batched = uuo_recorder != nullptr;
+  const int n = obj.n;
+  const int n_full = obj.n_full > 0 ? obj.n_full : obj.n;  // floats of the iterate (>= n on the compact packing)
+  const UuoIndexMap map = obj.map;
+  UUO_REQUIRE(n > 0 && n <= w->n_cap && n_full <= w->n_cap, "lbfgs: parameter count exceeds the workspace");
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  UUO_REQUIRE(hist + 1 <= w->cap, "lbfgs: history_size exceeds the workspace");
+  const int cap = hist + 1;
+  const int max_iter = opt->max_iter;
+  const int max_eval = opt->max_eval > 0 ? opt->max_eval : (max_iter * 5) / 4;
+  const double lr = opt->lr, tol_grad = opt->tolerance_grad, tol_change = opt->tolerance_change;
+  const double c1 = 1e-4, c2 = 0.9;
+  const size_t stride = (size_t)w->n_cap;
+  const int ncb = (n + LB_CW - 1) / LB_CW;                 // column blocks of the history holding this problem
+  const int gcb = (ncb + LB_MAXCHUNK - 1) / LB_MAXCHUNK;   // column blocks per dot-kernel group
+  const int nchunks = (ncb + gcb - 1) / gcb;               // groups = partial sums per Gram entry (<= LB_MAXCHUNK)
+  const int nb = (n + 255) / 256;
+  const int nstat = std::min(64, nb);
+  auto vec = [&](int i) { return w->vecs + (size_t)i * stride; };
+  // work vectors: 0 direction d, 1 spare iterate buffer, 2.. gradient pool.  Iterates and gradients change hands by
+  // pointer, never by copy: x lives in d_x or vec(1) (the other one receives the next trial point), the gradient at
+  // x and the previous gradient are pool entries.
+  float* d = vec(0);
+  float* xcur = d_x;
+  float* xoth = vec(1);
+  bool pool_used[LB_NVEC] = {false};
+  auto pool_alloc = [&]() {
+    for (int i = 2; i < LB_NVEC; ++i)
+      if (!pool_used[i]) {
+        pool_used[i] = true;
+        return i;
+      }
+    return -1;
+  };
+  LbHostOut* hh = reinterpret_cast<LbHostOut*>(w->h_out);
+  LbOut* ho = &hh->out;
+  double* stats_dev = reinterpret_cast<double*>((char*)w->st + offsetof(LbDev, out));
+  int evals_total = 0;
+
+  // evaluate at x_eval into gradient vector gv; statistics against d (or none); read back.
+  // Stage closures report through pinned memory: their finalize kernel copies the read-back block into w->h_out and
+  // then publishes a sequence number that this thread polls -- no copy command, no stream synchronisation.  A stuck
+  // or failed stream is caught by a periodic hipStreamQuery.
+  static const int poll_mode = UUO_ENV_INT("UUO_LBFGS_POLL", 1);
+  // the slowest evaluation of the path (first closure at F = 3000) is ~10 ms; a minute means the device is gone
+  const double eval_timeout_s = (double)UUO_ENV_INT("UUO_LBFGS_EVAL_TIMEOUT_S", 60);
+  unsigned long long* rep_words = reinterpret_cast<unsigned long long*>(w->h_out);
+  auto host_dmax = [&]() -> double {
+    float f;
+    std::memcpy(&f, &hh->dmax_bits, sizeof(float));
+    return (double)f;
+  };
+  auto evaluate = [&](const float* x_eval, float* gv, bool with_dir) -> int {
+    const float* dir = with_dir ? d : (const float*)nullptr;
+    const bool poll = obj.fused_stats && poll_mode != 0;
+    UuoEvalReport rep;
+    if (poll) {
+      rep.host = rep_words;
+      rep.seq = ++w->seq;
+    }
+    int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr, poll ? &rep : nullptr);
+    if (rc) return rc;
+    if (batched) {  // the batch scheduler issues the recorded launches of all its problems and waits for their reports
+      UUO_REQUIRE(poll && g_batch_yield, "lbfgs: a lock-step batch needs the polled report path");
+      g_batch_yield();
+      return 0;
+    }
+    if (poll) {
+      // Bounded wait: the report word is polled; every ~1M polls the stream is queried (a failed or drained stream that
+      // never reported is an error) and the wall clock is checked against eval_timeout_s -- a kernel that never finishes
+      // must not pin this host thread for ever.
+      UuoWaiter waiter;
+      timespec t_start;
+      clock_gettime(CLOCK_MONOTONIC, &t_start);
+      while (__atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
+        if (waiter.tick()) {
+          const hipError_t q = hipStreamQuery(s);
+          if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
+            uuo_set_error(std::string("lbfgs: closure evaluation did not report: ") + hipGetErrorString(q));
+            return -5;
+          }
+          timespec t_now;
+          clock_gettime(CLOCK_MONOTONIC, &t_now);
+          const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
+          if (waited > eval_timeout_s) {
+            uuo_set_error("lbfgs: closure evaluation " + std::to_string(evals_total) + " did not finish within " +
+                          std::to_string((int)eval_timeout_s) + " s (stream still busy); giving up on the solve");
+            return -62;  // -ETIME
+          }
+        }
+      }
+      if (sh) {
+        // joint statistics of this evaluation: one gather of 6 + cnt doubles per rank, reduced here in rank order
+        double mine[6 + 16];
+        auto word = [&](int i) { double v; std::memcpy(&v, &rep_words[i], sizeof(double)); return v; };
+        mine[0] = ho->loss; mine[1] = ho->gtd_new;
+        mine[2] = word(11); mine[3] = word(12); mine[4] = word(13);  // own parameters: max|g|, sum|g|, g.g
+        mine[5] = host_dmax();
+        for (int l = 0; l < sh->cnt; ++l) mine[6 + l] = word(14 + l);
+        const int m_ = 6 + sh->cnt;
+        const int grc = shared_gather(sh, mine, m_);
+        if (grc) return grc;
+        double loss_j = 0.0, gtd_j = 0.0, g1_j = 0.0, gg_j = 0.0, gmax_j = 0.0, dmax_j = 0.0, gb[16] = {0.0};
+        for (int r = 0; r < sh->world; ++r) {
+          const double* a_ = sh->all.data() + (size_t)r * m_;
+          loss_j += a_[0]; gtd_j += a_[1];
+          gmax_j = std::fmax(gmax_j, a_[2]); g1_j += a_[3]; gg_j += a_[4];
+          dmax_j = std::fmax(dmax_j, a_[5]);
+          for (int l = 0; l < sh->cnt; ++l) gb[l] += a_[6 + l];
+        }
+        float* slot = w->h_gb + 16 * (w->gb_slot++ & 3);  // (a slot is reused four reports later: its copy has executed)
+        for (int l = 0; l < sh->cnt; ++l) {
+          const float gbf = (float)gb[l];
+          slot[l] = gbf;
+          g1_j += std::fabs((double)gbf);
+          gg_j += (double)gbf * (double)gbf;
+          gmax_j = std::fmax(gmax_j, std::fabs((double)gbf));
+        }
+        UUO_HIP_CHECK(hipMemcpyAsync(gv + sh->off, slot, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
+        ho->loss = loss_j; ho->gtd_new = gtd_j; ho->gmax = gmax_j; ho->g1 = g1_j; ho->gg = gg_j;
+        const float dmf = (float)dmax_j;
+        std::memcpy(&hh->dmax_bits, &dmf, sizeof(float));
+      }
+      return 0;
+    }
+    if (!obj.fused_stats) {
+      uuo_lb_launch_stats(s, nstat, n, gv, dir, w->part, w->loss_dev, w->st);
+      UUO_HIP_CHECK(hipGetLastError());
+    }
+    UUO_HIP_CHECK(hipMemcpyAsync(w->h_out, (const char*)w->st + offsetof(LbDev, dmax_bits), sizeof(LbHostOut),
+                                 hipMemcpyDeviceToHost, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+  };
+  auto report = [&](double loss, const float* x_eval) {
+    if (cb) cb(cb_user, evals_total, (float)loss, x_eval);
+    if (opt->verbose) std::printf("lbfgs eval %d loss %.9g\n", evals_total, loss);
+    ++evals_total;
+  };
+
+  if (sh) {
+    UUO_REQUIRE(!batched && obj.fused_stats && poll_mode != 0, "lbfgs: shared solves need the fused, polled report path");
+    UUO_REQUIRE(sh->cnt > 0 && sh->cnt <= 16 && sh->off >= 0 && sh->off + sh->cnt <= n && sh->off_x >= 0 &&
+                sh->off_x + sh->cnt <= n_full && sh->world >= 1 &&
+                sh->rank >= 0 && sh->rank < sh->world && sh->gather, "lbfgs: bad shared-parameter description");
+    if (!w->h_rows) {
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_rows, (LB_ROWS * 3 + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_joint, 2 * LB_ROWS * 3 * sizeof(double), hipHostMallocDefault));
+      UUO_HIP_CHECK(hipHostMalloc((void**)&w->h_gb, 4 * 16 * sizeof(float), hipHostMallocDefault));
+      UUO_HIP_CHECK(hipMalloc((void**)&w->rd_joint, LB_ROWS * 3 * sizeof(double)));
+      std::memset(w->h_rows, 0, (LB_ROWS * 3 + 1) * sizeof(double));
+    }
+    // the replicas of the shared entries must be bit-identical: every rank takes rank 0's values
+    float hb[16];
+    double mine[16];
+    UUO_HIP_CHECK(hipMemcpyAsync(hb, d_x + sh->off_x, sizeof(float) * sh->cnt, hipMemcpyDeviceToHost, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));
+    for (int l = 0; l < sh->cnt; ++l) mine[l] = (double)hb[l];
+    const int grc = shared_gather(sh, mine, sh->cnt);
+    if (grc) return grc;
+    for (int l = 0; l < sh->cnt; ++l) hb[l] = (float)sh->all[l];
+    UUO_HIP_CHECK(hipMemcpyAsync(d_x + sh->off_x, hb, sizeof(float) * sh->cnt, hipMemcpyHostToDevice, s));
+    UUO_HIP_CHECK(hipStreamSynchronize(s));  // (hb is a stack buffer)
+  }
+  if (!batched) UUO_HIP_CHECK(hipEventRecord(w->ev0, s));
+  if (map.nseg) {
+    // compact packing: the trial points are written at the solver's coordinates only, so the other iterate buffer gets
+    // the parameter entries that have no coordinate (and never move) once, here
+    const int rc_ = lb_copy(s, xoth, xcur, (size_t)n_full * sizeof(float));
+    if (rc_) return rc_;
+  }
+  uuo_lb_launch_init(s, w->st);
+  int ig = pool_alloc();  // gradient at the current iterate
+  int ipg = -1;           // gradient at the previous iterate
+  int rc = evaluate(xcur, vec(ig), false);
+  if (rc) return rc;
+  double loss = ho->loss;
+  double gmax = ho->gmax;
+  double g1 = ho->g1;
+  const double gg0 = ho->gg;
+  report(loss, xcur);
+  stats->first_loss = (float)loss;
+  int current_evals = 1;
+  int n_iter = 0;
+  int reason = 0;
+  int head = 0, count = 0;
+  double t = 0.0, prev_loss = loss;
+  if (!(gmax > tol_grad)) {
+    reason = 6;
+  } else {
+    while (n_iter < max_iter) {
+      ++n_iter;
+      float* g = vec(ig);
+      // ---------------------------------------------------------------- step length guess (lbfgs.py:453-456)
+      const double t_prev_iter = t;
+      if (n_iter == 1)
+        t = std::fmin(1.0, 1.0 / g1) * lr;
+      else
+        t = lr;
+      // ---------------------------------------------------------------- direction + first trial point
+      if (n_iter == 1) {
+        LbNegArgs na{{0, 0}, n, g, d, xcur, (float)t, xoth, map};
+        lb_dispatch(UUO_OP_NEG, s, dim3(nb), uuo_lb_launch_neg, na);
+      } else {
+        const int cand = (head + count) % cap;
+        const int nrows = 2 * (count + 1) + 1;
+        LbDotsArgs da{{0, 0}, n, cap, w->cap, head, count, cand, w->S, w->Y, g, vec(ipg), d, (float)t_prev_iter, ncb, gcb, w->part};
+        if (sh && sh->rank != 0) {  // the replicated entries are counted once in the joint dot products: on rank 0
+          da.skip_lo = sh->off;
+          da.skip_hi = sh->off + sh->cnt;
+        }
+        lb_dispatch(UUO_OP_DOTS, s, dim3(nchunks, LB_DRS), uuo_lb_launch_dots, da);
+        const double* rd_in = nullptr;
+        if (sh) {
+          const unsigned long long rseq = ++w->row_seq;
+          uuo_lb_launch_rows(s, nchunks, cap, cand, w->part, w->st, w->h_rows, rseq);
+          UUO_HIP_CHECK(hipGetLastError());
+          unsigned long long* rw = reinterpret_cast<unsigned long long*>(w->h_rows + LB_ROWS * 3);
+          UuoWaiter waiter;
+          timespec t_start;
+          clock_gettime(CLOCK_MONOTONIC, &t_start);
+          while (__atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) {
+            if (waiter.tick()) {
+              const hipError_t q = hipStreamQuery(s);
+              timespec t_now;
+              clock_gettime(CLOCK_MONOTONIC, &t_now);
+              const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
+              if ((q != hipErrorNotReady && __atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) || waited > eval_timeout_s) {
+                uuo_set_error(std::string("lbfgs: the Gram rows of a shared solve did not arrive: ") + hipGetErrorString(q));
+                return -5;
+              }
+            }
+          }
+          const int nr = LB_ROWS * 3;
+          const int grc = shared_gather(sh, w->h_rows, nr);
+          if (grc) return grc;
+          double* joint = w->h_joint + (size_t)nr * (w->joint_slot++ & 1);  // (reused two iterations later)
+          for (int e = 0; e < nr; ++e) {
+            double acc = 0.0;
+            for (int r = 0; r < sh->world; ++r) acc += sh->all[(size_t)r * nr + e];
+            joint[e] = acc;
+          }
+          UUO_HIP_CHECK(hipMemcpyAsync(w->rd_joint, joint, sizeof(double) * nr, hipMemcpyHostToDevice, s));
+          rd_in = w->rd_joint;
+        }
+        static const int small_stop = UUO_ENV_INT("UUO_SMALL_STOP", 0);  // ablation only (debug flavour)
+        bool small_done = false;
+#ifdef UUO_DEBUG_HOOKS  // comparison only: the two earlier formulations of this step (solver_debug.hip)
+        static const int small_ref = UUO_ENV_INT("UUO_SMALL_REF", 0);
+        static const int small_block = UUO_ENV_INT("UUO_SMALL_BLOCK", 0);
+        if ((small_ref || small_block) && !uuo_recorder) {
+          uuo_debug_launch_small(small_ref ? 1 : 2, s, nchunks, cap, hist, cand, w->part, w->st, small_stop);
+          small_done = true;
+        }
+#endif
+        if (!small_done) {
+          LbSmallArgs sa{{0, 0}, nchunks, cap, hist, cand, w->part, w->st, small_stop};
+          sa.rd_in = rd_in;
+          lb_dispatch(UUO_OP_SMALL, s, dim3(1), [](hipStream_t s_, dim3, const LbSmallArgs& a_) { uuo_lb_launch_small(s_, a_); }, sa);
+        }
+        LbDirArgs ra{{0, 0}, n, cap, w->cap, w->S, w->Y, g, w->st, d, xcur, (float)t, xoth, map};
+        lb_dispatch(UUO_OP_DIR, s, dim3(2 * ncb), uuo_lb_launch_direction, ra);
+      }
+      UUO_HIP_CHECK(hipGetLastError());
+      prev_loss = loss;
+      // ---------------------------------------------------------------- first trial (speculative: launched
+      // before g.d is known on the host; discarded if the direction test fails)
+      LsPoint pnew;
+      pnew.buf = pool_alloc();
+      UUO_REQUIRE(pnew.buf >= 0, "lbfgs: gradient pool exhausted");
+      rc = evaluate(xoth, vec(pnew.buf), true);
+      if (rc) return rc;
+      double gtd, d_norm;
+      if (n_iter == 1) {  // d = -g: g.d = -g.g, max|d| = max|g|
+        gtd = -gg0;
+        d_norm = gmax;
+      } else {
+        gtd = ho->gtd_dir;
+        d_norm = host_dmax();
+        if (ho->accepted != 0.0) {
+          if (count == hist)
+            head = (head + 1) % cap;
+          else
+            count += 1;
+        }
+      }
+      if (gtd > -tol_change) {
+        pool_used[pnew.buf] = false;
+        reason = 5;
+        break;
+      }
+      pnew.t = t;
+      pnew.f = ho->loss;
+      pnew.gtd = ho->gtd_new;
+      pnew.gmax = ho->gmax;
+      report(pnew.f, xoth);
+      double t_at_xoth = t;  // step whose iterate currently sits in xoth
+      // ---------------------------------------------------------------- strong Wolfe (lbfgs.py:40-209)
+      const int max_ls = max_eval - current_evals;
+      int ls_func_evals = 1;
+      LsPoint p0;  // the point at t = 0
+      p0.t = 0;
+      p0.f = loss;
+      p0.gtd = gtd;
+      p0.gmax = gmax;
+      p0.buf = ig;
+      auto release = [&](int buf) {
+        if (buf != ig && buf >= 2) pool_used[buf] = false;
+      };
+      auto trial = [&](LsPoint& pt) -> int {
+        pt.buf = pool_alloc();
+        UUO_REQUIRE(pt.buf >= 0, "lbfgs: gradient pool exhausted");
+        LbAxpyArgs xa{{0, 0}, n, xcur, (float)pt.t, d, xoth, map};
+        lb_dispatch(UUO_OP_AXPY, s, dim3(nb), uuo_lb_launch_axpy, xa);
+        int r = evaluate(xoth, vec(pt.buf), true);
+        if (r) return r;
+        t_at_xoth = pt.t;
+        pt.f = ho->loss;
+        pt.gtd = ho->gtd_new;
+        pt.gmax = ho->gmax;
+        report(pt.f, xoth);
+        ++ls_func_evals;
+        return 0;
+      };
+      LsPoint pprev = p0;
+      LsPoint br[2];
+      int nbr = 0;
+      bool done = false;
+      int ls_iter = 0;
+      while (ls_iter < max_ls) {
+        if (pnew.f > (loss + c1 * pnew.t * gtd) || (ls_iter > 1 && pnew.f >= pprev.f)) {
+          br[0] = pprev;
+          br[1] = pnew;
+          nbr = 2;
+          break;
+        }
+        if (std::fabs(pnew.gtd) <= -c2 * gtd) {
+          br[0] = pnew;
+          nbr = 1;
+          done = true;
+          release(pprev.buf);
+          break;
+        }
+        if (pnew.gtd >= 0) {
+          br[0] = pprev;
+          br[1] = pnew;
+          nbr = 2;
+          break;
+        }
+        const double min_step = pnew.t + 0.01 * (pnew.t - pprev.t);
+        const double max_step = pnew.t * 10;
+        const double t_next = cubic_interpolate(pprev.t, pprev.f, pprev.gtd, pnew.t, pnew.f, pnew.gtd, true, min_step,
+                                                max_step);
+        release(pprev.buf);
+        pprev = pnew;
+        pnew = LsPoint();
+        pnew.t = t_next;
+        rc = trial(pnew);
+        if (rc) return rc;
+        ++ls_iter;
+      }
+      if (nbr == 0) {  // ls_iter == max_ls
+        br[0] = p0;
+        br[1] = pnew;
+        nbr = 2;
+        if (pprev.buf != pnew.buf) release(pprev.buf);
+      }
+      bool insuf_progress = false;
+      int low_pos, high_pos;
+      if (br[0].f <= br[nbr - 1].f) {
+        low_pos = 0;
+        high_pos = 1;
+      } else {
+        low_pos = 1;
+        high_pos = 0;
+      }
+      while (!done && ls_iter < max_ls) {
+        // torch 2.10's LBFGS.step does not hand its tolerance_change to _strong_wolfe (lbfgs.py:486-488): the line
+        // search always uses that function's default, 1e-9
+        if (std::fabs(br[1].t - br[0].t) * d_norm < 1e-9) break;
+        double tz = cubic_interpolate(br[0].t, br[0].f, br[0].gtd, br[1].t, br[1].f, br[1].gtd, false, 0, 0);
+        const double bmax = std::fmax(br[0].t, br[1].t), bmin = std::fmin(br[0].t, br[1].t);
+        const double eps = 0.1 * (bmax - bmin);
+        if (std::fmin(bmax - tz, tz - bmin) < eps) {
+          if (insuf_progress || tz >= bmax || tz <= bmin) {
+            if (std::fabs(tz - bmax) < std::fabs(tz - bmin))
+              tz = bmax - eps;
+            else
+              tz = bmin + eps;
+            insuf_progress = false;
+          } else {
+            insuf_progress = true;
+          }
+        } else {
+          insuf_progress = false;
+        }
+        LsPoint pz;
+        pz.t = tz;
+        rc = trial(pz);
+        if (rc) return rc;
+        ++ls_iter;
+        if (pz.f > (loss + c1 * pz.t * gtd) || pz.f >= br[low_pos].f) {
+          release(br[high_pos].buf);
+          br[high_pos] = pz;
+          if (br[0].f <= br[1].f) {
+            low_pos = 0;
+            high_pos = 1;
+          } else {
+            low_pos = 1;
+            high_pos = 0;
+          }
+        } else {
+          if (std::fabs(pz.gtd) <= -c2 * gtd) {
+            done = true;
+          } else if (pz.gtd * (br[high_pos].t - br[low_pos].t) >= 0) {
+            release(br[high_pos].buf);
+            br[high_pos] = br[low_pos];
+            br[low_pos] = pz;
+            continue;
+          }
+          // new point becomes new low (the old low is dropped unless it was just moved to high)
+          release(br[low_pos].buf);
+          br[low_pos] = pz;
+        }
+      }
+      const LsPoint res = (nbr == 1) ? br[0] : br[low_pos];
+      // ---------------------------------------------------------------- accept: x <- x + t d by pointer where the
+      // accepted point is the trial that already sits in xoth (p.add_(d, alpha=t) rounds exactly like the trial)
+      t = res.t;
+      loss = res.f;
+      gmax = res.gmax;
+      if (res.t == 0.0) {
+        // line search returned the starting point (bracket low at t = 0): iterate unchanged
+      } else {
+        if (t_at_xoth != res.t) {
+          LbAxpyArgs xa{{0, 0}, n, xcur, (float)t, d, xoth, map};
+          lb_dispatch(UUO_OP_AXPY_ACCEPT, s, dim3(nb), uuo_lb_launch_axpy, xa);
+        }
+        float* tmp = xcur;
+        xcur = xoth;
+        xoth = tmp;
+      }
+      UUO_HIP_CHECK(hipGetLastError());
+      {  // gradient hand-over: previous <- current, current <- accepted point's
+        const int old_g = ig, old_pg = ipg;
+        const int new_g = res.buf;
+        for (int i = 2; i < LB_NVEC; ++i) pool_used[i] = false;
+        if (new_g == old_g) {
+          // accepted point is the starting point: prev gradient must still become a copy of g (y = 0 next time)
+          ipg = (old_pg >= 0 && old_pg != old_g) ? old_pg : pool_alloc();
+          pool_used[ipg] = true;
+          { const int rc_ = lb_copy(s, vec(ipg), vec(old_g), (size_t)n * sizeof(float)); if (rc_) return rc_; }
+          ig = old_g;
+        } else {
+          ipg = old_g;
+          ig = new_g;
+        }
+        pool_used[ig] = true;
+        pool_used[ipg] = true;
+      }
+      current_evals += ls_func_evals;
+      // ---------------------------------------------------------------- termination (lbfgs.py:511-526)
+      if (n_iter == max_iter) {
+        reason = 0;
+        break;
+      }
+      if (current_evals >= max_eval) {
+        reason = 1;
+        break;
+      }
+      if (gmax <= tol_grad) {
+        reason = 2;
+        break;
+      }
+      if (d_norm * std::fabs(t) <= tol_change) {
+        reason = 3;
+        break;
+      }
+      if (std::fabs(loss - prev_loss) < tol_change) {
+        reason = 4;
+        break;
+      }
+    }
+  }
+  if (xcur != d_x) {
+    const int rc_ = lb_copy(s, d_x, xcur, (size_t)n_full * sizeof(float));
+    if (rc_) return rc_;
+  }
+  float ms = 0.f;
+  if (!batched) {
+    UUO_HIP_CHECK(hipEventRecord(w->ev1, s));
+    UUO_HIP_CHECK(hipEventSynchronize(w->ev1));
+    UUO_HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+  }
+  stats->n_iter = n_iter;
+  stats->n_eval = current_evals;
+  stats->final_loss = (float)loss;
+  stats->stop_reason = reason;
+  stats->device_ms = ms;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- fit workspace
+extern "C" int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out) {
+  return fit_create_impl(model, F, M, out, true);
+}
+int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bool sync) {
+  UUO_REQUIRE(model && out, "uuo_fit_create: null argument");
+  UUO_REQUIRE(F > 0 && M > 0, "uuo_fit_create: F and M must be positive");
+  uuo_fit* fit = new uuo_fit();
+  fit->model = model;
+  fit->F = F;
+  fit->M = M;
+  fit->nFT = (F + UUO_FT - 1) / UUO_FT;
+  fit->n_max = 219 * F + 10;
+  const int nFT = fit->nFT;
+  // one device allocation and one zero fill for the whole workspace (a lock-step batch creates hundreds of these)
+  hipError_t e = hipSuccess;
+  struct Piece { void** p; size_t bytes; };
+  std::vector<Piece> pieces;
+  auto A = [&](void** p, size_t bytes) { pieces.push_back({p, (bytes + 255) / 256 * 256}); };
+  A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));
+  A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
+  A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
+  A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
+  A((void**)&fit->part_sb, (size_t)model->V * 8 * sizeof(float));
+  A((void**)&fit->bbox, (size_t)F * ((model->V + 15) / 16) * 6 * sizeof(float));
+  A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
+  A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));
+  A((void**)&fit->frames, (size_t)F * sizeof(FrameLds));
+  A((void**)&fit->mask, (size_t)F * M * sizeof(float));
+  A((void**)&fit->scalars, 64 * sizeof(float));
+  A((void**)&fit->zeros16, 16 * sizeof(float));
+  A((void**)&fit->vecs, (size_t)fit->n_max * sizeof(float));
+  {
+    size_t total = 0;
+    for (const Piece& q : pieces) total += q.bytes;
+    e = hipMalloc(&fit->slab, total);
+    if (e == hipSuccess) e = hipMemset(fit->slab, 0, total);
+    size_t off = 0;
+    if (e == hipSuccess)
+      for (const Piece& q : pieces) {
+        *q.p = (char*)fit->slab + off;
+        off += q.bytes;
+      }
+  }
+  if (e == hipSuccess) e = hipEventCreate(&fit->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&fit->ev1);
+  if (e != hipSuccess) {
+    uuo_set_error(std::string("uuo_fit_create: ") + hipGetErrorString(e));
+    uuo_fit_destroy(fit);
+    return -12;
+  }
+  if (sync) UUO_HIP_CHECK(hipDeviceSynchronize());  // the zero fills above ran on the null stream
+  *out = fit;
+  return 0;
+}
+
+extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
+  if (!fit) return 0;
+  if (fit->slab) (void)hipFree(fit->slab);
+  if (fit->pose_cache && !fit->shared_pose_cache) (void)hipFree(fit->pose_cache);
+  if (fit->ev0) (void)hipEventDestroy(fit->ev0);
+  if (fit->ev1) (void)hipEventDestroy(fit->ev1);
+  if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);
+  delete fit;
+  return 0;
+}
+
+extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                               const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, uuo_eval_callback_t cb,
+                               void* cb_user) {
+  int rc = uuo_validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && opt && stats, "uuo_lbfgs_solve: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve: max_iter must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  // The optimiser's workspace (history S, Y: 2 x (hist+1) x n floats, 53 MB at n = 65 710) is sized for THIS problem,
+  // not for the largest stage of the sequence: a workspace that only ever solves the part stage (n = 3F + 11) stays
+  // ~70x smaller.  It is re-created only when the parameter count or the history grows.
+  const int n_params = uuo_problem_num_params(p);
+  LbWs* w = (LbWs*)fit->lbws;
+  if (!w || w->cap < hist + 1 || w->n_cap < n_params) {
+    const int keep_hist = w ? std::max(hist, w->cap - 1) : hist;
+    if (w) {
+      UUO_HIP_CHECK(hipStreamSynchronize(s));
+      lbws_destroy(w);
+    }
+    fit->lbws = nullptr;
+    rc = lbws_create(n_params, keep_hist, &w);
+    if (rc) return rc;
+    fit->lbws = w;
+  }
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  StageObjective obj;
+  rc = stage_objective_init(obj, fit, s, p, d_x);
+  if (rc) return rc;
+  std::memset(stats, 0, sizeof(*stats));
+  return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user);
+}
+
+// EXTENSION (BASELINE configs[3]; not reference behaviour): uuo_lbfgs_solve where the `world` ranks that call
+// it together -- one stage problem each, same stage -- share the shape vector.  See SharedCtx above.
+extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                                      const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
+                                      uuo_eval_callback_t cb, void* cb_user) {
+  UUO_REQUIRE(shared && shared->gather && shared->world >= 1 && shared->rank >= 0 && shared->rank < shared->world,
+              "uuo_lbfgs_solve_shared: bad rank description");
+  int rc = uuo_validate_problem(fit, p);
+  if (rc) return rc;
+  UUO_REQUIRE(d_x && opt && stats, "uuo_lbfgs_solve_shared: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve_shared: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_lbfgs_solve_shared: not inside a lock-step batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  const int n_params = uuo_problem_num_params(p);
+  LbWs* w = (LbWs*)fit->lbws;
+  if (!w || w->cap < hist + 1 || w->n_cap < n_params) {
+    const int keep_hist = w ? std::max(hist, w->cap - 1) : hist;
+    if (w) {
+      UUO_HIP_CHECK(hipStreamSynchronize(s));
+      lbws_destroy(w);
+    }
+    fit->lbws = nullptr;
+    rc = lbws_create(n_params, keep_hist, &w);
+    if (rc) return rc;
+    fit->lbws = w;
+  }
+  rc = uuo_ensure_mask(fit, s, p);
+  if (rc) return rc;
+  StageObjective obj;
+  rc = stage_objective_init(obj, fit, s, p, d_x);
+  if (rc) return rc;
+  SharedCtx sh;
+  sh.gather = shared->gather;
+  sh.user = shared->user;
+  sh.rank = shared->rank;
+  sh.world = shared->world;
+  sh.cnt = UUO_NUM_BETAS;
+  const int F = p->F;  // offset of the betas in the parameter vector and in the solver's packing (closure.hip stage_layout)
+  sh.off_x = (p->stage == UUO_STAGE_CHAMFER) ? 4 * F : (p->stage == UUO_STAGE_MARKER) ? 207 * F : 3 * F + 1;
+  sh.off = (p->stage == UUO_STAGE_MARKER && obj.compact) ? 138 * F : sh.off_x;
+  {  // every rank must run the same packing: a rank whose third rows differ from their targets makes all of them run full
+    double mine = obj.compact ? 1.0 : 0.0;
+    rc = shared_gather(&sh, &mine, 1);
+    if (rc) return rc;
+    bool all_compact = true;
+    for (int r = 0; r < sh.world; ++r) all_compact = all_compact && sh.all[r] != 0.0;
+    if (obj.compact && !all_compact) {
+      obj.compact = false;
+      obj.map = uuo_stage_index_map(p, false);
+      obj.n = obj.n_full;
+      sh.off = sh.off_x;
+    }
+  }
+  std::memset(stats, 0, sizeof(*stats));
+  return lbfgs_run(w, s, obj, d_x, opt, stats, cb, cb_user, &sh);
+}
+
+// ---------------------------------------------------------------------------------------------------- host-composed closures
+struct CallbackObjective : Objective {
+  uuo_closure_fn fn = nullptr;
+  void* user = nullptr;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*, const UuoEvalReport*) override {
+    const int rc = fn(user, (void*)s, x, loss_dev, grad);
+    if (rc) {
+      uuo_set_error("uuo_lbfgs_minimize: the closure returned " + std::to_string(rc));
+      return rc < 0 ? rc : -rc;
+    }
+    return 0;
+  }
+};
+
+extern "C" int uuo_lbfgs_minimize(void* stream, int n, float* d_x, const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats,
+                                  uuo_closure_fn closure, void* user, uuo_eval_callback_t cb, void* cb_user) {
+  UUO_REQUIRE(d_x && opt && stats && closure && n > 0, "uuo_lbfgs_minimize: bad arguments");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_minimize: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_lbfgs_minimize: not inside a lock-step batch");
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = nullptr;
+  int rc = lbws_create(n, hist, &w);
+  if (rc) return rc;
+  CallbackObjective obj;
+  obj.fn = closure;
+  obj.user = user;
+  obj.n = n;
+  std::memset(stats, 0, sizeof(*stats));
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, cb, cb_user);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  lbws_destroy(w);
+  return rc;
+}
+
+// the 2D-prior fit (reprojection.hip) under the same driver
+struct ReprojObjective : Objective {
+  uuo_reprojection* h = nullptr;
+  float* x_last = nullptr;
+  float* kp_last = nullptr;
+  int eval(hipStream_t s, const float* x, float* loss_dev, float* grad, const float*, double*, const UuoEvalReport*) override {
+    if (x_last) UUO_HIP_CHECK(hipMemcpyAsync(x_last, x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return uuo_reprojection_eval_impl(h, s, x, loss_dev, grad, kp_last, nullptr);
+  }
+};
+
+extern "C" int uuo_reprojection_solve(uuo_reprojection_t* h, void* stream, float* d_x, const uuo_lbfgs_options_t* opt,
+                                      uuo_lbfgs_stats_t* stats, float* d_x_last, float* d_kp_last, uuo_eval_callback_t cb,
+                                      void* cb_user) {
+  UUO_REQUIRE(h && d_x && opt && stats, "uuo_reprojection_solve: null argument");
+  UUO_REQUIRE(opt->max_iter > 0, "uuo_reprojection_solve: max_iter must be positive");
+  UUO_REQUIRE(uuo_recorder == nullptr, "uuo_reprojection_solve: not inside a lock-step batch");
+  const int n = uuo_reprojection_num_params(&h->p);
+  const int hist = opt->history_size > 0 ? opt->history_size : 100;
+  LbWs* w = nullptr;
+  int rc = lbws_create(n, hist, &w);
+  if (rc) return rc;
+  ReprojObjective obj;
+  obj.h = h;
+  obj.n = n;
+  obj.x_last = d_x_last;
+  obj.kp_last = d_kp_last;
+  std::memset(stats, 0, sizeof(*stats));
+  rc = lbfgs_run(w, (hipStream_t)stream, obj, d_x, opt, stats, cb, cb_user);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  lbws_destroy(w);
+  return rc;
+}
+
+extern "C" int uuo_copy_device(void* stream, void* d_dst, const void* d_src, size_t bytes) {
+  UUO_REQUIRE(d_dst && d_src, "uuo_copy_device: null argument");
+  if (bytes) UUO_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n) {
+  UUO_REQUIRE(d_src && h_dst && n >= 0, "uuo_copy_to_host: bad arguments");
+  UUO_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  UUO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+

@@ -490,7 +490,11 @@ __device__ __forceinline__ void sk2_unit_addresses(Sk2Epi& E, const Sk2Unit& P, 
   E.bo = (__umul24(f0, n24) + (unsigned)P.u * 24u) | (j == 0 ? 0u : 0x80000000u);
 }
 
-__device__ unsigned long long g_sk2_stamps[2048 * 16];  // debug (UUO_SK2_VAR=9): per-wave shader-clock stamps
+#ifdef UUO_DEBUG_HOOKS
+__device__ unsigned long long g_sk2_stamps[2048 * 16];  // debug flavour (UUO_SK2_VAR=9): per-wave shader-clock stamps
+#else
+__device__ unsigned long long g_sk2_stamps[16];  // product: only the VAR = 0 instantiations exist, nothing ever indexes this
+#endif
 
 template <bool BBOX, int VAR>
 __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_skin2(const float4* __restrict__ P3v, const float* __restrict__ vt3,

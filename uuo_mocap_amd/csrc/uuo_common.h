@@ -154,7 +154,7 @@ struct uuo_fit {
   float* mask = nullptr;            // [F][M] 0/1
   float* scalars = nullptr;         // device scalars block (see solver)
   float* vecs = nullptr;            // one work vector of n_max floats (timing helper gradient)
-  void* lbws = nullptr;             // L-BFGS workspace (solver.hip), created on first solve
+  void* lbws = nullptr;             // L-BFGS workspace (lbfgs_driver.hip), created on first solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float mask_sum = 0.f;  // host copy of sum(mask) (chamfer normaliser), refreshed by uuo_ensure_mask
   bool shared_pose_cache = false;  // pose_cache belongs to a uuo_batch (not freed with the fit)
@@ -240,7 +240,7 @@ struct UuoIndexMap {
 int uuo_stage_compactable(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const float* d_x, bool* compact);
 UuoIndexMap uuo_stage_index_map(const uuo_problem_t* p, bool compact);
 
-// ---- lock-step batches (uuo_batch_*: solver.hip) ------------------------------------------------------------------------
+// ---- lock-step batches (uuo_batch_*: batch.hip) ------------------------------------------------------------------------
 // Every kernel of the solve path exists in two launch forms over ONE device body: k_X(XArgs) for a single problem and
 // k_X_b(const XArgs* batch) where blockIdx.z picks the problem (blocks outside a problem's own grid extent exit at once).
 // While a batch is being stepped, launches are not issued but RECORDED per problem (uuo_recorder != nullptr); the

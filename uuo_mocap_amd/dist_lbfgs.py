@@ -10,7 +10,7 @@ of ONE subject fitted together with a single shape vector.  That is one joint L-
 with loss sum_r loss_r(x_r, shared).  Rank r stores only ``[x_r | shared]``; ``shared`` is replicated and kept bit-identical
 on every rank.  The algorithm is torch.optim.LBFGS(line_search_fn="strong_wolfe") (torch 2.10: history push iff y.s > 1e-10,
 H_diag = y.s / y.y, first step min(1, 1/|g|_1) lr, bracket / zoom with the insufficient-progress rule, max_ls = max_eval -
-evals, termination tests in torch's order) -- the same mirror as the device driver (csrc/solver.hip), evaluated the same way:
+evals, termination tests in torch's order) -- the same mirror as the device driver (csrc/lbfgs_driver.hip), evaluated the same way:
 in COEFFICIENT SPACE from Gram matrices of the (s, y) history, so an iteration needs a fixed, small number of collectives
 instead of 2 x history dependent dot products:
 
@@ -19,7 +19,7 @@ instead of 2 x history dependent dot products:
 * per iteration ONE ``all_gather`` of the new Gram row / column (``5 k + 4`` doubles) and one of ``max|d|``.
 
 Since round 3 this Python driver is the CHECKER: the product path (engine._StageProblem.solve_shared) runs the joint problem
-on the device solver itself (csrc/solver.hip, ``uuo_lbfgs_solve_shared``: one gather per evaluation, one per iteration,
+on the device solver itself (csrc/lbfgs_driver.hip, ``uuo_lbfgs_solve_shared``: one gather per evaluation, one per iteration,
 through ``Reducer.gather_array``); tests compare the two.
 
 Messages are < 1 KB: latency-bound, the 7 x 153 GB/s xGMI links of an MI355X node are irrelevant here.  Every
