@@ -86,6 +86,10 @@ def parse():
                     help="modes shared_betas / frames: process groups (gloo) for the yaw hypotheses, so that the hypotheses of a "
                          "fit run concurrently although every solve is a collective (one lane per hypothesis index); 0 = one "
                          "hypothesis after the other on the default group")
+    ap.add_argument("--collective-transport", default="auto", choices=["auto", "shm", "gloo", "rccl"],
+                    help="modes shared_betas / frames: what carries the 17 doubles a closure evaluation exchanges -- shm = the "
+                         "node-local shared-memory mailbox (csrc/mailbox.hip; auto picks it when all ranks are on one host), "
+                         "gloo / rccl = torch.distributed all_gather on process groups of that backend")
     ap.add_argument("--hypothesis-lockstep", action="store_true",
                     help="step the yaw hypotheses as one lock-step batch instead of one host thread + stream each "
                          "(multimodal_video_mocap(execution={'hypothesis_lockstep': True}); same results)")
@@ -94,6 +98,8 @@ def parse():
 
 MODE = "sequences"
 LANES = 0
+TRANSPORT = "auto"
+REDUCERS = []
 
 
 def fit_once(smpl, seq, cfg, dev):
@@ -106,10 +112,13 @@ def fit_once(smpl, seq, cfg, dev):
     if MODE == "hypotheses":
         ctx = parallel.shard_hypotheses()
     elif MODE == "shared_betas":
-        ctx = parallel.shared_betas(device=dev, lanes=LANES)
+        ctx = parallel.shared_betas(device=dev, lanes=LANES, transport=TRANSPORT)
     elif MODE == "frames":
-        ctx = parallel.shard_frames(device=dev, lanes=LANES)
-    with ctx:
+        ctx = parallel.shard_frames(device=dev, lanes=LANES, transport=TRANSPORT)
+    with ctx as handle:
+        red = getattr(handle, "reducer", handle)
+        if red is not None and hasattr(red, "stats") and red not in REDUCERS:
+            REDUCERS.append(red)
         out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
                                      save_stages=False, smpl_inference=smpl)
     return out, copy.deepcopy(dict(last_run_stats()))
@@ -300,10 +309,13 @@ def packaged_cfg_full():
 
 
 def main():
-    global MODE, LANES
+    global MODE, LANES, TRANSPORT
     args = parse()
     MODE = args.mode
     LANES = args.collective_lanes
+    TRANSPORT = args.collective_transport
+    if TRANSPORT in ("gloo", "rccl"):
+        TRANSPORT = "group"   # torch.distributed all_gather on the group's own backend (nccl = RCCL unless the ranks share a GPU)
     if MODE != "sequences":
         args.inflight = 1  # both modes issue collectives from the fitting thread: one sequence at a time per rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -387,6 +399,7 @@ def main():
         fit_many(seqs[:args.warmup], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight, device=dev,
                  wait_policy=fit_wait)
         barrier()
+        coll0 = [r_.stats() for r_ in REDUCERS]
         cg0 = cgroup_cpu_stat()
         t0 = time.perf_counter()
         fits = fit_many(seqs[args.warmup:n_seq], lambda sq: fit_once(smpl, sq, cfg, dev), inflight=args.inflight,
@@ -394,6 +407,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         cg1 = cgroup_cpu_stat()
+        coll1 = [r_.stats() for r_ in REDUCERS]
     all_stats = [st for _, st in fits]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -411,6 +425,14 @@ def main():
         q_mean = {k: float(np.mean([g[0][k] for g in gathered])) for k in q_mean}
         q_worst = {k: float(np.max([g[1][k] for g in gathered])) for k in q_worst}
 
+    # host side of every rank's timed region (its own cgroup view; ranks of one box share one quota)
+    host_mine = {"rank": rank, "torch_threads": host_threads,
+                 "cpu_seconds_timed": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 if cg0 else None,
+                 "nr_throttled_timed": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 else None}
+    host_all = [host_mine]
+    if world > 1:
+        host_all = [None] * world
+        dist.all_gather_object(host_all, host_mine)
     if rank == 0:
         n_eval = eval_counts(all_stats[-1])
         total_evals = sum(sum(eval_counts(s).values()) for s in all_stats)
@@ -457,8 +479,16 @@ def main():
                      "cpu_seconds_timed": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 if cg0 else None,
                      "nr_throttled_timed": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 else None,
                      "throttled_seconds_timed": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6
-                     if cg0 else None},
+                     if cg0 else None,
+                     "per_rank": host_all if world > 1 else None},
         }
+        if MODE in ("shared_betas", "frames"):
+            n_g = sum(b_["gathers"] - a_["gathers"] for a_, b_ in zip(coll0, coll1))
+            t_g = sum(b_["seconds"] - a_["seconds"] for a_, b_ in zip(coll0, coll1))
+            result["collective"] = {
+                "transport": type(REDUCERS[0]).__name__ if REDUCERS else None, "lanes": LANES,
+                "gathers_timed": n_g, "mean_gather_us": 1e6 * t_g / n_g if n_g else None,
+                "note": "rank 0's time inside gathers (message copy + waiting for the slowest rank) over the timed fits"}
         if world == 1 and MODE == "sequences":
             # latency of ONE sequence alone on the GPU (--inflight 1) beside the throughput headline (three in flight)
             n_lat = min(3, args.steps)

@@ -194,7 +194,7 @@ int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float*
  * (same stage) per rank, as ONE joint L-BFGS problem whose 10 betas are shared by all ranks' sequences.  Each rank keeps its
  * own parameters and a replica of the betas on its own device; the driver is uuo_lbfgs_solve's, and all that crosses the
  * ranks goes through `gather` -- called on the host, from the calling thread, at the same points on every rank:
- *   once at the start (the betas themselves: rank 0's values win), once per closure evaluation (16 doubles: loss, g.d,
+ *   once at the start (the betas themselves: rank 0's values win), once per closure evaluation (16 doubles + a status word: loss, g.d,
  *   gradient norms of the rank's own parameters, max|d|, its 10 betas-gradient entries) and once per iteration (the new
  *   Gram rows of the history, 627 doubles).  `gather(user, mine, n, all)` must fill all[r*n .. r*n+n) with rank r's `mine`
  *   for r = 0..world-1 (an all_gather: RCCL / gloo through torch.distributed in the Python mirror) and return 0.  Every rank
@@ -209,6 +209,17 @@ typedef struct {
 int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
                            const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
                            uuo_eval_callback_t cb, void* cb_user);
+
+/* Node-local transport for uuo_shared_t.gather: a mailbox in POSIX shared memory (csrc/mailbox.hip).  One table per
+ * concurrent lane of solves (name: "/something", the same on every rank; rank 0 creates it, the others wait for it);
+ * uuo_mailbox_gather is a uuo_gather_fn whose `user` is the mailbox: rank r copies its message into its row and reads the
+ * other rows as their sequence words arrive -- no system call, collective library or interpreter on the path of the
+ * 17 doubles a closure evaluation exchanges.  Messages are <= 640 doubles.  `timeout_s` (<= 0: 120 s) bounds every wait. */
+typedef struct uuo_mailbox uuo_mailbox_t;
+int uuo_mailbox_open(const char* name, int32_t rank, int32_t world, double timeout_s, uuo_mailbox_t** out);
+int uuo_mailbox_close(uuo_mailbox_t* mb);
+int uuo_mailbox_gather(void* mailbox, const double* mine, int n, double* all);
+int uuo_mailbox_stats(uuo_mailbox_t* mb, unsigned long long* gathers, unsigned long long* nanoseconds);
 
 /* The same driver for a closure composed on the host (the reference's optional objectives: the 2D reprojection fit,
  * utils/hmr_utils.py:170-425 (step at :367) -- which also has a fused closure of its own, uuo_reprojection_* above; the chamfer / marker / part stages with velocity, ground, foot-contact,

@@ -292,6 +292,11 @@ def test_batch_staging_state_machine():
     # error exit / end of a solve: everything was synchronised
     r = _staging([(FLUSH, 0, 100), (FLUSH, 1, 100), (SYNCED, 0, 0), (FLUSH, 0, 100), (FLUSH, 1, 100)])
     assert [x[0] for x in r] == [0, 0, 0, 0, 0]
+    # ... and nothing is held any more: score calls that follow each other with nothing to flush in between must
+    # not keep appending behind the previous call's structs until the region overflows
+    r = _staging([(FLUSH, 0, 1000), (APPEND, 0, 300), (SYNCED, 0, 0), (FLUSH, 0, 0), (APPEND, 0, 300), (SYNCED, 0, 0),
+                  (FLUSH, 0, 0), (APPEND, 0, 300)], region_cap=2048)
+    assert r[2][3] == 0 and r[4][:2] == (1, 0) and r[7][:2] == (1, 0)
 
 
 def test_model_with_dense_skin_weights_is_refused():

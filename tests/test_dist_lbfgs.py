@@ -168,3 +168,72 @@ def test_gather_hook_of_the_device_solver_over_gloo(tmp_path):
         assert np.array_equal(table, res[1][key])
         for r in range(world):
             assert np.array_equal(table[r], np.arange(n, dtype=np.float64) + 1000.0 * r + 0.25 * rep)
+
+
+def _mailbox_main(rank, world, port, out_dir):
+    import ctypes
+
+    import torch.distributed as dist
+
+    from uuo_mocap_amd import parallel
+    from uuo_mocap_amd.dist_lbfgs import ShmReducer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert parallel.ensure_process_group(None) == (rank, world)   # no pre-initialised group: the helper brings up gloo
+    try:
+        red = parallel._default_reducer(None, None, "auto")       # one host -> the shared-memory mailbox
+        assert isinstance(red, ShmReducer) and (red.rank, red.world) == (rank, world)
+        assert parallel._default_reducer(None, None, "auto") is red
+        fn, user = red.native()                                     # what engine.solve_shared hands to the C driver
+        got = {}
+        for rep in range(50):
+            for n in (11, 17, 628):                                 # betas, evaluation statistics, Gram rows (+ status word)
+                mine = (np.arange(n, dtype=np.float64) + 1000.0 * rank + 0.25 * rep)
+                out = np.full((world, n), np.nan)
+                rc = fn(user, mine.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n,
+                        out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+                assert rc == 0
+                got[(rep, n)] = out
+        # a long vector (frame blocks after a solve) is cut into mailbox-sized messages; lanes are independent tables
+        big = np.arange(5000, dtype=np.float64) * (rank + 1)
+        out = np.empty((world, 5000))
+        red.gather_array(big, out)
+        got["big"] = out
+        lanes = red.fork(3)
+        got["lane"] = lanes[2].gather([float(rank), 7.0])
+        # the sharded Python driver over the mailbox: same joint solve as over gloo
+        x, st, _ = _sharded_solve(rank, world, red, 40, 1.0)
+        got["st"], got["x"] = st, x
+        torch.save(got, os.path.join(out_dir, "mb%d.pt" % rank))
+        dist.barrier()
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_memory_mailbox_two_ranks(tmp_path):
+    """The node-local transport of the shared solves (csrc/mailbox.hip through dist_lbfgs.ShmReducer; no GPU involved): two
+    processes, the C function pointer called the way the device driver calls it, every message length of a solve, 150
+    gathers in a row (the two-slot rows must never be overwritten before both ranks have read them), a long vector, a
+    forked lane, and the Python checker's joint solve over it."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29500 + ((os.getpid() + 13) % 2000)
+    mp.spawn(_mailbox_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "mb%d.pt" % r), weights_only=False) for r in range(world)]
+    for key, table in res[0].items():
+        if not isinstance(key, tuple):
+            continue
+        rep, n = key
+        assert np.array_equal(table, res[1][key])
+        for r in range(world):
+            assert np.array_equal(table[r], np.arange(n, dtype=np.float64) + 1000.0 * r + 0.25 * rep)
+    for r in range(world):
+        assert np.array_equal(res[r]["big"][1], np.arange(5000, dtype=np.float64) * 2)
+        assert res[r]["lane"].tolist() == [[0.0, 7.0], [1.0, 7.0]]
+    assert res[0]["st"] == res[1]["st"]
+    assert torch.equal(res[0]["x"][N_LOCAL:], res[1]["x"][N_LOCAL:])
+    x_ref, losses_ref, n_iter_ref = _torch_reference(world, 40, 1.0)
+    joint = torch.cat([res[0]["x"][:N_LOCAL], res[1]["x"][:N_LOCAL], res[0]["x"][N_LOCAL:]])
+    np.testing.assert_allclose(joint.numpy(), x_ref.numpy(), atol=5e-5)

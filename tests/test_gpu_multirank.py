@@ -104,8 +104,14 @@ def _rank_main(rank, world, port, out_dir):
         # on their threads, every lane ordered by its own thread -- the same solves, so the same results bit for bit
         with parallel.shard_frames(device=dev, lanes=4):
             out["frames_lanes"] = _fit(smpl, seqs[0], cfg, dev)
-        with parallel.shared_betas(device=dev, lanes=4):
+        with parallel.shared_betas(device=dev, lanes=4) as red4:
             out["shared_lanes"] = _fit(smpl, same_subject[rank], cfg, dev)
+            out["shared_transport"] = type(red4).__name__
+        # (6b) the transports carry the same rank-ordered tables: the node-local mailbox (the default on one host) and
+        # torch.distributed's all_gather on the group itself give the same solves bit for bit
+        with parallel.shared_betas(device=dev, lanes=4, transport="gloo") as redg:
+            out["shared_lanes_gloo"] = _fit(smpl, same_subject[rank], cfg, dev)
+            out["shared_transport_gloo"] = type(redg).__name__
         # (7) the batch runner with all ranks on every sequence (--rank_mode frames): rank 0 writes, both take part
         from uuo_mocap_amd import runner
         from uuo_mocap_amd.config import CONFIG_DIR
@@ -230,6 +236,8 @@ def test_two_ranks_sequences_hypotheses_and_shared_betas(tmp_path):
         for k in ("trans", "pose_body", "betas", "root_orient", "yaw_scores"):
             assert np.array_equal(res[r]["frames_lanes"][k], res[r]["frames"][k]), ("frames", r, k)
             assert np.array_equal(res[r]["shared_lanes"][k], res[r]["shared"][k]), ("shared", r, k)
+            assert np.array_equal(res[r]["shared_lanes_gloo"][k], res[r]["shared"][k]), ("shared over gloo", r, k)
+    assert res[0]["shared_transport"] == "ShmReducer" and res[0]["shared_transport_gloo"] == "DistReducer"
 
 
 @pytest.mark.parametrize("stage", ["chamfer", "marker"])
@@ -267,3 +275,114 @@ def test_shared_betas_with_one_rank_is_the_device_driver_bit_for_bit(stage):
     assert abs(sa["n_iter"] - sc["n_iter"]) <= 2, (sa, sc)
     assert sa["first_loss"] == pytest.approx(sc["first_loss"], rel=1e-6)
     assert sc["final_loss"] == pytest.approx(sa["final_loss"], rel=0.1), (sa, sc)  # 40 iterations: the trajectories have parted
+
+
+def _nccl_one_rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dev = torch.device("cuda:0")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)   # "nccl" IS RCCL on ROCm
+    try:
+        from uuo_mocap_amd import parallel
+        from uuo_mocap_amd.dist_lbfgs import DistReducer
+        from uuo_mocap_amd.engine import ChamferProblem
+        from uuo_mocap_amd.synthetic import make_sequence
+
+        dev, tables, cfg, smpl = _setup()
+        out = {"backend": dist.get_backend()}
+        seq = make_sequence(tables, seed=81, num_frames=F, num_markers=M)
+        markers = torch.from_numpy(seq.markers.get_points()).float().to(dev)
+        o_pose = seq.img_smpl.pose_body.to(dev)
+        o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+        prob = ChamferProblem(smpl, markers, o_pose, o_betas, seq.img_smpl.root_orient.to(dev), cfg)
+        x0 = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas, o_pose)
+        red = DistReducer(None, dev)
+        out["reducer_device"] = str(red.device)
+        xa, xb = x0.clone(), x0.clone()
+        la, lb = [], []
+        sa = prob.solve(xa, max_iter=40, lr=0.1, callback=lambda i, l: la.append(l))
+        sb = prob.solve_shared(xb, red, max_iter=40, lr=0.1, callback=lambda i, l: lb.append(l))
+        out["solve"] = (sa, sb, la == lb, bool(torch.equal(xa, xb)))
+        # whole fits: the two collective modes with lanes = 0, i.e. every gather on the RCCL communicator of the default group
+        out["alone"] = _fit(smpl, seq, cfg, dev)
+        with parallel.shared_betas(device=dev, lanes=0, transport="rccl") as r1:
+            out["shared"] = _fit(smpl, seq, cfg, dev)
+            out["shared_reducer"] = (type(r1).__name__, str(r1.device))
+        with parallel.shard_frames(device=dev, lanes=0, transport="rccl"):
+            out["frames"] = _fit(smpl, seq, cfg, dev)
+        torch.save(out, os.path.join(out_dir, "nccl.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_device_branch_of_the_exchange(tmp_path):
+    """SURVEY 8e / north_star: the shared-beta exchange over RCCL.  One GPU box cannot hold two RCCL ranks, but a
+    world-size-1 "nccl" group CAN be created on it: every gather of a shared solve then goes through
+    all_gather_into_tensor on device buffers of the RCCL communicator (DistReducer's device branch: the code a multi-GPU node
+    runs), and with one rank the result must BE uuo_lbfgs_solve, bit for bit -- as a single joint solve and as whole fits in
+    both collective modes (shared betas, frame blocks) with the hypotheses serial on the default group (lanes = 0)."""
+    import torch.multiprocessing as mp
+
+    port = 29500 + ((os.getpid() + 31) % 2000)
+    mp.spawn(_nccl_one_rank_main, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(os.path.join(str(tmp_path), "nccl.pt"), weights_only=False)
+    assert out["backend"] == "nccl" and out["reducer_device"].startswith("cuda")
+    sa, sb, same_losses, same_x = out["solve"]
+    assert (sa["n_iter"], sa["n_eval"], sa["stop_reason"]) == (sb["n_iter"], sb["n_eval"], sb["stop_reason"]), (sa, sb)
+    assert same_losses and same_x and sa["n_iter"] >= 30
+    assert out["shared_reducer"][0] == "DistReducer" and out["shared_reducer"][1].startswith("cuda")
+    for mode in ("shared", "frames"):
+        for k in ("trans", "pose_body", "betas", "root_orient", "yaw_scores"):
+            assert np.array_equal(out[mode][k], out["alone"][k]), (mode, k)
+        assert all("world=1" in d for d in out[mode]["chamfer_driver"]), out[mode]["chamfer_driver"]
+
+
+def _runner_cli_main(rank, world, port, root, cfg_path):
+    # what `torchrun -m uuo_mocap_amd.runner` gives a rank: the launcher's environment and NOTHING initialised
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), UUO_SHARE_GPU="1")
+    import contextlib
+    import io
+
+    import torch.distributed as dist
+
+    from uuo_mocap_amd import runner
+
+    assert not dist.is_initialized()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        runner.main(["--config", cfg_path, "--dataset", "moyo_val", "--input_dir", root, "--rank_mode", "frames",
+                     "--print_options"])
+    assert dist.is_initialized() and dist.get_world_size() == world
+    with open(os.path.join(root, "cli%d.txt" % rank), "w") as fh:
+        fh.write(buf.getvalue().strip().splitlines()[-1])
+    dist.destroy_process_group()
+
+
+def test_runner_cli_brings_up_its_own_process_group(tmp_path):
+    """`--rank_mode frames` from the command line (no process group initialised by the caller) must create the
+    group itself -- it used to fall back to every rank fitting the whole sequence on its own and discarding the result."""
+    import torch.multiprocessing as mp
+
+    from uuo_mocap_amd import runner
+    from uuo_mocap_amd.body_model import synthetic_smpl
+    from uuo_mocap_amd.config import CONFIG_DIR
+    from uuo_mocap_amd.synthetic import make_sequence
+
+    root = str(tmp_path)
+    d = os.path.join(root, "moyo_val", "mocap", "subj")
+    os.makedirs(d, exist_ok=True)
+    seq = make_sequence(synthetic_smpl(0), seed=41, num_frames=F, num_markers=M)
+    runner.write_sequence_npz(os.path.join(d, "seq0.npz"), seq.markers.get_points(), 30.0, seq.img_smpl.pose_body,
+                              seq.img_smpl.root_orient, seq.img_smpl.betas)
+    cfg_path = os.path.join(root, "cfg.yaml")
+    with open(cfg_path, "w") as fh:
+        fh.write("parent: %s\nname: unit\nstages:\n  part:\n    num_iters: 6\n  chamfer:\n    num_iters: 6\n"
+                 "  marker:\n    num_iters: 6\n" % os.path.join(CONFIG_DIR, "video_mocap.yaml"))
+    port = 29500 + ((os.getpid() + 57) % 2000)
+    mp.spawn(_runner_cli_main, args=(2, port, root, cfg_path), nprocs=2, join=True)
+    assert os.path.isfile(os.path.join(root, "moyo_val", "results", "unit", "subj", "seq0_stageii.npz"))
+    assert open(os.path.join(root, "cli0.txt")).read() == "wrote 1 sequence(s)"
+    assert open(os.path.join(root, "cli1.txt")).read() == "wrote 0 sequence(s)"

@@ -97,6 +97,10 @@ _SIGNATURES = {
     "uuo_reprojection_solve": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(UuoLbfgsOptions), POINTER(UuoLbfgsStats),
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "uuo_set_wait_policy": (c_int, [c_int, c_int]),
+    "uuo_mailbox_open": (c_int, [c_char_p, c_int32, c_int32, ctypes.c_double, POINTER(c_void_p)]),
+    "uuo_mailbox_close": (c_int, [c_void_p]),
+    "uuo_mailbox_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "uuo_mailbox_stats": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong), POINTER(ctypes.c_ulonglong)]),
     "uuo_copy_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "uuo_batch_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "uuo_batch_destroy": (c_int, [c_void_p]),

@@ -234,7 +234,8 @@ struct SharedCtx {
   int rank = 0, world = 1;
   int off = 0, cnt = 0;     // the shared entries in the SOLVER's packing (gradient, direction, dot products)
   int off_x = 0;            // and in the parameter vector
-  std::vector<double> all;  // gather target
+  std::vector<double> all;  // gather target [world][n]
+  std::vector<double> send, recv;  // the messages with their status words
 };
 
 int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats,

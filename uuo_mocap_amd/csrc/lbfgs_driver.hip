@@ -141,14 +141,35 @@ struct LbHostOut {  // mirror of the tail of LbDev read back after every closure
 
 thread_local void (*g_batch_yield)(void) = nullptr;
 
-static int shared_gather(SharedCtx* sh, const double* mine, int n) {
-  sh->all.resize((size_t)sh->world * n);
-  const int rc = sh->gather(sh->user, mine, n, sh->all.data());
+// One gather of a shared solve.  Every message carries a status word behind its `n` values: a rank whose evaluation failed
+// (closure error, report time-out, a failing hook on its side) still takes part -- with status != 0 and no data -- so that
+// its peers leave the solve with the same error instead of waiting in their next gather for a rank that has gone (ADVICE r3:
+// a one-rank failure used to become a multi-minute hang of the whole job).  sh->all = [world][n], rank order.
+static int shared_gather(SharedCtx* sh, const double* mine, int n, int status = 0) {
+  std::vector<double>& send = sh->send;
+  std::vector<double>& recv = sh->recv;
+  send.assign((size_t)n + 1, 0.0);
+  if (mine && status == 0) std::memcpy(send.data(), mine, sizeof(double) * (size_t)n);
+  send[n] = (double)status;
+  recv.resize((size_t)sh->world * (n + 1));
+  const int rc = sh->gather(sh->user, send.data(), n + 1, recv.data());
   if (rc) {
     uuo_set_error("uuo_lbfgs_solve_shared: the gather hook returned " + std::to_string(rc));
     return rc < 0 ? rc : -rc;
   }
-  return 0;
+  sh->all.resize((size_t)sh->world * n);
+  for (int r = 0; r < sh->world; ++r) {
+    const double* row = recv.data() + (size_t)r * (n + 1);
+    if (row[n] != 0.0) {
+      if (r != sh->rank)
+        uuo_set_error("uuo_lbfgs_solve_shared: rank " + std::to_string(r) + " left the solve with code " +
+                      std::to_string((int)row[n]));
+      const int code = (int)row[n];
+      return status ? status : (code < 0 ? code : -code);
+    }
+    std::memcpy(sh->all.data() + (size_t)r * n, row, sizeof(double) * (size_t)n);
+  }
+  return status;  // (non-zero only when this rank itself reported a failure and no peer had one)
 }
 
 int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfgs_options_t* opt,
@@ -214,6 +235,7 @@ int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfg
       rep.seq = ++w->seq;
     }
     int rc = obj.eval(s, x_eval, w->loss_dev, gv, dir, obj.fused_stats ? stats_dev : nullptr, poll ? &rep : nullptr);
+    if (rc && sh) return shared_gather(sh, nullptr, 6 + sh->cnt, rc);  // tell the peers waiting in this evaluation's gather
     if (rc) return rc;
     if (batched) {  // the batch scheduler issues the recorded launches of all its problems and waits for their reports
       UUO_REQUIRE(poll && g_batch_yield, "lbfgs: a lock-step batch needs the polled report path");
@@ -232,7 +254,7 @@ int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfg
           const hipError_t q = hipStreamQuery(s);
           if (q != hipErrorNotReady && __atomic_load_n(&rep_words[10], __ATOMIC_ACQUIRE) != rep.seq) {
             uuo_set_error(std::string("lbfgs: closure evaluation did not report: ") + hipGetErrorString(q));
-            return -5;
+            return sh ? shared_gather(sh, nullptr, 6 + sh->cnt, -5) : -5;
           }
           timespec t_now;
           clock_gettime(CLOCK_MONOTONIC, &t_now);
@@ -240,7 +262,7 @@ int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfg
           if (waited > eval_timeout_s) {
             uuo_set_error("lbfgs: closure evaluation " + std::to_string(evals_total) + " did not finish within " +
                           std::to_string((int)eval_timeout_s) + " s (stream still busy); giving up on the solve");
-            return -62;  // -ETIME
+            return sh ? shared_gather(sh, nullptr, 6 + sh->cnt, -62) : -62;  // -ETIME
           }
         }
       }
@@ -382,7 +404,7 @@ int lbfgs_run(LbWs* w, hipStream_t s, Objective& obj, float* d_x, const uuo_lbfg
               const double waited = (double)(t_now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(t_now.tv_nsec - t_start.tv_nsec);
               if ((q != hipErrorNotReady && __atomic_load_n(rw, __ATOMIC_ACQUIRE) != rseq) || waited > eval_timeout_s) {
                 uuo_set_error(std::string("lbfgs: the Gram rows of a shared solve did not arrive: ") + hipGetErrorString(q));
-                return -5;
+                return shared_gather(sh, nullptr, LB_ROWS * 3, -5);
               }
             }
           }

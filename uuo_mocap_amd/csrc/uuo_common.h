@@ -321,7 +321,12 @@ struct UuoStaging {
     return true;
   }
   void report_arrived(int r) { pending[r] = false; }  // a kernel enqueued after the region's copy has reported
-  void synchronized() { pending[0] = pending[1] = false; }  // every stream that used the blob has been synchronised
+  // every stream that used the blob has been synchronised (a sequence of uuo_batch_part_scores calls with no solve in
+  // between would otherwise keep appending behind `used` until the region overflowed)
+  void synchronized() {
+    pending[0] = pending[1] = false;
+    used[0] = used[1] = 0;
+  }
 };
 
 #define UUO_BATCH_PICK(ArgsT, batch)                                      \

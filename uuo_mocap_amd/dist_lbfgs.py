@@ -52,6 +52,91 @@ class LocalReducer:
         return [self] * int(n)
 
 
+class ShmReducer:
+    """Ranks of ONE node: the gathers go through a mailbox in POSIX shared memory (csrc/mailbox.hip, uuo_mailbox_*): rank r
+    copies its block into its row of a shared table and reads the other rows as their sequence words arrive.  The device
+    solver calls the mailbox directly (`native()`: a C function pointer + handle -- no Python callback, no interpreter lock,
+    no collective library on the path of the 17 doubles a closure evaluation exchanges); `gather_array` is the same
+    exchange for Python callers, cut into 640-double messages.  `fork(n)` = n mailboxes more (one per concurrent lane of
+    solves), created COLLECTIVELY on first use."""
+
+    MAX_DOUBLES = 640
+
+    def __init__(self, name: str, rank: int, world: int, timeout_s: float = 120.0):
+        import ctypes
+
+        from . import _lib
+
+        self._lib = _lib.load()
+        self.name, self.rank, self.world, self.timeout_s = str(name), int(rank), int(world), float(timeout_s)
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.uuo_mailbox_open(self.name.encode(), self.rank, self.world, self.timeout_s,
+                                              ctypes.byref(handle)), "uuo_mailbox_open")
+        self._handle = handle
+        self._lanes: list = []
+
+    def native(self):
+        """(gather function pointer, user pointer) for uuo_shared_t."""
+        import ctypes
+
+        from ._lib import GATHER_FN
+
+        return ctypes.cast(self._lib.uuo_mailbox_gather, GATHER_FN), self._handle
+
+    def fork(self, n: int):
+        while len(self._lanes) < int(n):
+            self._lanes.append(ShmReducer("%s_l%d" % (self.name, len(self._lanes)), self.rank, self.world, self.timeout_s))
+        return self._lanes[:int(n)]
+
+    def gather_array(self, mine: np.ndarray, out: np.ndarray) -> None:
+        from . import _lib
+
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        n = int(mine.shape[0])
+        table = np.empty((self.world, min(n, self.MAX_DOUBLES)), dtype=np.float64)
+        for lo in range(0, max(n, 1), self.MAX_DOUBLES):
+            hi = min(n, lo + self.MAX_DOUBLES)
+            part = np.ascontiguousarray(mine[lo:hi])
+            t = table[:, :hi - lo] if hi - lo == table.shape[1] else np.empty((self.world, hi - lo), dtype=np.float64)
+            _lib.check(self._lib.uuo_mailbox_gather(self._handle, part.ctypes.data, hi - lo, t.ctypes.data),
+                       "uuo_mailbox_gather")
+            out[:, lo:hi] = t
+
+    def gather(self, values: Sequence[float]) -> np.ndarray:
+        mine = np.asarray(list(values), dtype=np.float64)
+        out = np.empty((self.world, mine.shape[0]), dtype=np.float64)
+        self.gather_array(mine, out)
+        return out
+
+    def stats(self):
+        """{"gathers", "seconds"} over this mailbox and its lanes: count and time spent inside gathers (waiting for the slowest
+        rank included)."""
+        import ctypes
+
+        n, ns = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        self._lib.uuo_mailbox_stats(self._handle, ctypes.byref(n), ctypes.byref(ns))
+        out = {"gathers": int(n.value), "seconds": ns.value * 1e-9}
+        for lane in self._lanes:
+            ls = lane.stats()
+            out["gathers"] += ls["gathers"]
+            out["seconds"] += ls["seconds"]
+        return out
+
+    def close(self):
+        for lane in self._lanes:
+            lane.close()
+        self._lanes = []
+        if self._handle is not None:
+            self._lib.uuo_mailbox_close(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DistReducer:
     """Partials of every rank through ONE all_gather on a torch.distributed process group ("nccl" = RCCL on ROCm, "gloo" in
     the CPU tests); each rank then reduces the [world, n] table itself, in rank order."""
@@ -67,6 +152,7 @@ class DistReducer:
 
         self._bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._lanes: list = []
+        self._n_gathers, self._seconds = 0, 0.0
 
     def fork(self, n: int):
         """`n` reducers over the same ranks, each on a process group of its own, so that `n` host threads (the yaw hypotheses
@@ -78,7 +164,12 @@ class DistReducer:
         while len(self._lanes) < int(n):
             ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else \
                 list(range(self.dist.get_world_size()))
-            self._lanes.append(DistReducer(self.dist.new_group(ranks=ranks, backend="gloo"), torch.device("cpu")))
+            import datetime
+
+            # a peer that died must fail the collective promptly, not after gloo's 30-minute default
+            self._lanes.append(DistReducer(self.dist.new_group(ranks=ranks, backend="gloo",
+                                                               timeout=datetime.timedelta(seconds=180)),
+                                           torch.device("cpu")))
         return self._lanes[:int(n)]
 
     def gather(self, values: Sequence[float]) -> np.ndarray:
@@ -96,10 +187,23 @@ class DistReducer:
             bufs = (torch.empty(n, dtype=torch.float64, device=self.device),
                     torch.empty(self.world * n, dtype=torch.float64, device=self.device))
             self._bufs[n] = bufs
+        import time
+
+        t0 = time.perf_counter()
         local, full = bufs
         local.copy_(torch.from_numpy(mine))
         self.dist.all_gather_into_tensor(full, local, group=self.group)
         out[...] = (full.cpu() if full.is_cuda else full).numpy().reshape(self.world, n)
+        self._n_gathers += 1
+        self._seconds += time.perf_counter() - t0
+
+    def stats(self):
+        out = {"gathers": self._n_gathers, "seconds": self._seconds}
+        for lane in self._lanes:
+            ls = lane.stats()
+            out["gathers"] += ls["gathers"]
+            out["seconds"] += ls["seconds"]
+        return out
 
 
 def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):

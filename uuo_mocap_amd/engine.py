@@ -501,8 +501,11 @@ class _StageProblem:
                 failure.append(exc)
                 return 5
 
-        gather_c = GATHER_FN(gather)
-        shared = UuoShared(gather_c, None, int(reducer.rank), world)
+        if hasattr(reducer, "native"):   # the node-local mailbox: the driver calls it directly, no Python on the path
+            gather_c, user = reducer.native()
+        else:
+            gather_c, user = GATHER_FN(gather), None
+        shared = UuoShared(gather_c, user, int(reducer.rank), world)
         cb = EVAL_CALLBACK(lambda user, i, loss, d_x_eval: callback(i, loss)) if callback is not None else None
         with torch.cuda.device(self.device):
             rc = self.lib.uuo_lbfgs_solve_shared(self.fit, current_stream(self.device), byref(self.problem), _ptr(x),

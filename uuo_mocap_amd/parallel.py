@@ -5,6 +5,7 @@ timing barrier, the max-over-ranks of the elapsed time and the gather of per-seq
 from __future__ import annotations
 
 import os
+import threading
 import time
 from typing import Callable, Dict, List, Sequence
 
@@ -60,11 +61,30 @@ def limit_host_threads(reserve: int = 4) -> int:
     return torch.get_num_threads()
 
 
+_wait_lock = threading.Lock()
+_wait_app_policy = (None, 20.0)  # what the APPLICATION asked for last (spin_us, sleep_us); fit_many("auto") restores it
+_wait_auto_users = 0             # fit_many("auto") calls in progress (they share one temporary policy)
+
+
 def set_wait_policy(spin_us: float = None, sleep_us: float = 20.0) -> None:
     """How the solver's host threads wait for the GPU's evaluation reports (uuo_set_wait_policy).  `spin_us=None`: spin
     (the default: lowest latency, one CPU per solve in flight -- twelve with three sequences in flight).  Otherwise a wait
     spins for about `spin_us` microseconds and then sleeps `sleep_us` at a time: for hosts whose CPU quota is smaller than
-    the number of solves in flight.  Process-wide; call from the application."""
+    the number of solves in flight.  Process-wide; call from the application.  While a `fit_many(wait_policy="auto")` is in
+    progress the new policy takes effect when the last such call ends."""
+    global _wait_app_policy
+    with _wait_lock:
+        _wait_app_policy = (spin_us, sleep_us)
+        if _wait_auto_users == 0:
+            _apply_wait_policy(spin_us, sleep_us)
+
+
+def get_wait_policy():
+    """(spin_us, sleep_us) the application set last (spin_us None = pure spinning)."""
+    return _wait_app_policy
+
+
+def _apply_wait_policy(spin_us, sleep_us) -> None:
     from . import _lib
 
     lib = _lib.load()
@@ -73,6 +93,34 @@ def set_wait_policy(spin_us: float = None, sleep_us: float = 20.0) -> None:
     else:
         # one poll = a load + `pause` ~ 40 ns on current x86 hosts
         _lib.check(lib.uuo_set_wait_policy(int(max(0.0, spin_us) * 25), int(max(1.0, sleep_us) * 1000)), "uuo_set_wait_policy")
+
+
+def ensure_process_group(device=None):
+    """The default torch.distributed process group of a multi-rank launch (torchrun's RANK / WORLD_SIZE / MASTER_*), created
+    here when the application has not done it: "nccl" (= RCCL) bound to `device`, or "gloo" when the ranks of this host
+    share a GPU (UUO_SHARE_GPU=1 or fewer devices than local ranks -- RCCL refuses two ranks on one device).  Must run
+    before the first HIP call of a rank that is going to use RCCL.  Returns (rank, world).  A one-rank launch needs no group.
+    Raises when a multi-rank environment cannot be brought up -- the collective modes never degrade to every rank fitting
+    everything on its own."""
+    import torch.distributed as dist
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env <= 1:
+        return (0, 1)
+    if not dist.is_available():
+        raise RuntimeError("WORLD_SIZE=%d but torch.distributed is not available" % world_env)
+    if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world_env))))
+        share = os.environ.get("UUO_SHARE_GPU", os.environ.get("UUO_BENCH_SHARE_GPU", "0")) == "1" or \
+            (torch.cuda.is_available() and torch.cuda.device_count() < local_world)
+        if share or device is None or torch.device(device).type != "cuda":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    if dist.get_world_size() != world_env:
+        raise RuntimeError("process group has %d ranks, the launcher started %d" % (dist.get_world_size(), world_env))
+    return (dist.get_rank(), dist.get_world_size())
 
 
 def shard_indices(num_items: int, rank: int, world: int) -> List[int]:
@@ -146,11 +194,20 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None, 
     if inflight <= 1 or len(items) <= 1:
         return [fit_fn(it) for it in items]
     if wait_policy == "auto":
-        set_wait_policy(spin_us=10.0, sleep_us=20.0)
+        # a temporary, process-wide policy shared by every "auto" call in progress; the last one to finish restores what the
+        # application had set (it used to restore pure spinning unconditionally, and overlapping calls raced)
+        global _wait_auto_users
+        with _wait_lock:
+            if _wait_auto_users == 0:
+                _apply_wait_policy(10.0, 20.0)
+            _wait_auto_users += 1
         try:
             return fit_many(items, fit_fn, inflight, device, wait_policy="keep")
         finally:
-            set_wait_policy(spin_us=None)
+            with _wait_lock:
+                _wait_auto_users -= 1
+                if _wait_auto_users == 0:
+                    _apply_wait_policy(*_wait_app_policy)
     use_cuda = device is not None and torch.device(device).type == "cuda"
     main = torch.cuda.current_stream(device) if use_cuda else None
     free_groups = list(range(1, inflight + 1))  # group 0 stays with the calling thread
@@ -198,15 +255,37 @@ def shared_betas_reducer():
 _reducer_cache: Dict = {}
 
 
-def _default_reducer(group, device):
-    """One DistReducer per (group, device) and process: its lanes are process groups, which are not to be created per fit."""
-    from .dist_lbfgs import DistReducer, LocalReducer
+def _default_reducer(group, device, transport: str = "auto"):
+    """One reducer per (group, device, transport) and process: its lanes are shared-memory tables / process groups, which are
+    not to be created per fit.  COLLECTIVE on first use.  `transport`: "shm" = the node-local mailbox (dist_lbfgs.ShmReducer:
+    what the ranks of one node use -- the exchanged blocks are produced in and consumed from HOST memory, so host shared
+    memory is their shortest path); "rccl" / "gloo" = torch.distributed all_gather on the group itself (DistReducer: device
+    buffers over RCCL when the group's backend is nccl; ranks on several nodes); "auto" = shm when every rank of the group
+    runs on this host, else the group's own backend."""
+    from .dist_lbfgs import DistReducer, LocalReducer, ShmReducer
 
-    if _dist() is None:
+    dist = _dist()
+    if dist is None:
         return LocalReducer()
-    key = (id(group) if group is not None else 0, str(device))
+    if transport not in ("auto", "shm", "rccl", "gloo", "group"):
+        raise ValueError("unknown collective transport %r" % transport)
+    key = (id(group) if group is not None else 0, str(device), transport)
     if key not in _reducer_cache:
-        _reducer_cache[key] = DistReducer(group, device)
+        use_shm = transport == "shm"
+        if transport == "auto":
+            import socket
+
+            hosts = [None] * dist.get_world_size(group)
+            dist.all_gather_object(hosts, socket.gethostname(), group=group)
+            use_shm = len(set(hosts)) == 1
+        if use_shm:
+            import secrets
+
+            token = [secrets.token_hex(6) if dist.get_rank(group) == 0 else None]
+            dist.broadcast_object_list(token, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            _reducer_cache[key] = ShmReducer("/uuo_mb_%s" % token[0], dist.get_rank(group), dist.get_world_size(group))
+        else:
+            _reducer_cache[key] = DistReducer(group, device)
     return _reducer_cache[key]
 
 
@@ -237,7 +316,7 @@ def collective_lanes(count: int):
 
 
 @contextlib.contextmanager
-def shared_betas(group=None, device=None, reducer=None, lanes: int = 0):
+def shared_betas(group=None, device=None, reducer=None, lanes: int = 0, transport: str = "auto"):
     """EXTENSION (BASELINE configs[3]; not reference behaviour -- the reference fits every sequence with its own betas,
     SURVEY.md F12): inside this context every chamfer / marker stage solve is ONE joint L-BFGS problem over the ranks of
     `group`, the sequences of the ranks (same subject) sharing a single shape vector.  All ranks must run the same stages in
@@ -247,7 +326,7 @@ def shared_betas(group=None, device=None, reducer=None, lanes: int = 0):
     hypotheses run on their threads as usual, each ordering only its own lane.  Without an initialised process group the
     context is the one-rank case of the same driver."""
     if reducer is None:
-        reducer = _default_reducer(group, device)
+        reducer = _default_reducer(group, device, transport)
     prev = getattr(_ctx, "shared", None), getattr(_ctx, "lanes", None), getattr(_ctx, "lanes_kind", None)
     _ctx.shared = reducer
     _ctx.lanes = reducer.fork(lanes) if lanes > 0 else None
@@ -355,14 +434,14 @@ def frame_shard():
 
 
 @contextlib.contextmanager
-def shard_frames(group=None, device=None, reducer=None, lanes: int = 0):
+def shard_frames(group=None, device=None, reducer=None, lanes: int = 0, transport: str = "auto"):
     """Inside this context the chamfer and marker stage solves of a fit (optim_chamfer / optim_markers on their fused
     closures) are spread over the ranks of `group` by frame blocks (FrameShard): one sequence uses all the
     GPUs of the group.  All ranks must call the fit with the same inputs; every rank returns the full, identical result.  The
     yaw hypotheses run one after the other (every solve is a collective) unless `lanes` >= their number (see
     shared_betas).  Without an initialised process group the context is the one-rank case."""
     if reducer is None:
-        reducer = _default_reducer(group, device)
+        reducer = _default_reducer(group, device, transport)
     prev = getattr(_ctx, "frames", None), getattr(_ctx, "lanes", None), getattr(_ctx, "lanes_kind", None)
     _ctx.frames = FrameShard(reducer)
     _ctx.lanes = reducer.fork(lanes) if lanes > 0 else None

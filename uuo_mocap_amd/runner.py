@@ -185,7 +185,14 @@ def run(args, fit_fn: Optional[Callable] = None) -> int:
         if args.cpu_only or not torch.cuda.is_available():
             raise RuntimeError("uuo_mocap_amd fits on the GPU only: --cpu_only / a machine without a HIP device cannot "
                                "run the accelerated path (use the reference for CPU runs)")
-        device = torch.device("cuda:%d" % (args.gpu if args.gpu is not None else local_rank))
+        n_dev = max(torch.cuda.device_count(), 1)
+        device = torch.device("cuda:%d" % (args.gpu if args.gpu is not None else local_rank % n_dev))
+        if world > 1 and getattr(args, "rank_mode", "sequences") != "sequences":
+            # the collective modes need the process group BEFORE the first HIP call (RCCL binds to the device); without it every
+            # rank would silently fit the whole sequence on its own
+            from .parallel import ensure_process_group
+
+            ensure_process_group(device)
         torch.cuda.set_device(device)
         from .multimodal import multimodal_video_mocap
         from .smpl import SmplInference
@@ -218,6 +225,13 @@ def run(args, fit_fn: Optional[Callable] = None) -> int:
             jobs = jobs[:args.num_files + 1]  # the reference stops after file_count > num_files (test.py:145-147)
         rank_mode = getattr(args, "rank_mode", "sequences")
         together = rank_mode != "sequences" and world > 1
+        if together:
+            from .parallel import _dist
+
+            d_ = _dist()
+            if d_ is None or d_.get_world_size() != world:
+                raise RuntimeError("--rank_mode %s with WORLD_SIZE=%d needs an initialised torch.distributed process group of "
+                                   "that size (parallel.ensure_process_group)" % (rank_mode, world))
         mine = jobs if together else [jobs[i] for i in shard_indices(len(jobs), rank, world)]
 
         def one(job):
