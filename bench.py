@@ -90,6 +90,10 @@ def parse():
                     help="modes shared_betas / frames: what carries the 17 doubles a closure evaluation exchanges -- shm = the "
                          "node-local shared-memory mailbox (csrc/mailbox.hip; auto picks it when all ranks are on one host), "
                          "gloo / rccl = torch.distributed all_gather on process groups of that backend")
+    ap.add_argument("--history-size", type=int, default=0,
+                    help="EXPERIMENT ONLY (not the metric's workload): L-BFGS history of the chamfer / marker solves instead of "
+                         "torch's default 100 -- halves the bytes of the two history passes; used to measure what those passes "
+                         "cost a fit (compare frame_evals_per_s, the solves take other trajectories)")
     ap.add_argument("--hypothesis-lockstep", action="store_true",
                     help="step the yaw hypotheses as one lock-step batch instead of one host thread + stream each "
                          "(multimodal_video_mocap(execution={'hypothesis_lockstep': True}); same results)")
@@ -356,6 +360,8 @@ def main():
     cfg = packaged_config(args.config)
     if args.hypothesis_lockstep:
         cfg["execution"] = {"hypothesis_lockstep": True}
+    if args.history_size > 0:
+        cfg["optimizer"]["history_size"] = args.history_size
     smpl = SmplInference(dev, tables=tables)
     F, M = args.frames, args.markers
     n_seq = args.warmup + args.steps
@@ -460,7 +466,8 @@ def main():
             "config": {"workload": "%s.yaml full fit, F=%d frames x M=%d markers, synthetic SMPL-shaped model, one "
                                    "sequence per step per GPU" % (args.config, F, M if not limb else 10),
                        "frames": F, "markers": M, "sequences_per_gpu": args.steps,
-                       "sequences_in_flight": args.inflight, "rank_mode": MODE},
+                       "sequences_in_flight": args.inflight, "rank_mode": MODE,
+                       **({"EXPERIMENT_history_size": args.history_size} if args.history_size > 0 else {})},
             "closure_evals_per_step": total_evals / max(args.steps, 1), "closure_evals_last_step": n_eval,
             "frame_evals_per_s": world * total_evals * F / elapsed if world == 1 else None,
             "fit_quality": {"mean": q_mean, "worst": q_worst, "steps": len(quality) * world,
@@ -511,9 +518,27 @@ def main():
             # config (one yaw hypothesis)
             result["other_configs"] = {}
             n_other = min(args.steps, 4)
-            for name in ("hmr_full", "hmr_part", "mht_rotation"):
+            for name in ("hmr_full", "hmr_part", "mht_rotation", "hmr_part_soft"):
                 cfg_o = packaged_config(name)
-                limb_o = name == "hmr_part"
+                limb_o = name in ("hmr_part", "hmr_part_soft")
+                if name == "hmr_part_soft":
+                    # EXTENSION (soft-assignment data term in the part stage; operator-composed closures, one candidate after
+                    # the other): seconds per fit -- one fit, no warm-up fit of its own, no in-flight leg
+                    seq_s = make_sequence(tables, seed=1001, num_frames=F, num_markers=10, limb_only=True)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        out_s, st_s = fit_once(smpl, seq_s, cfg_o, dev)
+                        torch.cuda.synchronize(dev)
+                        dt = time.perf_counter() - t1
+                    result["other_configs"][name] = {
+                        "value": F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 1, "sequences_in_flight": 1,
+                        "markers": 10, "closure_evals_per_step": sum(eval_counts(st_s).values()),
+                        "fit_quality_mean": fit_quality(smpl, seq_s, out_s, dev),
+                        "note": "EXTENSION, not a reference configuration: hmr_part.yaml with the soft-min data term "
+                                "(stages.part.losses.soft_chamfer, soft_tau 2.5e-4 m^2); closures composed from the HIP "
+                                "operators under the device L-BFGS driver, candidates one after the other"}
+                    continue
                 seqs_o = [make_sequence(tables, seed=1000 + i, num_frames=F, num_markers=10 if limb_o else M,
                                         limb_only=limb_o) for i in range(n_other + 1)]
                 with contextlib.redirect_stdout(io.StringIO()):

@@ -531,3 +531,72 @@ def test_workspaces_are_evicted_and_memory_returns(tables, dev):
     assert _FitHandle.live == live_start
     leaked = free_start - free_bytes()
     assert leaked < 1 << 30, (leaked, used)
+
+
+@pytest.mark.parametrize("F,M,limb", [(300, 50, False), (60, 10, True)])
+def test_soft_assignment_part_term_against_the_float64_formula(smpl, oracle_smpl, tables, dev, F, M, limb):
+    """EXTENSION (BASELINE configs[2] names a soft-assignment path; the reference has none): the soft-min data term of the
+    part stage -- mean_f mean_m -tau log sum_v exp(-|x_fm - v_fv|^2 / tau) over a candidate's vertices -- on REAL skinned
+    vertices at the BASELINE size (300 x 50, the whole body) and at the size of the `hmr_part` fixture (60 x 10 on one
+    limb's vertices): value and both gradients against the float64 torch formula, and the hard term as its tau -> 0 limit."""
+    from uuo_mocap_amd.losses import chamfer_distance, soft_chamfer_distance
+
+    seq = make_sequence(tables, seed=9, num_frames=F, num_markers=M, limb_only=limb)
+    markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float()
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum())
+    out = smpl(seq.img_smpl.pose_body.to(dev), o_betas.expand(F, 10).contiguous().to(dev), seq.img_smpl.root_orient.to(dev),
+               torch.median(markers, dim=1)[0].to(dev))
+    vlabels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    joints = [16, 18, 20, 22] if limb else list(range(24))     # the left arm / the full skeleton
+    vidx = torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in joints]).to(dev)
+    tau = 2.5e-4
+    x = markers.to(dev).requires_grad_(True)
+    y = out["vertices"][:, vidx].detach().contiguous().requires_grad_(True)
+    loss = soft_chamfer_distance(x, y, tau)[0]
+    gx, gy = torch.autograd.grad(loss, (x, y))
+    ref, rgx, rgy = 0.0, [], []
+    for f0 in range(0, F, 25):   # float64, a block of frames at a time (300 x 50 x 6890 distances do not fit otherwise)
+        xd = x.detach()[f0:f0 + 25].double().cpu().requires_grad_(True)
+        yd = y.detach()[f0:f0 + 25].double().cpu().requires_grad_(True)
+        d2 = ((xd[:, :, None] - yd[:, None]) ** 2).sum(-1)
+        part = (-tau * torch.logsumexp(-d2 / tau, dim=-1)).sum(1).div(M).sum() / F
+        a, b = torch.autograd.grad(part, (xd, yd))
+        ref += float(part)
+        rgx.append(a)
+        rgy.append(b)
+    rgx, rgy = torch.cat(rgx), torch.cat(rgy)
+    assert float(loss) == pytest.approx(ref, rel=2e-5, abs=1e-9)
+    assert _rel_err(gx.cpu().double().numpy(), rgx.numpy()) < 2e-4
+    assert _rel_err(gy.cpu().double().numpy(), rgy.numpy()) < 2e-4
+    hard = float(chamfer_distance(x.detach(), y.detach(), single_directional=True)[0])
+    assert float(soft_chamfer_distance(x.detach(), y.detach(), 1e-7)[0]) == pytest.approx(hard, rel=1e-4)
+    assert float(loss) <= hard + 1e-9
+
+
+def test_soft_assignment_part_stage_end_to_end(smpl, tables, dev, record_property):
+    """EXTENSION: `hmr_part_soft.yaml` (hmr_part.yaml with the soft-min data term in the stage that configuration actually
+    runs) fits a 60 x 10 limb sequence through the reference's own orchestration -- same candidate list as the hard fit,
+    every candidate solved by the device L-BFGS on the operator-composed closure -- and lands where the hard fit lands."""
+    import copy
+
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
+
+    seq = make_sequence(tables, seed=22, num_frames=60, num_markers=10, limb_only=True)
+    outs = {}
+    for name in ("hmr_part", "hmr_part_soft"):
+        cfg = packaged_config(name)
+        outs[name] = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                            save_stages=False, smpl_inference=smpl)
+        outs[name + "_stats"] = copy.deepcopy(dict(last_run_stats()))
+    hard, soft = outs["hmr_part"], outs["hmr_part_soft"]
+    assert len(outs["hmr_part_soft_stats"]["part"]) == len(outs["hmr_part_stats"]["part"]) > 10
+    assert all("host closure" in str(s_.get("driver", "")) for s_ in outs["hmr_part_soft_stats"]["part"])
+    assert np.array_equal(np.asarray(hard["chain"]), np.asarray(soft["chain"]))
+    vh = smpl(hard["pose_body"].to(dev), hard["betas"].to(dev), hard["root_orient"].to(dev), hard["trans"].to(dev))["vertices"]
+    vs = smpl(soft["pose_body"].to(dev), soft["betas"].to(dev), soft["root_orient"].to(dev), soft["trans"].to(dev))["vertices"]
+    gap = float((vh - vs).norm(dim=-1).mean())
+    agree = float((np.asarray(hard["markers_labels"]) == np.asarray(soft["markers_labels"])).mean())
+    record_property("hmr_part_soft_vs_hard_mean_vertex_distance_m", gap)
+    record_property("hmr_part_soft_vs_hard_label_agreement", agree)
+    print("hmr_part_soft vs hmr_part: mean vertex distance %.4f m, labels equal %.2f" % (gap, agree))
+    assert np.isfinite(gap) and gap < 0.25

@@ -310,8 +310,9 @@ def _nccl_one_rank_main(rank, world, port, out_dir):
         with parallel.shared_betas(device=dev, lanes=0, transport="rccl") as r1:
             out["shared"] = _fit(smpl, seq, cfg, dev)
             out["shared_reducer"] = (type(r1).__name__, str(r1.device))
-        with parallel.shard_frames(device=dev, lanes=0, transport="rccl"):
+        with parallel.shard_frames(device=dev, lanes=0, transport="rccl", joint_with_one_rank=True):
             out["frames"] = _fit(smpl, seq, cfg, dev)
+        out["gathers"] = r1.stats()["gathers"]
         torch.save(out, os.path.join(out_dir, "nccl.pt"))
     finally:
         dist.destroy_process_group()
@@ -336,7 +337,8 @@ def test_one_rank_rccl_group_runs_the_device_branch_of_the_exchange(tmp_path):
     for mode in ("shared", "frames"):
         for k in ("trans", "pose_body", "betas", "root_orient", "yaw_scores"):
             assert np.array_equal(out[mode][k], out["alone"][k]), (mode, k)
-        assert all("world=1" in d for d in out[mode]["chamfer_driver"]), out[mode]["chamfer_driver"]
+        assert all("world=1" in d for d in out[mode]["chamfer_driver"] + out[mode]["marker_driver"]), out[mode]["chamfer_driver"]
+    assert out["gathers"] > 500   # every closure evaluation and iteration of both fits went through the communicator
 
 
 def _runner_cli_main(rank, world, port, root, cfg_path):

@@ -455,6 +455,81 @@ def test_compact_solver_packing_is_exact(smpl, dev, stage):
     assert moved > 0.5, moved  # the prior pulls those rows: they DO move there
 
 
+@pytest.mark.parametrize("stage", ["chamfer", "marker"])
+def test_fused_finalize_is_bit_identical_to_the_separate_kernel(smpl, dev, stage):
+    """Round 4: the backward kernel's LAST block to finish sums the per-frame partials and reports (no k_finalize launch, no
+    cache-flushing fence: the partials cross the XCDs through the scope bits of their own stores and loads).  Against the
+    separate kernel (UUO_FIN_UNFUSED=1 in the debug flavour): (a) 600 closure evaluations at moving points -- loss and the
+    whole gradient bit for bit, every time (a block reading a stale partial would show up as a wrong sum); (b) a whole solve:
+    same losses evaluation by evaluation, same counts, same iterate, bit for bit."""
+    import ctypes
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd._lib import UuoLbfgsOptions, UuoLbfgsStats
+    from uuo_mocap_amd.engine import ChamferProblem, MarkerProblem, _ptr, current_stream
+
+    dbg = _lib.load_debug()
+    F, M = 300, 50   # as many blocks as the bench launches: they finish on all eight XCDs
+    seq = make_sequence(smpl.tables, seed=33, num_frames=F, num_markers=M)
+    cfg = packaged_config("video_mocap")
+    markers = _t(np.nan_to_num(seq.markers.get_points()), dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    trans0 = torch.median(markers, dim=1)[0]
+    if stage == "chamfer":
+        prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, cfg)
+        x0, lr = prob.pack(trans0, torch.zeros(F, 1, 1, device=dev), o_betas, o_pose), 0.1
+    else:
+        prob = MarkerProblem(smpl, markers, o_pose, o_betas, torch.from_numpy(seq.gt["marker_vids"]).to(dev), cfg)
+        x0, lr = prob.pack(o_pose, o_betas, root, trans0), 1.0
+    prob._need_workspace()
+
+    def evaluate(x, unfused):
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        grad = torch.empty((prob.n,), dtype=torch.float32, device=dev)
+        os.environ["UUO_FIN_UNFUSED"] = "1" if unfused else "0"
+        try:
+            rc = dbg.uuo_closure_eval(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), _ptr(loss), _ptr(grad),
+                                      None)
+        finally:
+            os.environ.pop("UUO_FIN_UNFUSED", None)
+        assert rc == 0, dbg.uuo_last_error()
+        return loss, grad
+
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = x0.clone()
+    for it in range(600):
+        lf, gf = evaluate(x, False)
+        lu, gu = evaluate(x, True)
+        assert torch.equal(lf, lu) and torch.equal(gf, gu), (stage, it, float(lf), float(lu))
+        if it % 20 == 0:
+            x = x0 + 0.01 * torch.randn(prob.n, generator=gen).to(dev)
+        else:
+            x = x - 1e-3 * gf
+
+    def solve(unfused):
+        xs = x0.clone()
+        losses = []
+        cb = _lib.EVAL_CALLBACK(lambda user, i, loss, d_x_eval: losses.append(loss))
+        opt = UuoLbfgsOptions(80, 100, lr, 1e-7, 1e-9, 0, 0)
+        st = UuoLbfgsStats()
+        os.environ["UUO_FIN_UNFUSED"] = "1" if unfused else "0"
+        try:
+            rc = dbg.uuo_lbfgs_solve(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(xs), ctypes.byref(opt),
+                                     ctypes.byref(st), ctypes.cast(cb, ctypes.c_void_p), None)
+        finally:
+            os.environ.pop("UUO_FIN_UNFUSED", None)
+        assert rc == 0, dbg.uuo_last_error()
+        torch.cuda.synchronize()
+        return xs, losses, (st.n_iter, st.n_eval, st.stop_reason)
+
+    xa, la, sa = solve(False)
+    xb, lb, sb = solve(True)
+    assert sa == sb and la == lb and torch.equal(xa, xb) and sa[0] >= 60, (sa, sb)
+
+
 def test_device_lbfgs_with_a_host_closure_follows_torch(dev):
     """DeviceLBFGS (uuo_lbfgs_minimize: the device driver calling back a closure composed in Python) against
     torch.optim.LBFGS on the same closure: a well-scaled coupled quadratic over three parameter tensors, one of which

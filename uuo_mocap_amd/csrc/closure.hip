@@ -10,6 +10,25 @@
 
 #define UUO_STAGE_UPSTREAM 3  // internal: not a fitting stage (uuo_smpl_backward)
 
+struct FinArgs {
+  UuoGridHdr h;
+  int stage, F;
+  uuo_gptr<const float> frame_part;
+  uuo_gptr<const float> betas;
+  uuo_gptr<const float> o_betas;
+  double closs;   // data-term coefficient on the summed per-frame values
+  double cpose;   // w_pose / (F*207)
+  double cbetas;  // w_betas / 10
+  uuo_gptr<float> g_betas;
+  uuo_gptr<float> g_z;  // part stage
+  uuo_gptr<float> loss;
+  uuo_gptr<const float> dir_betas;  // optional direction entries of the shared parameters
+  uuo_gptr<const float> dir_z;
+  uuo_gptr<double> stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
+  uuo_gptr<unsigned long long> rep_host;  // optional zero-copy report (UuoEvalReport)
+  unsigned long long rep_seq;
+};
+
 struct BwdArgs {
   UuoGridHdr h;  // grid extent of this problem (lock-step batches: uuo_common.h)
   // model
@@ -53,7 +72,155 @@ struct BwdArgs {
   uuo_gptr<float> g_betas_frame;    // [F][10]
   uuo_gptr<float> frame_part;  // [F][UUO_FP]: 0 data-loss sum, 1 dz (part), 2 pose prior sq sum, 4..13 dbeta,
                       //              16 g.d, 17 sum|g|, 18 g.g, 19 max|g| over this frame's gradient entries
+  // fused finalize (k_bwd_sparse): the block that finishes LAST sums the per-frame partials and reports (see bwd_body's tail)
+  uuo_gptr<unsigned> fin_counter;   // blocks of this launch that have published their partials (null: k_finalize follows)
+  FinArgs fin;
 };
+
+// ----------------------------------------------------------------------------------------------------
+// K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
+// prior, writes the loss and the shared-parameter gradients (betas; z for the part stage).
+// ----------------------------------------------------------------------------------------------------
+
+// NT threads (a multiple of 32 that divides 1024).  The sums are formed exactly as by the 1024-thread kernel whatever NT is:
+// 32 groups of frames x 32 components, group g takes frames g, g + 32, ...; with NT < 1024 a thread forms the sums of
+// 1024 / NT groups one after the other.  COHERENT: the partials were written by OTHER blocks of the running kernel (fused
+// finalize at the end of k_bwd_sparse): they are read with agent-scope loads (sc1: not served from this XCD's L2) and the
+// report is written without a cache write-back (see bwd_body's tail).
+template <int NT, bool COHERENT>
+__device__ __forceinline__ void finalize_body(const FinArgs& a) {
+  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  __shared__ double sh[32][32];
+  const int tid = threadIdx.x;
+  const int comp = tid & 31;  // 32 groups of frames, components 0..UUO_FP-1
+  // thread 0's inputs for the tail (shape prior, direction entries, the part of the report block the direction kernels
+  // left) are on their way while the partials are summed
+  float pb[10], po[10], pd[10], pdz = 0.f;
+  unsigned long long rep_pre[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < 10; ++l) {
+      pb[l] = a.betas[l];
+      po[l] = a.o_betas[l];
+      pd[l] = a.dir_betas ? a.dir_betas[l] : 0.f;
+    }
+    if (a.dir_z) pdz = a.dir_z[0];
+    if (a.stats && a.rep_host) {
+      const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats.get()) - 1;
+      rep_pre[0] = blk[0];
+#pragma unroll
+      for (int i = 6; i < 10; ++i) rep_pre[i - 5] = blk[i];
+    }
+  }
+#pragma unroll
+  for (int gi = 0; gi < 1024 / NT; ++gi) {
+    const int grp = (tid >> 5) + gi * (NT / 32);
+    double acc = 0.0;
+    if (comp < UUO_FP) {
+      const bool is_max = (comp == 19);
+      for (int f0 = grp; f0 < a.F; f0 += 32 * 8) {  // 8 independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 32 * u;
+          const float* src = a.frame_part.get() + (size_t)f * UUO_FP + comp;
+          if constexpr (COHERENT)
+            v[u] = (f < a.F) ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          else
+            v[u] = (f < a.F) ? *src : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = is_max ? fmax(acc, (double)v[u]) : acc + (double)v[u];
+      }
+    }
+    sh[grp][comp] = acc;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double s = 0.0;
+    if (tid == 19) {
+      for (int g = 0; g < 32; ++g) s = fmax(s, sh[g][tid]);
+    } else {
+      for (int g = 0; g < 32; ++g) s += sh[g][tid];
+    }
+    sh[0][tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double bsq = 0.0, sd = sh[0][16], s1 = sh[0][17], s2 = sh[0][18], sm = sh[0][19];
+    for (int l = 0; l < 10; ++l) {
+      const double diff = (double)pb[l] - (double)po[l];
+      bsq += diff * diff;
+      const float gb = (float)(sh[0][4 + l] + 2.0 * a.cbetas * diff);
+      a.g_betas[l] = gb;
+      if (a.dir_betas) sd += (double)gb * (double)pd[l];
+      s1 += fabs((double)gb);
+      s2 += (double)gb * (double)gb;
+      sm = fmax(sm, fabs((double)gb));
+    }
+    const float lossf = (float)(a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq);
+    a.loss[0] = lossf;
+    // the statistics of this problem's OWN parameters (everything but the shape vector), for solves that share the betas
+    // with other ranks (uuo_lbfgs_solve_shared: the betas' gradient is summed over the ranks before it enters any norm)
+    double own1 = sh[0][17], own2 = sh[0][18], ownm = sh[0][19];
+    float gb_local[10];
+#pragma unroll
+    for (int l = 0; l < 10; ++l) gb_local[l] = (float)(sh[0][4 + l] + 2.0 * a.cbetas * ((double)pb[l] - (double)po[l]));
+    if (a.stage == UUO_STAGE_PART) {
+      const float gz = (float)sh[0][1];
+      a.g_z[0] = gz;
+      if (a.dir_z) sd += (double)gz * (double)pdz;
+      s1 += fabs((double)gz);
+      s2 += (double)gz * (double)gz;
+      sm = fmax(sm, fabs((double)gz));
+      own1 += fabs((double)gz);
+      own2 += (double)gz * (double)gz;
+      ownm = fmax(ownm, fabs((double)gz));
+    }
+    if (a.stats) {
+      a.stats[0] = (double)lossf;
+      a.stats[1] = sd;
+      a.stats[2] = sm;
+      a.stats[3] = s1;
+      a.stats[4] = s2;
+      if (a.rep_host) {
+        // the solver's read-back block {max|d| bits, pad, out[9]} starts one word before stats; words 1..5 are
+        // the values just written, the rest was left by the direction kernels of this iteration
+        // (the block is {max|d| bits, stats[0..4], four more words}; nothing is read back from device memory here)
+        const double five[5] = {(double)lossf, sd, sm, s1, s2};
+        // COHERENT (fused finalize): the block is written with system-scope stores (pinned host memory: they go straight out)
+        // and published after they have been acknowledged -- no __threadfence_system(), i.e. no write-back of this XCD's
+        // whole L2 (which holds other solves' freshly skinned vertices) per evaluation
+#define FIN_REP(i_, v_)                                                                                              \
+  do {                                                                                                               \
+    if constexpr (COHERENT)                                                                                          \
+      __hip_atomic_store(a.rep_host.get() + (i_), (unsigned long long)(v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    else                                                                                                             \
+      a.rep_host[i_] = (unsigned long long)(v_);                                                                     \
+  } while (0)
+        FIN_REP(0, rep_pre[0]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) FIN_REP(1 + i, __double_as_longlong(five[i]));
+#pragma unroll
+        for (int i = 6; i < 10; ++i) FIN_REP(i, rep_pre[i - 5]);
+        // words 11..23: own-parameter statistics and this problem's shape gradient (read by shared-betas solves only)
+        FIN_REP(11, __double_as_longlong(ownm));
+        FIN_REP(12, __double_as_longlong(own1));
+        FIN_REP(13, __double_as_longlong(own2));
+#pragma unroll
+        for (int l = 0; l < 10; ++l) FIN_REP(14 + l, __double_as_longlong((double)gb_local[l]));
+#undef FIN_REP
+        if constexpr (COHERENT) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          __threadfence_system();
+          __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
+}
 
 // ----------------------------------------------------------------------------------------------------
 // K_C  one block (4 waves) per frame.  Phase 1: waves stride over the frame's markers; per marker the
@@ -84,6 +251,9 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 // the posed-template vertex is read from the cache k_part_fwd searched: v_posed = C[f][v] + S[v] . beta.
 // NWV = waves per block.  One wave per frame (part stage: <= 16 items, the tail's steps never use more than 60 lanes)
 // leaves the per-block latency about where it is and lets four times as many frames be resident.
+// per-frame partials go out with agent-scope stores (write-through: the finalize block may run on another XCD)
+#define BWD_FP_STORE(i_, v_) \
+  __hip_atomic_store(a.frame_part.get() + (size_t)f * UUO_FP + (i_), (float)(v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 template <bool PART = false, int NWV = BWD_NW>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   static_assert(NWV == BWD_NW || (PART && NWV == 1), "one-wave blocks exist for the part stage only");
@@ -488,7 +658,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   if (tid < 10) {
     float acc = red[4 + tid];
     for (int jj = 0; jj < UUO_NUM_JOINTS; ++jj) acc += w_dpf[0][jj * 10 + tid];
-    a.frame_part[(size_t)f * UUO_FP + 4 + tid] = acc;
+    BWD_FP_STORE(4 + tid, acc);
     if (a.stage == UUO_STAGE_UPSTREAM) a.g_betas_frame[(size_t)f * 10 + tid] = acc;
   }
   BWD_STAMP(7);
@@ -578,7 +748,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
         dzv = fmaf(sdR[0][c], (-sz * r0[c] - cz * r0[3 + c]), dzv);
         dzv = fmaf(sdR[0][3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
       }
-      a.frame_part[(size_t)f * UUO_FP + 1] = dzv;
+      BWD_FP_STORE(1, dzv);
     }
   }
   if (tid >= 32 && tid < 35 && a.g_trans) {
@@ -601,16 +771,35 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     } else {
       for (int w = 0; w < 27; ++w) acc = fmaxf(acc, sstat[w][3]);
     }
-    a.frame_part[(size_t)f * UUO_FP + 16 + tid] = acc;
+    BWD_FP_STORE(16 + tid, acc);
   }
   if (tid == 0) {
     float ps = 0.f;
     for (int jj = 1; jj < UUO_NUM_JOINTS; ++jj) ps += spsq[jj];
-    a.frame_part[(size_t)f * UUO_FP + 0] = red[0];
-    a.frame_part[(size_t)f * UUO_FP + 2] = ps;
-    if (a.stage != UUO_STAGE_PART) a.frame_part[(size_t)f * UUO_FP + 1] = 0.f;
+    BWD_FP_STORE(0, red[0]);
+    BWD_FP_STORE(2, ps);
+    if (a.stage != UUO_STAGE_PART) BWD_FP_STORE(1, 0.f);
   }
   BWD_STAMP(10);
+  if constexpr (!PART) {
+    // ---- fused finalize.  Every block has published its partials with write-through stores; it waits for their
+    // acknowledgement, counts itself in, and the block that arrives LAST does what k_finalize did (same sums in the same
+    // order: bit-identical) and reports to the host.  No release fence anywhere: a device-scope fence on this part writes back
+    // the XCD's whole L2 (round 1 measured the fenced version: the single chain 8 us shorter, four chains 3 % slower); the
+    // partials alone are made visible, by the scope bits of their own stores and loads.
+    if (a.fin_counter) {
+      __shared__ unsigned s_arrived;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        s_arrived = __hip_atomic_fetch_add(a.fin_counter.get(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_arrived == (unsigned)a.h.gx - 1u) {
+        if (tid == 0) __hip_atomic_store(a.fin_counter.get(), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        finalize_body<NT, true>(a.fin);
+      }
+    }
+  }
 }
 
 // The general backward kernel (<= 4 skin weights per vertex: SMPL; uuo_model_create refuses anything else) is
@@ -638,143 +827,10 @@ __global__ __launch_bounds__(BWD_NW * 64) void k_bwd_part_b(const BwdArgs* __res
   bwd_body<true>(a);
 }
 
-// ----------------------------------------------------------------------------------------------------
-// K_D  finalize: sums the per-frame partials in a fixed order (double accumulators), adds the shape
-// prior, writes the loss and the shared-parameter gradients (betas; z for the part stage).
-// ----------------------------------------------------------------------------------------------------
-struct FinArgs {
-  UuoGridHdr h;
-  int stage, F;
-  uuo_gptr<const float> frame_part;
-  uuo_gptr<const float> betas;
-  uuo_gptr<const float> o_betas;
-  double closs;   // data-term coefficient on the summed per-frame values
-  double cpose;   // w_pose / (F*207)
-  double cbetas;  // w_betas / 10
-  uuo_gptr<float> g_betas;
-  uuo_gptr<float> g_z;  // part stage
-  uuo_gptr<float> loss;
-  uuo_gptr<const float> dir_betas;  // optional direction entries of the shared parameters
-  uuo_gptr<const float> dir_z;
-  uuo_gptr<double> stats;           // optional [5]: loss, g.d, max|g|, sum|g|, g.g of the whole gradient
-  uuo_gptr<unsigned long long> rep_host;  // optional zero-copy report (UuoEvalReport)
-  unsigned long long rep_seq;
-};
-
-__device__ __forceinline__ void finalize_body(const FinArgs& a) {
-  __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
-  __shared__ double sh[32][32];
-  const int tid = threadIdx.x;
-  const int comp = tid & 31, grp = tid >> 5;  // 32 groups of frames, components 0..UUO_FP-1
-  // thread 0's inputs for the tail (shape prior, direction entries, the part of the report block the direction kernels
-  // left) are on their way while the partials are summed
-  float pb[10], po[10], pd[10], pdz = 0.f;
-  unsigned long long rep_pre[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-  if (tid == 0) {
-#pragma unroll
-    for (int l = 0; l < 10; ++l) {
-      pb[l] = a.betas[l];
-      po[l] = a.o_betas[l];
-      pd[l] = a.dir_betas ? a.dir_betas[l] : 0.f;
-    }
-    if (a.dir_z) pdz = a.dir_z[0];
-    if (a.stats && a.rep_host) {
-      const unsigned long long* blk = reinterpret_cast<const unsigned long long*>(a.stats.get()) - 1;
-      rep_pre[0] = blk[0];
-#pragma unroll
-      for (int i = 6; i < 10; ++i) rep_pre[i - 5] = blk[i];
-    }
-  }
-  double acc = 0.0;
-  if (comp < UUO_FP) {
-    const bool is_max = (comp == 19);
-    for (int f0 = grp; f0 < a.F; f0 += 32 * 8) {  // 8 independent loads in flight per thread
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + 32 * u;
-        v[u] = (f < a.F) ? a.frame_part[(size_t)f * UUO_FP + comp] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = is_max ? fmax(acc, (double)v[u]) : acc + (double)v[u];
-    }
-  }
-  sh[grp][comp] = acc;
-  __syncthreads();
-  if (tid < 32) {
-    double s = 0.0;
-    if (tid == 19) {
-      for (int g = 0; g < 32; ++g) s = fmax(s, sh[g][tid]);
-    } else {
-      for (int g = 0; g < 32; ++g) s += sh[g][tid];
-    }
-    sh[0][tid] = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double bsq = 0.0, sd = sh[0][16], s1 = sh[0][17], s2 = sh[0][18], sm = sh[0][19];
-    for (int l = 0; l < 10; ++l) {
-      const double diff = (double)pb[l] - (double)po[l];
-      bsq += diff * diff;
-      const float gb = (float)(sh[0][4 + l] + 2.0 * a.cbetas * diff);
-      a.g_betas[l] = gb;
-      if (a.dir_betas) sd += (double)gb * (double)pd[l];
-      s1 += fabs((double)gb);
-      s2 += (double)gb * (double)gb;
-      sm = fmax(sm, fabs((double)gb));
-    }
-    const float lossf = (float)(a.closs * sh[0][0] + a.cpose * sh[0][2] + a.cbetas * bsq);
-    a.loss[0] = lossf;
-    // the statistics of this problem's OWN parameters (everything but the shape vector), for solves that share the betas
-    // with other ranks (uuo_lbfgs_solve_shared: the betas' gradient is summed over the ranks before it enters any norm)
-    double own1 = sh[0][17], own2 = sh[0][18], ownm = sh[0][19];
-    float gb_local[10];
-#pragma unroll
-    for (int l = 0; l < 10; ++l) gb_local[l] = (float)(sh[0][4 + l] + 2.0 * a.cbetas * ((double)pb[l] - (double)po[l]));
-    if (a.stage == UUO_STAGE_PART) {
-      const float gz = (float)sh[0][1];
-      a.g_z[0] = gz;
-      if (a.dir_z) sd += (double)gz * (double)pdz;
-      s1 += fabs((double)gz);
-      s2 += (double)gz * (double)gz;
-      sm = fmax(sm, fabs((double)gz));
-      own1 += fabs((double)gz);
-      own2 += (double)gz * (double)gz;
-      ownm = fmax(ownm, fabs((double)gz));
-    }
-    if (a.stats) {
-      a.stats[0] = (double)lossf;
-      a.stats[1] = sd;
-      a.stats[2] = sm;
-      a.stats[3] = s1;
-      a.stats[4] = s2;
-      if (a.rep_host) {
-        // the solver's read-back block {max|d| bits, pad, out[9]} starts one word before stats; words 1..5 are
-        // the values just written, the rest was left by the direction kernels of this iteration
-        // (the block is {max|d| bits, stats[0..4], four more words}; nothing is read back from device memory here)
-        const double five[5] = {(double)lossf, sd, sm, s1, s2};
-        a.rep_host[0] = rep_pre[0];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) a.rep_host[1 + i] = (unsigned long long)__double_as_longlong(five[i]);
-#pragma unroll
-        for (int i = 6; i < 10; ++i) a.rep_host[i] = rep_pre[i - 5];
-        // words 11..23: own-parameter statistics and this problem's shape gradient (read by shared-betas solves only)
-        a.rep_host[11] = (unsigned long long)__double_as_longlong(ownm);
-        a.rep_host[12] = (unsigned long long)__double_as_longlong(own1);
-        a.rep_host[13] = (unsigned long long)__double_as_longlong(own2);
-#pragma unroll
-        for (int l = 0; l < 10; ++l) a.rep_host[14 + l] = (unsigned long long)__double_as_longlong((double)gb_local[l]);
-        __threadfence_system();
-        __hip_atomic_store(&a.rep_host[10], a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_finalize(FinArgs a) { finalize_body(a); }
+__global__ __launch_bounds__(1024) void k_finalize(FinArgs a) { finalize_body<1024, false>(a); }
 __global__ __launch_bounds__(1024) void k_finalize_b(const FinArgs* __restrict__ batch) {
   UUO_BATCH_PICK(FinArgs, batch)
-  finalize_body(a);
+  finalize_body<1024, false>(a);
 }
 
 // batched launches of this file's kernels (uuo_common.h): 0 = launched, 1 = not one of mine, < 0 = error
@@ -1158,21 +1214,6 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   a.off_pose = gl.off_pose; a.off_root = gl.off_root; a.off_z = gl.off_z; a.off_trans = gl.off_trans;
   a.h.gx = F;
   a.h.gy = 1;
-  const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
-  if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && !part_general) {
-    a.C = fit->pose_cache;
-    const int waves = M <= 16 ? 1 : BWD_NW;
-    if (!uuo_record(UUO_OP_BWD_PART, F, waves, a)) {
-      if (waves == 1)
-        hipLaunchKernelGGL(k_bwd_part1, dim3(F), dim3(64), 0, s, a);
-      else
-        hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
-    }
-  } else {
-    if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
-  }
-  UUO_HIP_CHECK(hipGetLastError());
-
   FinArgs fa;
   std::memset(&fa, 0, sizeof(fa));
   fa.stage = p->stage; fa.F = F;
@@ -1192,8 +1233,36 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   fa.rep_seq = report ? report->seq : 0ull;
   fa.h.gx = 1;
   fa.h.gy = 1;
-  if (!uuo_record(UUO_OP_FIN, 1, 1, fa)) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
+  bool fin_fused = false;
+  const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
+  if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && !part_general) {
+    a.C = fit->pose_cache;
+    const int waves = M <= 16 ? 1 : BWD_NW;
+    if (!uuo_record(UUO_OP_BWD_PART, F, waves, a)) {
+      if (waves == 1)
+        hipLaunchKernelGGL(k_bwd_part1, dim3(F), dim3(64), 0, s, a);
+      else
+        hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    }
+  } else {
+    // the general kernel finalizes by itself: its last block to finish sums the per-frame partials and reports (bwd_body)
+#ifndef UUO_FIN_FUSED
+#define UUO_FIN_FUSED 1  // (0: A/B builds of tools/build_variant.sh)
+#endif
+    const int fin_unfused = UUO_ENV_INT("UUO_FIN_UNFUSED", !UUO_FIN_FUSED);  // debug flavour only: the separate k_finalize, for comparison
+    if (!fin_unfused) {
+      a.fin = fa;
+      a.fin_counter = reinterpret_cast<unsigned*>(fit->scalars + 32);
+      fin_fused = true;
+    }
+    if (!uuo_record(UUO_OP_BWD, F, 1, a)) hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+  }
   UUO_HIP_CHECK(hipGetLastError());
+  if (!fin_fused) {
+    if (!uuo_record(UUO_OP_FIN, 1, 1, fa)) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, fa);
+    UUO_HIP_CHECK(hipGetLastError());
+  }
+
   return 0;
 }
 

@@ -268,7 +268,7 @@ enum {
   UUO_OP_FIN,
   UUO_OP_COUNT
 };
-#define UUO_OP_ARG_MAX 448
+#define UUO_OP_ARG_MAX 640
 struct UuoOpRec {
   int op;
   int gx, gy;

@@ -112,6 +112,14 @@ def soft_weighted_chamfer_distance(x: torch.Tensor, y: torch.Tensor, x_weights: 
     return (d * w).sum() / wsum, None
 
 
+def soft_chamfer_distance(x: torch.Tensor, y: torch.Tensor, tau: float):
+    """EXTENSION, not reference behaviour: the one-directional `chamfer_distance(x, y, single_directional=True)` of the part
+    stage (markers_utils.py:471-475: mean over the clouds of the mean over the points, unmasked) with the hard minimum over
+    the candidate vertices replaced by the soft minimum -tau log sum_j exp(-|x_i - y_j|^2 / tau)."""
+    d = _SoftMin.apply(x, y, tau)                      # [N, P1]
+    return d.sum(1).div(float(max(x.shape[1], 1))).sum() / float(max(x.shape[0], 1)), None
+
+
 def weighted_chamfer_distance(x: torch.Tensor, y: torch.Tensor, x_weights: torch.Tensor,
                               single_directional: bool = False):
     """sum_{n,i} w[n,i] * min_j |x[n,i]-y[n,j]|^2 / sum(w)  (the reference flattens to one cloud per marker and

@@ -18,7 +18,7 @@ import torch
 from .body_model import SMPL_JOINT_NAMES
 from .device_lbfgs import DeviceLBFGS
 from .engine import _f32, PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
-from .losses import chamfer_distance
+from .losses import chamfer_distance, soft_chamfer_distance
 from .transforms import compute_root_orient_z
 
 LAST_STATS: Dict[str, list] = {}
@@ -166,6 +166,9 @@ def _retained_hierarchies_cached(subtrees, similarity_threshold):
 _PART_FUSED_LOSSES = {"chamfer", "reg_betas"}
 #: further terms of the reference closure (markers_utils.py:477-533), evaluated by `part_extra_losses`
 _PART_OPTIONAL_LOSSES = {"reproject", "foot_contact", "foot_velocity", "velocity", "ground"}
+#: EXTENSION (BASELINE configs[2] names a "soft-assignment path"; the reference has none): the part stage's data
+#: term with a soft minimum over the candidate's vertices, temperature stages.part.soft_tau (m^2); replaces or joins `chamfer`
+_PART_EXTENSION_LOSSES = {"soft_chamfer"}
 
 
 def part_extra_losses(losses: Dict, smpl_inference, smpl_output: Dict, pose_body, betas, root_orient, trans, z_angle,
@@ -244,10 +247,13 @@ def find_best_part_fits(
     st = config["stages"]["part"]
     if st["mode"] != "cluster":
         raise NotImplementedError("stages.part.mode 'network' needs segmenter checkpoints the reference does not ship")
-    unknown = set(st["losses"]) - _PART_FUSED_LOSSES - _PART_OPTIONAL_LOSSES
+    unknown = set(st["losses"]) - _PART_FUSED_LOSSES - _PART_OPTIONAL_LOSSES - _PART_EXTENSION_LOSSES
     if unknown:
         raise NotImplementedError("part-stage losses the reference does not define: %s" % sorted(unknown))
-    extra = set(st["losses"]) & _PART_OPTIONAL_LOSSES
+    extra = {k for k in st["losses"] if k in (_PART_OPTIONAL_LOSSES | _PART_EXTENSION_LOSSES) and
+             (k not in _PART_EXTENSION_LOSSES or float(st["losses"][k]) != 0.0)}
+    if not any(float(st["losses"].get(k, 0.0)) != 0.0 for k in ("chamfer", "soft_chamfer")):
+        raise ValueError("the part stage needs a data term: stages.part.losses.chamfer (reference) or soft_chamfer (extension)")
     if "reproject" in extra and any(v is None for v in (joints_2d_gt, focal_length, reproject_mask, camera_center,
                                                         cam_trans)):
         raise ValueError("the part-stage 'reproject' loss needs the camera of the reprojection_part stage "
@@ -370,8 +376,13 @@ def find_best_part_fits(
                 optimizer.zero_grad()
                 n_eval[0] += 1
                 z_root_c, out = forward()
-                loss = chamfer_distance(markers_subset, out["vertices"][:, vertex_indices].contiguous(),
-                                        single_directional=True)[0] * st["losses"]["chamfer"]
+                verts_sub = out["vertices"][:, vertex_indices].contiguous()
+                loss = 0
+                if float(st["losses"].get("chamfer", 0.0)) != 0.0:  # (a child config switches the hard term off with weight 0)
+                    loss = loss + chamfer_distance(markers_subset, verts_sub, single_directional=True)[0] * st["losses"]["chamfer"]
+                if float(st["losses"].get("soft_chamfer", 0.0)) != 0.0:  # EXTENSION: soft assignment of every marker to the candidate's vertices
+                    loss = loss + soft_chamfer_distance(markers_subset, verts_sub, float(st.get("soft_tau", 2.5e-4)))[0] * \
+                        st["losses"]["soft_chamfer"]
                 terms = part_extra_losses(st["losses"], smpl_inference, out, pose_body, betas_s, root_orient, trans,
                                           z_angle, markers_subset_mean, camera, foot_contacts)
                 if "reg_betas" in st["losses"]:

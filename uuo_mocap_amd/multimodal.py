@@ -479,7 +479,7 @@ def multimodal_video_mocap(
 
     hyp_shard = hypothesis_shard()
     lanes = None
-    if (frame_shard() is not None and frame_shard().world > 1) or shared_betas_reducer() is not None:
+    if (frame_shard() is not None and frame_shard().active) or shared_betas_reducer() is not None:
         # frame blocks across ranks / shared betas (extension): every solve is a collective, so all ranks must
         # issue them in one order -- one hypothesis after the other, or every hypothesis on a lane (process group) of its own
         if hyp_shard is not None or (frame_shard() is not None and shared_betas_reducer() is not None):

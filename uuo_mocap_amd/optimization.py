@@ -65,7 +65,7 @@ def optim_chamfer(
     from .parallel import frame_shard
 
     fs = frame_shard()
-    if fs is not None and fs.world > 1:
+    if fs is not None and fs.active:
         return _optim_chamfer_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
                                             smpl_inference, config, iter_fn)
     prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, root_orient, config)
@@ -245,7 +245,8 @@ def _solve(prob, x, config, stage: str, lr: float, verbose_tag: str, verbose: bo
     if kind == "lbfgs":
         return prob.solve(x, max_iter=config["stages"][stage]["num_iters"], lr=lr, tolerance_grad=opt["tolerance_grad"],
                           tolerance_change=opt["tolerance_change"], callback=_printer(verbose_tag, verbose),
-                          point_callback=point_cb)
+                          point_callback=point_cb,
+                          history_size=int(opt.get("history_size", 100)))  # torch.optim.LBFGS's default; the reference never sets it
     if kind != "adam":
         raise ValueError("optimizer.type must be 'lbfgs' or 'adam' (got %r)" % kind)
     if point_cb is not None:
@@ -371,7 +372,7 @@ def optim_markers(
     from .parallel import frame_shard
 
     fs = frame_shard()
-    if fs is not None and fs.world > 1:
+    if fs is not None and fs.active:
         return _optim_markers_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, assign,
                                             smpl_inference, config, iter_fn)
     prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config)

@@ -305,7 +305,7 @@ def collective_lanes(count: int):
             if kind == "shared":
                 _ctx.shared = lanes[i]
             else:
-                _ctx.frames = FrameShard(lanes[i])
+                _ctx.frames = FrameShard(lanes[i], getattr(prev_f, "active", False))
             try:
                 yield
             finally:
@@ -395,9 +395,12 @@ class FrameShard:
     tensors, so everything around the solves (segmentation, candidate search, placement, scoring) runs replicated and
     unchanged."""
 
-    def __init__(self, reducer):
+    def __init__(self, reducer, joint_with_one_rank: bool = False):
         self.reducer = reducer
         self.rank, self.world = int(reducer.rank), int(reducer.world)
+        # one rank: the plain solver IS the joint solve of one block; `joint_with_one_rank` sends it through the joint driver
+        # and its exchanges all the same (tests: the collective code of a one-rank RCCL group on a one-GPU box)
+        self.active = self.world > 1 or bool(joint_with_one_rank)
 
     def bounds(self, num_frames: int) -> List[int]:
         base, rem = divmod(int(num_frames), self.world)
@@ -434,7 +437,8 @@ def frame_shard():
 
 
 @contextlib.contextmanager
-def shard_frames(group=None, device=None, reducer=None, lanes: int = 0, transport: str = "auto"):
+def shard_frames(group=None, device=None, reducer=None, lanes: int = 0, transport: str = "auto",
+                 joint_with_one_rank: bool = False):
     """Inside this context the chamfer and marker stage solves of a fit (optim_chamfer / optim_markers on their fused
     closures) are spread over the ranks of `group` by frame blocks (FrameShard): one sequence uses all the
     GPUs of the group.  All ranks must call the fit with the same inputs; every rank returns the full, identical result.  The
@@ -443,7 +447,7 @@ def shard_frames(group=None, device=None, reducer=None, lanes: int = 0, transpor
     if reducer is None:
         reducer = _default_reducer(group, device, transport)
     prev = getattr(_ctx, "frames", None), getattr(_ctx, "lanes", None), getattr(_ctx, "lanes_kind", None)
-    _ctx.frames = FrameShard(reducer)
+    _ctx.frames = FrameShard(reducer, joint_with_one_rank)
     _ctx.lanes = reducer.fork(lanes) if lanes > 0 else None
     _ctx.lanes_kind = "frames"
     try:
