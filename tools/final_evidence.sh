@@ -1,7 +1,12 @@
-# The round-end evidence run: default bench line, the driver-flags line, tools/prof_all.sh (kernel stats + PMC).
-#   gpurun --timeout 1200 -- bash tools/final_evidence.sh   ->  gpurun_out/r3_bench_*.json, p_*_kernel_stats.csv, pmc_summary.json
+# The round-end evidence run: default bench line, the driver-flags line, tools/prof_all.sh (kernel stats + PMC), the L-BFGS
+# passes' PMC bytes, the pass microbenchmark.
+#   gpurun --timeout 1200 -- bash tools/final_evidence.sh [round tag, default r4]   ->  gpurun_out/<tag>/...
 set -e
-python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3_bench_driver_flags.json 2> gpurun_out/r3_bench_driver_flags.err
-bash tools/prof_all.sh > gpurun_out/r3_prof_all.log 2>&1
-ls gpurun_out/p_*kernel_stats.csv gpurun_out/pmc_summary.json gpurun_out/roof_plain.log
+T=${1:-r4}
+mkdir -p gpurun_out/$T
+python bench.py > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/$T/bench_driver_flags.json 2> gpurun_out/$T/bench_driver_flags.err
+bash tools/prof_all.sh > gpurun_out/$T/prof_all.log 2>&1
+bash tools/pmc_lbfgs.sh > gpurun_out/$T/pmc_lbfgs.log 2>&1
+for f in p_bench_kernel_stats.csv p_closure_kernel_stats.csv p_roof_kernel_stats.csv pmc_summary.json pmc_lbfgs_summary.json roof_plain.log; do cp gpurun_out/$f gpurun_out/$T/$f; done
+ls gpurun_out/$T

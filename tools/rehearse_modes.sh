@@ -25,5 +25,5 @@ run 2 frames "--collective-lanes 4 --collective-transport shm" frames_shm
 run 2 frames "--collective-lanes 4 --collective-transport gloo" frames_gloo
 run 2 hypotheses "" hypotheses
 # the launch SCALE uses (--mode sequences, three sequences in flight per rank), with as many ranks as the pool's process guard
-# lets one box hold on its GPU (6; the 8-rank case is the driver's to run on a real node)
-STEPS=2 run 6 sequences "" sequences_inflight3
+# lets one box hold on its GPU with margin (the guard counts the launcher too: 6 ranks + torchrun = 7 > 6 was killed; the 8-rank case is the driver's to run on a real node)
+STEPS=2 run 4 sequences "" sequences_inflight3

@@ -251,9 +251,25 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 // the posed-template vertex is read from the cache k_part_fwd searched: v_posed = C[f][v] + S[v] . beta.
 // NWV = waves per block.  One wave per frame (part stage: <= 16 items, the tail's steps never use more than 60 lanes)
 // leaves the per-block latency about where it is and lets four times as many frames be resident.
+// Fused finalize (round 4): BUILT, MEASURED, NOT THE DEFAULT.  With UUO_FIN_FUSED the block of
+// k_bwd_sparse that finishes last does k_finalize's work (bit-identical sums, tests/test_gpu_parity.py) without any
+// cache-flushing fence.  Alternating runs, 3 x 9 sequences each: 5.29 vs 5.32 M frame-evaluations/s with three sequences in
+// flight (k_finalize hides behind other chains' kernels anyway) and 328-336 vs 320-323 ms for one sequence alone -- the
+// write-through stores at the end of every block and the last block's uncached reads cost more than the 2-3 us launch gap
+// they replace (profiles/r4_ab_finalize_separate_vs_fused.log).  Compiled into the debug flavour (UUO_FIN_UNFUSED=0 selects
+// it) and into builds with -DUUO_FIN_FUSED=1 only; the product kernel is round 3's.
+#ifndef UUO_FIN_FUSED
+#define UUO_FIN_FUSED 0
+#endif
+#if UUO_FIN_FUSED || defined(UUO_DEBUG_HOOKS)
+#define UUO_FIN_FUSED_BUILT 1
 // per-frame partials go out with agent-scope stores (write-through: the finalize block may run on another XCD)
 #define BWD_FP_STORE(i_, v_) \
   __hip_atomic_store(a.frame_part.get() + (size_t)f * UUO_FP + (i_), (float)(v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define UUO_FIN_FUSED_BUILT 0
+#define BWD_FP_STORE(i_, v_) a.frame_part[(size_t)f * UUO_FP + (i_)] = (float)(v_)
+#endif
 template <bool PART = false, int NWV = BWD_NW>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   static_assert(NWV == BWD_NW || (PART && NWV == 1), "one-wave blocks exist for the part stage only");
@@ -781,6 +797,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     if (a.stage != UUO_STAGE_PART) BWD_FP_STORE(1, 0.f);
   }
   BWD_STAMP(10);
+#if UUO_FIN_FUSED_BUILT
   if constexpr (!PART) {
     // ---- fused finalize.  Every block has published its partials with write-through stores; it waits for their
     // acknowledgement, counts itself in, and the block that arrives LAST does what k_finalize did (same sums in the same
@@ -800,6 +817,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       }
     }
   }
+#endif
 }
 
 // The general backward kernel (<= 4 skin weights per vertex: SMPL; uuo_model_create refuses anything else) is

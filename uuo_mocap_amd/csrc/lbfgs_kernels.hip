@@ -6,8 +6,11 @@
 #include "lbfgs.h"
 #include "frame_math.h"
 
+#ifndef LB_PASS_PRIO
+#define LB_PASS_PRIO 1  // wave priority of the two history passes (0..3)
+#endif
 #ifndef LB_ACC32
-#define LB_ACC32 true  // history passes on packed fp32 partial sums (see lb_dots_body)
+#define LB_ACC32 false  // true: the history passes on packed fp32 partial sums (see lb_dots_body: measured in round 4, not adopted)
 #endif
 
 __global__ void k_lb_init(LbDev* st) {
@@ -139,11 +142,14 @@ __global__ __launch_bounds__(64) void k_lb_stats_final(int nblk, const double* _
 // loads of a column block in flight together.  Per-lane fp64 accumulators, one wave reduction per row at the end.
 #define LB_DRW ((LB_ROWS + 4 * LB_DRS - 1) / (4 * LB_DRS))  // rows per wave (4)
 typedef float lbf2 __attribute__((ext_vector_type(2)));
-// ACC32: the per-lane partial sums are fp32 pairs updated by packed FMAs (v_pk_fma_f32: two history elements per
-// instruction); a lane adds <= 4 * gcb products per accumulator component before the sums continue in fp64 (lane pair,
-// wave, column groups).  torch.optim.LBFGS's own dots are fp32 throughout (lbfgs.py:396-441).  ACC32 = false is the fp64
-// accumulation of rounds 1-3 (one conversion + three fp64 FMAs per history element: ~a third of the kernel's cycles were
-// VALU issue, profiles/r2_pmc_sq_summary.json), kept for the microbenchmark tools/lb_pass_bench.hip.
+// ACC32 (round 4; NOT the default): the per-lane partial sums are fp32 pairs updated by packed FMAs
+// (v_pk_fma_f32: two history elements per instruction); a lane adds <= 4 * gcb products per accumulator component before the
+// sums continue in fp64 (lane pair, wave, column groups) -- torch.optim.LBFGS's own dots are fp32 throughout
+// (lbfgs.py:396-441).  Measured (tools/lb_pass_bench.hip, profiles/r4_lb_pass_bench.log): 12.6 -> 10.8 us with twelve
+// histories cycling through HBM, 10.3 -> 7.7 us out of the Infinity Cache, against 7.5 / 3.8 us for a plain read of the same
+// bytes; in the fit (alternating runs, 3 x 9 sequences each) 5.32 vs 5.31 M frame-evaluations/s -- nothing.  And fp32 sums in
+// another lane order are another trajectory: the solves of the small reference fixtures ended outside the bands the
+// end-to-end tests hold (5 of 125 GPU tests).  ACC32 = false is the fp64 accumulation of rounds 1-3.
 template <bool ACC32>
 __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head, int count, int cand,
                                                   float* __restrict__ S, float* __restrict__ Y,
@@ -151,7 +157,7 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
                                                   const float* __restrict__ d, float t, int ncb, int gcb,
                                                   double* __restrict__ part /* [groups][LB_ROWS][3] */,
                                                   int skip_lo = 0, int skip_hi = 0) {
-  __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  __builtin_amdgcn_s_setprio(LB_PASS_PRIO);  // do not queue behind co-resident MFMA waves
   const int grp = blockIdx.x, rs = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wg = rs * 4 + wave;  // wave's index among the 4 * LB_DRS row owners
@@ -560,7 +566,7 @@ __device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, cons
                                                              LbDev* __restrict__ st, float* __restrict__ d,
                                                              const float* __restrict__ x, float t, float* __restrict__ xt,
                                                              const UuoIndexMap& map) {
-  __builtin_amdgcn_s_setprio(1);  // latency-bound kernel: do not queue behind co-resident MFMA waves
+  __builtin_amdgcn_s_setprio(LB_PASS_PRIO);  // do not queue behind co-resident MFMA waves
   // d = cg g + sum_j cy_j y_j + cs_j s_j, max|d|, and the first line-search trial point xt = x + t d in the same pass.
   // One block per 256-column strip of the history (FOUR columns per lane: 16-byte loads -- the vector-memory pipe costs
   // ~16 cycles per wave instruction whatever its width, and 8-byte loads made this kernel bound by it).  The strip's
