@@ -245,6 +245,9 @@ class DeviceModel:
                 del self._fits[k]  # the handle frees the workspace once no problem references it any more
             return h
 
+    #: device memory a lock-step batch may reserve beyond what its problems need (the growth head-room of the part stage)
+    BATCH_FLOOR_BYTES = 8 << 30
+
     def batch(self, stage: int, F: int, M: int, count: int) -> "_BatchHandle":
         """A lock-step batch (uuo_batch_t) able to step `count` problems of (stage, F, M) together; one per workspace group
         and stage is kept (re-created when the shape changes or more problems are needed)."""
@@ -259,8 +262,12 @@ class DeviceModel:
             if count <= 8:
                 cap = max(int(count), 4)
             else:
+                # ... within a memory budget: a member's workspace is ~83 KB per frame (the vertex buffer), so the
+                # 256-member floor alone would reserve tens of GB for a handful of candidates of a 3000-frame sequence
+                per_member = int(F) * (self.V * 12 + 1024) + (1 << 20)
+                floor = max(64, min(256, self.BATCH_FLOOR_BYTES // per_member // 64 * 64))
                 prev = h.capacity if h is not None and h.shape == (int(F), int(M)) else 0
-                cap = max(256, (int(count) + 63) // 64 * 64, (prev * 3 // 2 + 63) // 64 * 64 if prev else 0)
+                cap = max(floor, (int(count) + 63) // 64 * 64, (prev * 3 // 2 + 63) // 64 * 64 if prev else 0)
             if h is not None:
                 del self._batches[key]
                 h = None
