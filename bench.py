@@ -269,10 +269,10 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
     skin_flops = SKIN_EXECUTED_FLOPS_PER_FRAME * F
     achieved = skin_flops / (skin_ms * 1e-3) / 1e12                       # executed useful FLOPs: what `frac` is made of
     survey = SKIN_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12           # SURVEY 8d's count (dense skinning credited)
-    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r3_pmc_summary.json):
-    # FETCH_SIZE 15 080 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 413 KB, at F=300.
+    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r4_pmc_summary.json; the kernel is round 3's):
+    # FETCH_SIZE 15 276 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 408 KB, at F=300.
     # An OFFLINE figure (a PMC pass cannot run inside this process): null at any other size.
-    traffic = int((15079.6 * 2 + 30412.6) * 1024) if (F == 300) else None
+    traffic = int((15276.1 * 2 + 30407.7) * 1024) if (F == 300) else None
     mfma_useful = SKIN_MFMA_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12
     closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -287,7 +287,7 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
                 "traffic_vs_algorithmic": (traffic / FUSED_ALGORITHMIC_BYTES(F)) if traffic else None,
                 "traffic_vs_unfused_budget": (traffic / (18688848 + F * (6890 * 12 + 431 * 24))) if traffic else None,
                 "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel at F=300 "
-                                  "(profiles/r3_pmc_summary.json), not measured by this run",
+                                  "(profiles/r4_pmc_summary.json), not measured by this run",
                 "kernel": "k_skin2<true,0>",
                 # frac credits SURVEY 8d's dense 24-joint skinning product; the kernel does that part as <=4-weight VALU
                 # work, so the matrix pipe's own useful rate is the blend contraction alone:
