@@ -154,7 +154,9 @@ __device__ __forceinline__ float row16_max(float v) {
   return fmaxf(v, dpp_row<0x121>(v));
 }
 #define UUO_BIG 3.0e38f
-#define SKIN_WAVES 8
+#ifndef SKIN_WAVES
+#define SKIN_WAVES 8  // waves per block of the skinning kernels (4: A/B builds only, one wave per SIMD)
+#endif
 #define SKIN_GROUPS (UUO_KP / 16)  // 14 groups of 4 K-steps (one dwordx4 per lane per coordinate each)
 #define SKIN_CG 2                  // groups per register buffer  -> 7 chunks, 24 MFMAs each
 #define SKIN_NCHUNK (SKIN_GROUPS / SKIN_CG)
