@@ -369,3 +369,30 @@ def test_chamfer_stage_options_match_reference(golden, oracle_smpl, tag):
     ref = g[tag + "_losses"]
     n = min(len(trace), 30)
     np.testing.assert_allclose(trace[:n], ref[:n], rtol=2e-4)
+
+
+@pytest.mark.parametrize("case", ["e2e_config0", "e2e_mht_rotation", "e2e_hmr_part"])
+def test_oracle_reproduces_the_references_losses_at_its_recorded_points(case, oracle_smpl):
+    """The converged-point records of the end-to-end fixtures (oracle/make_golden_e2e.py: for every `LBFGS.step` of the
+    reference's own run the parameters it ended on, the loss of the reference's closure there, its constants) against the
+    oracle's closures on the CPU: the oracle evaluated AT the recorded final parameters gives the recorded loss, and
+    evaluated at the start rebuilt from the records (the way the reference's orchestrator chains its solves) gives the
+    recorded first loss.  This pins the oracle at the points where the solves END, not only where they begin, and checks
+    the bookkeeping the GPU test (tests/test_gpu_converged.py) relies on."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from converged_records import _solves, _starts
+
+    from uuo_mocap_amd.config import packaged_config
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case + ".npz"), allow_pickle=False)
+    cfg = packaged_config(str(d["yaml"]))
+    solves = _solves(d, oracle_smpl)
+    starts = _starts(solves)
+    for s in (solves if len(solves) <= 12 else solves[::6]):
+        at_final, _ = s.oracle(s.final, oracle_smpl, cfg)
+        at_start, _ = s.oracle(starts[s.k], oracle_smpl, cfg)
+        assert at_final == pytest.approx(s.loss_at_final, rel=1e-6), (case, s.k, s.stage)
+        assert at_start == pytest.approx(s.first_loss, rel=1e-6), (case, s.k, s.stage)

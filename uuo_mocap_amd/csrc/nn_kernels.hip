@@ -412,11 +412,15 @@ int uuo_launch_nn(hipStream_t s, int N, int P1, int P2, const float* x, const fl
 // A frame is split over several blocks by marker groups so that several waves share each SIMD.  If a block has too
 // many survivors for its LDS list (poor bounds: first call, markers far from the body) it enumerates all pairs.
 // ----------------------------------------------------------------------------------------------------
-#define CULL_CAP 4096
+#define CULL_CAP 3072
+#define CULL_CAP2 1024  // surviving (marker, super-box) pairs a block lists; more = poor bounds: enumerate everything
 #define CULL_MG 64
 #define CULL_MAXU 512
 #define CULL_UB 4
 #define CULL_MAXG 8
+#ifndef CULL_SUPER
+#define CULL_SUPER 8  // units per super-box of the two-level box test (0: one level, rounds 1-3)
+#endif
 #ifndef CULL_T
 #define CULL_T 256  // threads per block (128: 7 us slower alone and 2 % slower fits; 512: no faster)
 #endif
@@ -429,7 +433,7 @@ __device__ __forceinline__ void nn_cull_body(int M, int V, int nunits, int mper,
   __shared__ float sub[CULL_MG];
   __shared__ unsigned long long skey[CULL_MG];
   __shared__ unsigned slist[CULL_CAP];
-  __shared__ unsigned scount;
+  __shared__ unsigned scount, scount2;
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.y * mper;
   const int mg = min(mper, M - m0);
@@ -453,7 +457,60 @@ __device__ __forceinline__ void nn_cull_body(int M, int V, int nunits, int mper,
     sub[tid] = __uint_as_float((unsigned)(key >> 32));
   }
   if (tid == 0) scount = 0u;
+  if (tid == 1) scount2 = 0u;
   __syncthreads();
+#if CULL_SUPER
+  // ---- phase A, two levels (round 4).  A marker needs a unit only if the unit's box can hold a vertex at most d_ub away;
+  // 2-3 % of the 21 550 (marker, unit) pairs of a frame pass that test, and testing them all was most of this kernel's
+  // vector work (as many VALU cycles per launch as k_skin2's whole epilogue, profiles/r2_pmc_sq_summary.json).  The boxes of
+  // CULL_SUPER consecutive units are merged into a super-box first; a marker is tested against the 54 super-boxes, and
+  // against the units of the survivors only.  The lower bound of a super-box is <= that of each of its units (every
+  // operation of the bound is monotone), so exactly the same (marker, unit) pairs survive as before: bit-identical result.
+  constexpr int NSUP_MAX = (CULL_MAXU + CULL_SUPER - 1) / CULL_SUPER;
+  __shared__ float ssup[NSUP_MAX * 6];
+  __shared__ unsigned slist2[CULL_CAP2];
+  const int nsup = (nunits + CULL_SUPER - 1) / CULL_SUPER;
+  for (int sidx = tid; sidx < nsup * 6; sidx += CULL_T) {
+    const int sp = sidx / 6, c = sidx - sp * 6;
+    const int u0 = sp * CULL_SUPER, u1 = min(nunits, u0 + CULL_SUPER);
+    float v = sbox[u0 * 6 + c];
+    for (int u = u0 + 1; u < u1; ++u) v = (c < 3) ? fminf(v, sbox[u * 6 + c]) : fmaxf(v, sbox[u * 6 + c]);
+    ssup[sidx] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < nsup * mg; e += CULL_T) {  // (super-box, marker) pairs
+    const int sp = e / mg, m = e - sp * mg;
+    const float* b = ssup + sp * 6;
+    const float qx = smx[m * 3], qy = smx[m * 3 + 1], qz = smx[m * 3 + 2];
+    const float dx = fmaxf(fmaxf(__fsub_rn(b[0], qx), __fsub_rn(qx, b[3])), 0.f);
+    const float dy = fmaxf(fmaxf(__fsub_rn(b[1], qy), __fsub_rn(qy, b[4])), 0.f);
+    const float dz = fmaxf(fmaxf(__fsub_rn(b[2], qz), __fsub_rn(qz, b[5])), 0.f);
+    const float lb = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    if (lb <= sub[m]) {
+      const unsigned pos = atomicAdd(&scount2, 1u);
+      if (pos < CULL_CAP2) slist2[pos] = ((unsigned)m << 16) | (unsigned)sp;
+    }
+  }
+  __syncthreads();
+  const int found2 = (int)scount2;
+  if (found2 > CULL_CAP2 && tid == 0) scount = CULL_CAP + 1u;  // (the overflow path below enumerates all pairs)
+  for (int e = tid; e < min(found2, CULL_CAP2 + 0) * CULL_SUPER && found2 <= CULL_CAP2; e += CULL_T) {  // the units of the surviving super-boxes
+    const unsigned ent = slist2[e / CULL_SUPER];
+    const int m = (int)(ent >> 16), u = (int)(ent & 0xFFFFu) * CULL_SUPER + (e % CULL_SUPER);
+    if (u < nunits) {
+      const float* b = sbox + u * 6;
+      const float qx = smx[m * 3], qy = smx[m * 3 + 1], qz = smx[m * 3 + 2];
+      const float dx = fmaxf(fmaxf(__fsub_rn(b[0], qx), __fsub_rn(qx, b[3])), 0.f);
+      const float dy = fmaxf(fmaxf(__fsub_rn(b[1], qy), __fsub_rn(qy, b[4])), 0.f);
+      const float dz = fmaxf(fmaxf(__fsub_rn(b[2], qz), __fsub_rn(qz, b[5])), 0.f);
+      const float lb = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (lb <= sub[m]) {
+        const unsigned pos = atomicAdd(&scount, 1u);
+        if (pos < CULL_CAP) slist[pos] = ((unsigned)m << 16) | (unsigned)u;
+      }
+    }
+  }
+#else
   // ---- phase A: thread = unit (box in registers); the marker loop only sets bits of a survivor mask (no branch,
   // no atomic on the loop path), then one LDS atomicAdd per thread reserves the list slots
   for (int u = tid; u < nunits; u += CULL_T) {
@@ -480,6 +537,7 @@ __device__ __forceinline__ void nn_cull_body(int M, int V, int nunits, int mper,
       }
     }
   }
+#endif
   __syncthreads();
   const int found = (int)scount;
   const bool overflow = found > CULL_CAP;  // poor bounds (first call, markers far from the body): enumerate all pairs
