@@ -276,7 +276,7 @@ def test_reprojection_stage_at_baseline_size_against_the_reference(smpl, tables,
 def test_end_to_end_config0_against_the_reference_fit(smpl, oracle_smpl, golden, dev, record_property):
     """BASELINE ``configs[0]``: 30 frames x 41 markers, ``video_mocap.yaml`` as shipped (10000-iteration budgets, 4 yaw
     hypotheses).  tests/golden/e2e_config0.npz holds the reference's OWN ``multimodal_video_mocap`` run on these inputs
-    (oracle/make_golden_config0.py: 434 s on the CPU, 2345 closure evaluations).  Converged quantities are compared, not
+    (oracle/make_golden_e2e.py --case config0: 434 s on the CPU, 2345 closure evaluations).  Converged quantities are compared, not
     trajectories (hard assignments make two fp32 trajectories part after some dozens of iterations: SURVEY.md section 7):
     stage structure, every solve's starting loss where the start is determined by the inputs alone, part labels and
     chain, the selected hypothesis' quality, and the distance between the two fitted bodies."""
@@ -366,7 +366,7 @@ def _bodies_apart(g, out, oracle_smpl):
 def test_end_to_end_config1_hmr_full_against_the_reference_fit(smpl, oracle_smpl, golden, dev, record_property):
     """BASELINE ``configs[1]`` at the BASELINE size: 300 frames x 50 markers, ``hmr_full.yaml`` as shipped (full-skeleton
     part stage + the 4-yaw selection; chamfer / marker stages are off there).  tests/golden/e2e_config1.npz is
-    the reference's OWN ``multimodal_video_mocap`` on these inputs (oracle/make_golden_configs.py: 97 s on the CPU, 42
+    the reference's OWN ``multimodal_video_mocap`` on these inputs (oracle/make_golden_e2e.py --case config1: 97 s on the CPU, 42
     closure evaluations at 1.9 s each).  The part solve's start is fixed by the inputs, its end is a converged 911-parameter
     problem: losses, evaluation count, the selected yaw's body and the labels are compared."""
     g = golden("e2e_config1.npz")
