@@ -388,3 +388,57 @@ def test_runner_cli_brings_up_its_own_process_group(tmp_path):
     assert os.path.isfile(os.path.join(root, "moyo_val", "results", "unit", "subj", "seq0_stageii.npz"))
     assert open(os.path.join(root, "cli0.txt")).read() == "wrote 1 sequence(s)"
     assert open(os.path.join(root, "cli1.txt")).read() == "wrote 0 sequence(s)"
+
+
+def _failing_rank_main(rank, world, port, out_dir):
+    import time
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), UUO_SHARE_GPU="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from uuo_mocap_amd import parallel
+        from uuo_mocap_amd.engine import ChamferProblem
+        from uuo_mocap_amd.synthetic import make_sequence
+
+        dev, tables, cfg, smpl = _setup()
+        res = {}
+        for transport in ("shm", "gloo"):
+            red = parallel._default_reducer(None, dev, transport)
+            sq = make_sequence(tables, seed=70 + rank, num_frames=F, num_markers=M)
+            markers = torch.from_numpy(sq.markers.get_points()).float().to(dev)
+            o_betas = (sq.img_smpl.betas.sum(0, keepdim=True) / sq.img_smpl.img_mask.sum()).to(dev)
+            prob = ChamferProblem(smpl, markers, sq.img_smpl.pose_body.to(dev), o_betas, sq.img_smpl.root_orient.to(dev), cfg)
+            x = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas,
+                          sq.img_smpl.pose_body.to(dev))
+            if rank == 1:
+                prob.problem.M = 0   # this rank's problem does not validate: its solve fails before the first exchange
+            t0 = time.perf_counter()
+            try:
+                prob.solve_shared(x, red, max_iter=10, lr=0.1)
+                res[transport] = ("returned", time.perf_counter() - t0, "")
+            except RuntimeError as exc:
+                res[transport] = ("raised", time.perf_counter() - t0, str(exc))
+            dist.barrier()
+        torch.save(res, os.path.join(out_dir, "fail%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_takes_its_peers_out_of_a_shared_solve(tmp_path):
+    """a rank that leaves a shared solve (here: its problem does not validate) used to leave the other ranks
+    blocked in their next gather until the transport's time-out.  Every gathered message carries a status word now and a
+    rank that fails still takes part in the exchange its peers are waiting in: both ranks raise within seconds, over the
+    shared-memory mailbox and over gloo, and the healthy rank's message names the one that failed."""
+    import torch.multiprocessing as mp
+
+    port = 29500 + ((os.getpid() + 77) % 2000)
+    mp.spawn(_failing_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "fail%d.pt" % r), weights_only=False) for r in range(2)]
+    for transport in ("shm", "gloo"):
+        for r in range(2):
+            kind, seconds, msg = res[r][transport]
+            assert kind == "raised" and seconds < 30.0, (transport, r, res[r][transport])
+        assert "rank 1" in res[0][transport][2], res[0][transport]

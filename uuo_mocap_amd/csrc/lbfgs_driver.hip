@@ -780,17 +780,14 @@ extern "C" int uuo_lbfgs_solve(uuo_fit_t* fit, void* stream, const uuo_problem_t
 
 // EXTENSION (BASELINE configs[3]; not reference behaviour): uuo_lbfgs_solve where the `world` ranks that call
 // it together -- one stage problem each, same stage -- share the shape vector.  See SharedCtx above.
-extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
-                                      const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
-                                      uuo_eval_callback_t cb, void* cb_user) {
-  UUO_REQUIRE(shared && shared->gather && shared->world >= 1 && shared->rank >= 0 && shared->rank < shared->world,
-              "uuo_lbfgs_solve_shared: bad rank description");
+// everything of a shared solve that can fail BEFORE the first exchange (argument checks, workspace, mask, packing decision)
+static int shared_prepare(uuo_fit_t* fit, hipStream_t s, const uuo_problem_t* p, float* d_x, const uuo_lbfgs_options_t* opt,
+                          uuo_lbfgs_stats_t* stats, StageObjective& obj, LbWs** w_out) {
   int rc = uuo_validate_problem(fit, p);
   if (rc) return rc;
   UUO_REQUIRE(d_x && opt && stats, "uuo_lbfgs_solve_shared: null argument");
   UUO_REQUIRE(opt->max_iter > 0, "uuo_lbfgs_solve_shared: max_iter must be positive");
   UUO_REQUIRE(uuo_recorder == nullptr, "uuo_lbfgs_solve_shared: not inside a lock-step batch");
-  hipStream_t s = (hipStream_t)stream;
   const int hist = opt->history_size > 0 ? opt->history_size : 100;
   const int n_params = uuo_problem_num_params(p);
   LbWs* w = (LbWs*)fit->lbws;
@@ -807,15 +804,35 @@ extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_pr
   }
   rc = uuo_ensure_mask(fit, s, p);
   if (rc) return rc;
-  StageObjective obj;
   rc = stage_objective_init(obj, fit, s, p, d_x);
   if (rc) return rc;
+  *w_out = w;
+  return 0;
+}
+
+extern "C" int uuo_lbfgs_solve_shared(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, float* d_x,
+                                      const uuo_lbfgs_options_t* opt, uuo_lbfgs_stats_t* stats, const uuo_shared_t* shared,
+                                      uuo_eval_callback_t cb, void* cb_user) {
+  UUO_REQUIRE(shared && shared->gather && shared->world >= 1 && shared->rank >= 0 && shared->rank < shared->world,
+              "uuo_lbfgs_solve_shared: bad rank description");
+  hipStream_t s = (hipStream_t)stream;
   SharedCtx sh;
   sh.gather = shared->gather;
   sh.user = shared->user;
   sh.rank = shared->rank;
   sh.world = shared->world;
   sh.cnt = UUO_NUM_BETAS;
+  StageObjective obj;
+  LbWs* w = nullptr;
+  int rc = shared_prepare(fit, s, p, d_x, opt, stats, obj, &w);
+  if (rc) {
+    // a rank that cannot even start tells its peers in the solve's FIRST exchange (they are waiting there), so that they
+    // leave with its error code instead of timing out
+    const std::string why = uuo_last_error();
+    (void)shared_gather(&sh, nullptr, 1, rc);
+    uuo_set_error(why);
+    return rc;
+  }
   const int F = p->F;  // offset of the betas in the parameter vector and in the solver's packing (closure.hip stage_layout)
   sh.off_x = (p->stage == UUO_STAGE_CHAMFER) ? 4 * F : (p->stage == UUO_STAGE_MARKER) ? 207 * F : 3 * F + 1;
   sh.off = (p->stage == UUO_STAGE_MARKER && obj.compact) ? 138 * F : sh.off_x;
