@@ -242,7 +242,6 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None, 
 # with a context manager, so the operator surface (multimodal_video_mocap, optim_chamfer, optim_markers) stays the reference's.
 # ---------------------------------------------------------------------------------------------------------------------
 import contextlib
-import threading
 
 _ctx = threading.local()
 
