@@ -141,6 +141,12 @@ typedef struct {
   uint64_t pose_cache_id;    /* part stage: non-zero = the body pose d_o_pose is constant for every evaluation that
                                 carries this id, so the pose-corrective blend (207 x 20670 contraction, 70 % of the
                                 forward's arithmetic) is computed once and re-used; 0 = recompute every evaluation */
+  /* EXTENSION (not reference behaviour; BASELINE configs[2] "hmr_part.yaml, soft-assignment path"): the part stage's data
+   * term with the hard minimum over the candidate's vertices (markers/markers_utils.py:471-475) joined or replaced by the
+   * soft minimum  -tau log sum_v exp(-|x - v|^2 / tau):  loss_data = (1 / (F M)) sum_{f,m} (w_data min_v d2 + w_soft softmin).
+   * Fused closure (k_part_soft): needs pose_cache_id != 0 and M <= 16.  w_soft = 0: the reference's term alone. */
+  float w_soft;              /* stages.part.losses.soft_chamfer (0 = absent) */
+  float soft_tau;            /* temperature in m^2 (> 0 when w_soft != 0) */
 } uuo_problem_t;
 
 int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out);

@@ -621,6 +621,111 @@ def test_soft_assignment_part_term_against_the_float64_formula(smpl, oracle_smpl
     assert float(loss) <= hard + 1e-9
 
 
+def _soft_part_reference(msub, o_pose, b, o_betas, root, t, z, vidx, oracle_smpl, w_hard, w_soft, w_reg, tau):
+    """The part closure with the soft term in float64 over the oracle's (fp32, differentiable) SMPL forward: loss and the
+    flat gradient [z | trans | betas]."""
+    F, M = msub.shape[0], msub.shape[1]
+    z_root = stages_ref.compute_root_orient_z(torch.repeat_interleave(z, repeats=F, dim=0)) @ root   # as part_stage_loss
+    out = stages_ref._smpl_repeat_betas(oracle_smpl, o_pose, b, z_root, t)
+    vs = out["vertices"][:, vidx].double()
+    loss = 0.0
+    for f0 in range(0, F, 50):
+        d2 = ((msub[f0:f0 + 50].double()[:, :, None] - vs[f0:f0 + 50][:, None]) ** 2).sum(-1)
+        loss = loss + (w_soft * (-tau * torch.logsumexp(-d2 / tau, dim=-1)) + w_hard * d2.min(-1)[0]).sum() / (F * M)
+    loss = loss + w_reg * ((b - o_betas) ** 2).mean().double()
+    loss.backward()
+    return float(loss), torch.cat([x.grad.reshape(-1) for x in (z, t, b)]).numpy(), out
+
+
+@pytest.mark.parametrize("F,M,limb,w_hard", [(300, 10, True, 0.0), (60, 10, True, 0.0), (30, 16, False, 0.0), (60, 7, True, 4.0)])
+def test_fused_soft_part_closure_against_float64(smpl, oracle_smpl, tables, dev, record_property, F, M, limb, w_hard):
+    """EXTENSION (BASELINE configs[2]: hmr_part.yaml, soft-assignment path): the FUSED soft part closure (k_part_soft: online
+    soft-min over the candidate's vertices in registers, dense backward collapsed to per-frame sums, k_bwd_part's kinematic
+    tail) against the same objective with the soft term in float64 over the oracle's SMPL forward under autograd -- value to
+    2e-5, the flat gradient [yaw | translations | shape] to 2e-4 -- at a perturbed point; the assignment it reports is the
+    hard search's, bit for bit; soft alone and soft joined with the reference's hard term."""
+    import copy
+
+    from uuo_mocap_amd.engine import PartProblem
+
+    cfg = copy.deepcopy(packaged_config("hmr_part_soft"))
+    tau = float(cfg["stages"]["part"]["soft_tau"])
+    cfg["stages"]["part"]["losses"]["chamfer"] = w_hard
+    w_soft, w_reg = float(cfg["stages"]["part"]["losses"]["soft_chamfer"]), float(cfg["stages"]["part"]["losses"]["reg_betas"])
+    seq = make_sequence(tables, seed=9, num_frames=F, num_markers=M if limb else 50, limb_only=limb)
+    markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float()
+    msub = markers[:, :M].contiguous()
+    o_pose = seq.img_smpl.pose_body.clone()
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).clone()
+    root = seq.img_smpl.root_orient.clone()
+    vlabels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    joints = [13, 16, 18, 20, 22] if limb else [0, 1, 4, 7, 10]   # collar + left arm / pelvis + left leg
+    vidx = torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in joints])
+    gen = torch.Generator().manual_seed(4)
+    z = torch.full((1, 1, 1), 0.4, requires_grad=True)
+    t = (torch.median(msub, dim=1)[0] + 0.02 * torch.randn(F, 3, generator=gen)).requires_grad_(True)
+    b = (o_betas + 0.3 * torch.randn(1, 10, generator=gen)).requires_grad_(True)
+    ref, ref_grad, _ = _soft_part_reference(msub, o_pose, b, o_betas, root, t, z, vidx, oracle_smpl, w_hard, w_soft, w_reg, tau)
+    prob = PartProblem(smpl, msub.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), vidx.to(dev), cfg)
+    assert prob.problem.w_soft == w_soft and prob.problem.soft_tau == pytest.approx(tau)
+    x = prob.pack(z.detach().to(dev), t.detach().to(dev), b.detach().to(dev))
+    loss, grad, nn = prob.evaluate(x)
+    loss2, grad2, _ = prob.evaluate(x)
+    assert loss2 == loss and torch.equal(grad, grad2), "the fused soft closure must be bit-reproducible"
+    err = _rel_err(grad.cpu().numpy().astype(np.float64), ref_grad.astype(np.float64))
+    record_property("soft_part_closure_%dx%d_loss_rel" % (F, M), abs(loss - ref) / abs(ref))
+    record_property("soft_part_closure_%dx%d_grad_rel_l2" % (F, M), err)
+    print("fused soft part closure %dx%d: loss %.8f vs %.8f, gradient rel-L2 %.2e" % (F, M, loss, ref, err))
+    np.testing.assert_allclose(loss, ref, rtol=2e-5)
+    assert err < 2e-4
+    # per block of the gradient as well: the yaw is one number next to 3F translations
+    n = 3 * F + 1
+    g = grad.cpu().numpy()
+    assert abs(g[0] - ref_grad[0]) <= 2e-4 * max(abs(ref_grad[0]), np.abs(ref_grad[1:n]).max())
+    assert _rel_err(g[n:].astype(np.float64), ref_grad[n:].astype(np.float64)) < 5e-4
+    # the assignment it leaves (labels, d_nn_idx) is the hard search's
+    hard_cfg = copy.deepcopy(packaged_config("hmr_part"))
+    hard = PartProblem(smpl, msub.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), vidx.to(dev), hard_cfg)
+    _, _, nn_hard = hard.evaluate(x)
+    assert torch.equal(nn, nn_hard)
+
+
+def test_fused_soft_part_solve_and_batch(smpl, tables, dev):
+    """The fused soft closure under the device L-BFGS: a lock-step batch of candidates is bit-identical to solving them one
+    by one, and every solve lowers its objective."""
+    import copy
+
+    from uuo_mocap_amd.engine import PartProblem, solve_batch
+
+    cfg = copy.deepcopy(packaged_config("hmr_part_soft"))
+    F, M = 48, 9
+    seq = make_sequence(tables, seed=3, num_frames=F, num_markers=M, limb_only=True)
+    markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float().to(dev)
+    o_pose = seq.img_smpl.pose_body.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    root = seq.img_smpl.root_orient.to(dev)
+    vlabels = torch.argmax(smpl.get_lbs_weights(), dim=-1)
+    cands = [[13, 16, 18, 20], [16, 18, 20, 22], [14, 17, 19, 21], [0, 1, 4, 7], [0, 2, 5, 8], [3, 6, 9, 12], [9, 13, 16, 18],
+             [9, 14, 17, 19], [1, 4, 7, 10]]
+    vis = [torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in c]) for c in cands]
+    trans0 = torch.median(markers, dim=1)[0]
+    one = []
+    for vi in vis:
+        p_ = PartProblem(smpl, markers, o_pose, o_betas, root, vi, cfg)
+        x = p_.pack(torch.zeros(1, 1, 1, device=dev), trans0, o_betas)
+        st = p_.solve(x, max_iter=40)
+        assert st["final_loss"] < st["first_loss"]
+        one.append((x.clone(), st))
+    probs = [PartProblem(smpl, markers, o_pose, o_betas, root, vi, cfg, own_workspace=False) for vi in vis]
+    for p_ in probs[1:]:
+        p_.problem.pose_cache_id = probs[0].problem.pose_cache_id
+    xs = [probs[0].pack(torch.zeros(1, 1, 1, device=dev), trans0, o_betas) for _ in probs]
+    stats = solve_batch(probs, xs, max_iter=40, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9)
+    for (x1, st1), xb, stb in zip(one, xs, stats):
+        assert torch.equal(x1, xb)
+        assert st1["n_eval"] == stb["n_eval"] and st1["final_loss"] == stb["final_loss"]
+
+
 def test_soft_assignment_part_stage_end_to_end(smpl, tables, dev, record_property):
     """EXTENSION: `hmr_part_soft.yaml` (hmr_part.yaml with the soft-min data term in the stage that configuration actually
     runs) fits a 60 x 10 limb sequence through the reference's own orchestration -- same candidate list as the hard fit,
@@ -631,15 +736,27 @@ def test_soft_assignment_part_stage_end_to_end(smpl, tables, dev, record_propert
 
     seq = make_sequence(tables, seed=22, num_frames=60, num_markers=10, limb_only=True)
     outs = {}
-    for name in ("hmr_part", "hmr_part_soft"):
-        cfg = packaged_config(name)
+    for name, exe in (("hmr_part", None), ("hmr_part_soft", None), ("hmr_part_soft_ops", {"part_soft_fused": False})):
+        cfg = packaged_config(name.replace("_ops", ""))
         outs[name] = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
-                                            save_stages=False, smpl_inference=smpl)
+                                            save_stages=False, smpl_inference=smpl, execution=exe)
         outs[name + "_stats"] = copy.deepcopy(dict(last_run_stats()))
-    hard, soft = outs["hmr_part"], outs["hmr_part_soft"]
+    hard, soft, soft_ops = outs["hmr_part"], outs["hmr_part_soft"], outs["hmr_part_soft_ops"]
     assert len(outs["hmr_part_soft_stats"]["part"]) == len(outs["hmr_part_stats"]["part"]) > 10
-    assert all("host closure" in str(s_.get("driver", "")) for s_ in outs["hmr_part_soft_stats"]["part"])
+    # the default route is the fused closure in the lock-step batch; execution["part_soft_fused"] = False is its checker, the
+    # closure composed from the differentiable operators, one candidate after the other
+    assert not any("host closure" in str(s_.get("driver", "")) for s_ in outs["hmr_part_soft_stats"]["part"])
+    assert all("host closure" in str(s_.get("driver", "")) for s_ in outs["hmr_part_soft_ops_stats"]["part"])
     assert np.array_equal(np.asarray(hard["chain"]), np.asarray(soft["chain"]))
+    assert np.array_equal(np.asarray(soft_ops["chain"]), np.asarray(soft["chain"]))
+    # candidate by candidate the two routes minimise the same objective from the same start
+    first_f = np.array([s_["first_loss"] for s_ in outs["hmr_part_soft_stats"]["part"]])
+    first_o = np.array([s_["first_loss"] for s_ in outs["hmr_part_soft_ops_stats"]["part"]])
+    np.testing.assert_allclose(first_f, first_o, rtol=2e-5)
+    final_f = np.array([s_["final_loss"] for s_ in outs["hmr_part_soft_stats"]["part"]])
+    final_o = np.array([s_["final_loss"] for s_ in outs["hmr_part_soft_ops_stats"]["part"]])
+    record_property("hmr_part_soft_fused_vs_operators_final_loss_median_rel", float(np.median(np.abs(final_f - final_o) / final_o)))
+    assert np.median(np.abs(final_f - final_o) / final_o) < 5e-3
     vh = smpl(hard["pose_body"].to(dev), hard["betas"].to(dev), hard["root_orient"].to(dev), hard["trans"].to(dev))["vertices"]
     vs = smpl(soft["pose_body"].to(dev), soft["betas"].to(dev), soft["root_orient"].to(dev), soft["trans"].to(dev))["vertices"]
     gap = float((vh - vs).norm(dim=-1).mean())

@@ -37,7 +37,7 @@ def test_native_library_loaded():
     from uuo_mocap_amd import _lib
 
     lib = _lib.load()
-    assert lib.uuo_abi_version() == 1
+    assert lib.uuo_abi_version() == 2
     assert any("libuuo_hip.so" in line for line in open("/proc/self/maps"))
 
 

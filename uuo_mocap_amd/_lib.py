@@ -21,6 +21,7 @@ class UuoProblem(ctypes.Structure):
         ("d_assign", c_void_p), ("d_subset", c_void_p), ("n_subset", c_int32),
         ("w_data", c_float), ("w_pose", c_float), ("w_betas", c_float), ("marker_distance", c_float),
         ("pose_cache_id", ctypes.c_uint64),
+        ("w_soft", c_float), ("soft_tau", c_float),   # EXTENSION: soft-assignment data term of the part stage
     ]
 
 

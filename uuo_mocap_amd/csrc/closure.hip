@@ -65,6 +65,8 @@ struct BwdArgs {
                          // solver's compact packing: the third rows, whose gradient is identically zero, left out)
   uuo_gptr<const float> frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
   uuo_gptr<const float> C;       // part stage (k_bwd_part): the cached template + pose-corrective blend [F][V][3]
+  uuo_gptr<const float> pre;     // part stage with a soft assignment (extension): [F][UUO_PRE] sums left by k_part_soft; the item
+                                 // loop is skipped and the kinematic tail runs on them (null: the reference's hard term)
   // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
   // (+ the 21 vertex-picked joints) with dL/dv given, instead of markers with a residual
   uuo_gptr<const float> up_verts;   // [F][V][3] or null
@@ -336,6 +338,18 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
 
   if (a.stop == 1) return;
   BWD_STAMP(1);
+  // soft part closure: k_part_soft has already summed the (dense) vertex gradients of this frame -- the joint forces are the
+  // translation columns of dA, the rotation blocks are not needed (the yaw's gradient comes as a torque, below)
+  bool use_pre = false;
+  if constexpr (PART) use_pre = a.pre.get() != nullptr;  // block-uniform
+  if (use_pre) {
+    const float* pr = a.pre.get() + (size_t)f * UUO_PRE;
+    for (int i = tid; i < UUO_NUM_JOINTS * 12; i += NT) {
+      const int jj = i / 12, e = i - jj * 12;
+      sdA[i] = ((e & 3) == 3) ? pr[16 + jj * 3 + (e >> 2)] : 0.f;
+    }
+    if (tid < 14) red[tid] = pr[tid];
+  } else {
   float tr[3] = {0.f, 0.f, 0.f};
   if (a.src.trans) {
     tr[0] = a.src.trans[(size_t)f * 3];
@@ -544,6 +558,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
     for (int w = 1; w < SLOTS; ++w) acc += w_red[w][tid];
     red[tid] = acc;
   }
+  }  // !use_pre
   __syncthreads();
 
   if (a.stop == 3) return;
@@ -764,6 +779,10 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
         dzv = fmaf(sdR[0][c], (-sz * r0[c] - cz * r0[3 + c]), dzv);
         dzv = fmaf(sdR[0][3 + c], (cz * r0[c] - sz * r0[3 + c]), dzv);
       }
+      if constexpr (PART) {
+        // d v / d z = e_z x (v - root joint - trans): torque about trans_f (k_part_soft) moved to the root joint J_0 = G_0^t
+        if (use_pre) dzv = a.pre[(size_t)f * UUO_PRE + 14] - (L.Gt[0][0] * red[2] - L.Gt[0][1] * red[1]);
+      }
       BWD_FP_STORE(1, dzv);
     }
   }
@@ -928,6 +947,8 @@ static int validate_problem(const uuo_fit* fit, const uuo_problem_t* p) {
   if (p->stage == UUO_STAGE_MARKER) UUO_REQUIRE(p->d_assign != nullptr, "closure: marker stage needs d_assign");
   if (p->stage == UUO_STAGE_PART)
     UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0 && p->n_subset <= fit->model->V, "closure: part stage needs a vertex subset");
+  UUO_REQUIRE(p->w_soft == 0.f || (p->stage == UUO_STAGE_PART && p->soft_tau > 0.f && p->pose_cache_id != 0 && p->M <= 16),
+              "closure: w_soft is the part stage's soft-assignment term (extension): needs soft_tau > 0, a pose cache id and M <= 16");
   return 0;
 }
 
@@ -995,6 +1016,14 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   }
   const int unfused = UUO_ENV_INT("UUO_PART_UNFUSED", 0);  // debug flavour only: the two-kernel path, for comparison
   const bool fused = cached && !need_verts && !unfused && p->M >= 1 && p->M <= 16;
+  if (p->stage == UUO_STAGE_PART && p->w_soft != 0.f && !need_verts) {  // EXTENSION: soft assignment (k_part_soft)
+    UUO_REQUIRE(cached && p->M >= 1 && p->M <= 16 && p->soft_tau > 0.f,
+                "closure: the fused soft-assignment part closure needs a pose cache id, 1..16 markers and soft_tau > 0");
+    rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames, p->d_subset, p->n_subset, fit->part_sb);
+    if (rc) return rc;
+    return uuo_launch_part_soft(m, s, p->F, p->M, fit->pose_cache, fit->part_sb, fit->A, src.trans, p->d_subset, p->n_subset,
+                                p->d_markers, fit->nn, fit->soft_pre, p->w_data, p->w_soft, p->soft_tau);
+  }
   if (fused) {
     rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames, p->d_subset, p->n_subset, fit->part_sb);
     if (rc) return rc;
@@ -1200,7 +1229,9 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
     denom = (double)fit->mask_sum;  // pytorch3d: div = weights.sum()
   else
     denom = (double)F * (double)M;  // mean over frames and markers
-  const double data_c = (denom > 0.0) ? (double)p->w_data / denom : 0.0;
+  const bool soft = p->stage == UUO_STAGE_PART && p->w_soft != 0.f;
+  // (soft part closure: k_part_soft weights its own terms -- w_data min + w_soft softmin -- so only 1 / (F M) is left here)
+  const double data_c = (denom > 0.0) ? (soft ? 1.0 : (double)p->w_data) / denom : 0.0;
 
   BwdArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -1255,6 +1286,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const int part_general = UUO_ENV_INT("UUO_PART_GENERAL_BWD", 0);  // debug flavour only: the general kernel, for comparison
   if (p->stage == UUO_STAGE_PART && p->pose_cache_id != 0 && fit->pose_cache_id == p->pose_cache_id && !part_general) {
     a.C = fit->pose_cache;
+    a.pre = soft ? fit->soft_pre : nullptr;
     const int waves = M <= 16 ? 1 : BWD_NW;
     if (!uuo_record(UUO_OP_BWD_PART, F, waves, a)) {
       if (waves == 1)
@@ -1263,6 +1295,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
         hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
     }
   } else {
+    UUO_REQUIRE(!soft, "closure: the soft-assignment part closure runs on the cached pose blend only");
     // the general kernel finalizes by itself: its last block to finish sums the per-frame partials and reports (bwd_body)
 #ifndef UUO_FIN_FUSED
 #define UUO_FIN_FUSED 1  // (0: A/B builds of tools/build_variant.sh)

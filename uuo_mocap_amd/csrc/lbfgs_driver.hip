@@ -701,6 +701,7 @@ int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bool sync
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
   A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
   A((void**)&fit->part_sb, (size_t)model->V * 8 * sizeof(float));
+  A((void**)&fit->soft_pre, (size_t)F * UUO_PRE * sizeof(float));
   A((void**)&fit->bbox, (size_t)F * ((model->V + 15) / 16) * 6 * sizeof(float));
   A((void**)&fit->nn, (size_t)F * M * sizeof(unsigned long long));
   A((void**)&fit->frame_part, (size_t)F * UUO_FP * sizeof(float));

@@ -351,6 +351,289 @@ int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const 
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// EXTENSION (not reference behaviour; BASELINE configs[2] "hmr_part.yaml, soft-assignment path"): the part stage's data term
+// with a SOFT assignment of every marker to the candidate's vertices, fused like k_part_fwd (vertices only in registers):
+//   loss_data = (1 / (F M)) sum_{f,m} [ w_hard min_v d2_fmv  +  w_soft ( -tau log sum_v exp(-d2_fmv / tau) ) ]
+// A soft assignment makes the backward DENSE -- every vertex of the candidate receives gradient
+//   g_v = - sum_m (c_soft p_mv + c_hard [v = argmin_m]) (x_m - v),   p_mv = exp((dmin_m - d2_mv)/tau) / S_m
+// -- so it cannot be the <= 16-item gather of k_bwd_part.  But the part stage optimises a yaw about the root joint, a
+// translation per frame and the shape only (markers/markers_utils.py:416-434), and for those the dense backward collapses
+// to per-frame sums over the vertices that this kernel forms while it holds the vertex:
+//   d trans_f = sum_v g_v;   torque_z = sum_v (v - trans_f) x g_v  (the yaw: d v / d z = e_z x (v - root joint));
+//   d beta (blend-shape path) = sum_v S_v^T T_v^R^T g_v;   joint forces F_j = sum_v w_vj g_v  (= d A_j^t: the shape's joint path).
+// They go to a [F][UUO_PRE] record; k_bwd_part in `pre` mode skips its item loop and runs its kinematic tail on them.
+// One wave per (candidate, frame), two passes over the candidate's vertices: pass 1 keeps per lane and marker the running
+// (minimum, first index, sum of exp relative to that minimum) with ONE exponential per pair (online soft-min), merged over
+// the wave in a fixed order; pass 2 re-skins, forms p_mv and accumulates.  No float atomics: the joint forces are
+// accumulated in per-lane LDS columns and reduced in a fixed order, everything else by DPP wave sums: bit-reproducible.
+// ----------------------------------------------------------------------------------------------------
+struct PartSoftArgs {
+  UuoGridHdr h;  // gx = F
+  int F, V, ns, P1;
+  uuo_gptr<const int32_t> subset;
+  uuo_gptr<const float> C;
+  uuo_gptr<const float> SB;   // [ns][8] (k_pose_prep's tail, as for k_part_fwd)
+  uuo_gptr<const float> A;
+  uuo_gptr<const float> trans;
+  uuo_gptr<const float> x;
+  uuo_gptr<const float> ST;   // [V][3][10] shape basis
+  uuo_gptr<unsigned long long> out;  // [F][P1] packed (min distance bits << 32 | first candidate)
+  uuo_gptr<float> pre;        // [F][UUO_PRE]
+  float kexp;                 // log2(e) / tau
+  float tau_ln2;              // tau * ln 2
+  float w_hard, w_soft;       // loss weights
+  float c_hard, c_soft;       // 2 w / (F M)
+};
+#define PSO_U 2  // vertices per lane in flight
+// the candidate's vertex c (clamped id cl) of frame f: position o, blended transform T2 (3x4 row-major, as pairs)
+__device__ __forceinline__ void pso_skin(const float* __restrict__ Cf, const float4* __restrict__ SB4, const float* sA,
+                                         const float* sTr, unsigned v, unsigned cl, float* o, pf2* T2, float4& ww, unsigned& pj) {
+  const float* pc = Cf + v * 3u;
+  const float4 k0 = SB4[cl * 2u];
+  ww = SB4[cl * 2u + 1u];
+  const float px = pc[0] + k0.x, py = pc[1] + k0.y, pz = pc[2] + k0.z;
+  pj = __float_as_uint(k0.w);
+  const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+  for (int e = 0; e < 6; ++e) T2[e] = pf2{0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const float4* pa = reinterpret_cast<const float4*>(sA) + ((pj >> (8 * n)) & 0xFFu);
+    const float4 r0 = pa[0], r1 = pa[1], r2 = pa[2];
+    const pf2 ar[6] = {pf2{r0.x, r0.y}, pf2{r0.z, r0.w}, pf2{r1.x, r1.y}, pf2{r1.z, r1.w}, pf2{r2.x, r2.y}, pf2{r2.z, r2.w}};
+    const pf2 w2 = pf2{wv[n], wv[n]};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) T2[e] = __builtin_elementwise_fma(w2, ar[e], T2[e]);
+  }
+  o[0] = fmaf(T2[1].x, pz, fmaf(T2[0].y, py, T2[0].x * px)) + T2[1].y + sTr[0];
+  o[1] = fmaf(T2[3].x, pz, fmaf(T2[2].y, py, T2[2].x * px)) + T2[3].y + sTr[1];
+  o[2] = fmaf(T2[5].x, pz, fmaf(T2[4].y, py, T2[4].x * px)) + T2[5].y + sTr[2];
+}
+template <int QB>
+__device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
+  __shared__ __align__(16) float sA[UUO_NUM_JOINTS * 12];
+  __shared__ float sF[UUO_NUM_JOINTS * 3 * 64];  // joint forces: entry (3 j + e) of lane l at [(3 j + e) * 64 + l]
+  const int tid = threadIdx.x;
+  constexpr int P1 = QB;
+  constexpr int QP = (QB + 1) / 2;
+  {
+    const float4* Af = reinterpret_cast<const float4*>(a.A + (size_t)f * UUO_NUM_JOINTS * 12);
+    for (int i = tid; i < UUO_NUM_JOINTS * 3; i += 64) reinterpret_cast<float4*>(sA)[i] = Af[i];
+#pragma unroll
+    for (int i = 0; i < UUO_NUM_JOINTS * 3; ++i) sF[i * 64 + tid] = 0.f;
+  }
+  pf2 qx[QP], qy[QP], qz[QP];
+  float sTr[3];
+  const float* xq = a.x + (size_t)f * P1 * 3;
+#pragma unroll
+  for (int k = 0; k < QP; ++k) {
+    const int q0 = 2 * k, q1 = (2 * k + 1 < QB) ? 2 * k + 1 : QB - 1;
+    qx[k] = pf2{pfw_uniform(xq[q0 * 3]), pfw_uniform(xq[q1 * 3])};
+    qy[k] = pf2{pfw_uniform(xq[q0 * 3 + 1]), pfw_uniform(xq[q1 * 3 + 1])};
+    qz[k] = pf2{pfw_uniform(xq[q0 * 3 + 2]), pfw_uniform(xq[q1 * 3 + 2])};
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sTr[i] = a.trans ? pfw_uniform(a.trans[(size_t)f * 3 + i]) : 0.f;
+  const float* Cf = a.C + (size_t)f * a.V * 3;
+  const float4* SB4 = reinterpret_cast<const float4*>(a.SB.get());
+  const int last = a.ns - 1;
+  const float kexp = a.kexp;
+  __syncthreads();
+
+  // ---- pass 1: per lane and marker the running minimum, its first candidate, and sum exp((min - d2) / tau)
+  float pm[QB], ps[QB];
+  unsigned pi[QB];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    pm[q] = 3.0e38f;  // (finite: the first candidate's exp(-(3e38 - d2)/tau) underflows to an exact 0, no inf - inf anywhere)
+    ps[q] = 0.f;
+    pi[q] = 0xFFFFFFFFu;
+  }
+  for (int base = 0; base < a.ns; base += 64 * PSO_U) {
+    float o[PSO_U][3];
+    unsigned cid[PSO_U];
+#pragma unroll
+    for (int u = 0; u < PSO_U; ++u) {
+      const int c = base + tid + 64 * u;
+      const bool valid = c < a.ns;
+      const unsigned cl = (unsigned)min(c, last);
+      const unsigned v = min((unsigned)a.subset[cl], (unsigned)(a.V - 1));
+      pf2 T2[6];
+      float4 ww;
+      unsigned pj;
+      pso_skin(Cf, SB4, sA, sTr, v, cl, o[u], T2, ww, pj);
+      if (!valid) o[u][0] = o[u][1] = o[u][2] = 1.0e18f;  // a lane past the end: d2 ~ 3e36, every weight an exact 0
+      cid[u] = valid ? (unsigned)c : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < PSO_U; ++u) {
+      const pf2 ox2 = pf2{o[u][0], o[u][0]}, oy2 = pf2{o[u][1], o[u][1]}, oz2 = pf2{o[u][2], o[u][2]};
+#pragma unroll
+      for (int k = 0; k < QP; ++k) {
+        const pf2 dx = qx[k] - ox2, dy = qy[k] - oy2, dz = qz[k] - oz2;
+        const pf2 d2 = ((dx * dx) + (dy * dy)) + (dz * dz);  // sqdist(): the K=1 search's arithmetic (same minimum, same ties)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * k + h;
+          if (q < QB) {
+            const float d = h ? d2.y : d2.x;
+            const float diff = d - pm[q];
+            const float e = __builtin_amdgcn_exp2f(-fabsf(diff) * kexp);
+            const bool lt = diff < 0.f;  // strict: ascending candidates per lane -> the first index is kept on ties
+            ps[q] = lt ? fmaf(ps[q], e, 1.f) : ps[q] + e;
+            pm[q] = lt ? d : pm[q];
+            pi[q] = lt ? cid[u] : pi[q];
+          }
+        }
+      }
+    }
+  }
+  // ---- merge over the wave (fixed order): minimum and first candidate as k_part_fwd, the sums rescaled to the wave's minimum
+  float uM[QB], uW[QB];
+  unsigned uI[QB];
+  float loss = 0.f;
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    const unsigned mb = __float_as_uint(pm[q]);
+    const unsigned dmin = wave_min_u32(mb);
+    const unsigned imin = wave_min_u32(mb == dmin ? pi[q] : 0xFFFFFFFFu);
+    const float Mf = __uint_as_float(dmin);
+    const float S = wave_sum_fast(ps[q] * __builtin_amdgcn_exp2f((Mf - pm[q]) * kexp));  // >= 1
+    const float soft = Mf - a.tau_ln2 * __builtin_amdgcn_logf(S);                          // v_log_f32 = log2
+    loss += a.w_hard * Mf + a.w_soft * soft;
+    uM[q] = pfw_uniform(Mf);
+    uW[q] = pfw_uniform(a.c_soft / S);
+    uI[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)imin);
+    if (tid == 0) a.out[(size_t)f * P1 + q] = ((unsigned long long)dmin << 32) | (unsigned long long)imin;
+  }
+
+  // ---- pass 2: weights, vertex gradients, the per-frame sums
+  float gs[3] = {0.f, 0.f, 0.f}, tq = 0.f, db[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) db[k] = 0.f;
+  const float c_hard = a.c_hard;
+  for (int base = 0; base < a.ns; base += 64 * PSO_U) {
+#pragma unroll
+    for (int u = 0; u < PSO_U; ++u) {
+      const int c = base + tid + 64 * u;
+      const bool valid = c < a.ns;
+      const unsigned cl = (unsigned)min(c, last);
+      const unsigned v = min((unsigned)a.subset[cl], (unsigned)(a.V - 1));
+      const float2* st2 = reinterpret_cast<const float2*>(a.ST + (size_t)v * 30);
+      float2 sv[15];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) sv[i] = st2[i];
+      pf2 T2[6];
+      float4 ww;
+      unsigned pj;
+      float o[3];
+      pso_skin(Cf, SB4, sA, sTr, v, cl, o, T2, ww, pj);
+      const float rx = o[0] - sTr[0], ry = o[1] - sTr[1];
+      if (!valid) o[0] = o[1] = o[2] = 1.0e18f;
+      const unsigned cidv = valid ? (unsigned)c : 0xFFFFFFFFu;
+      const pf2 ox2 = pf2{o[0], o[0]}, oy2 = pf2{o[1], o[1]}, oz2 = pf2{o[2], o[2]};
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int k = 0; k < QP; ++k) {
+        const pf2 dx = qx[k] - ox2, dy = qy[k] - oy2, dz = qz[k] - oz2;
+        const pf2 d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * k + h;
+          if (q < QB) {
+            const float d = h ? d2.y : d2.x;
+            float p = __builtin_amdgcn_exp2f((uM[q] - d) * kexp) * uW[q];
+            p += (cidv == uI[q]) ? c_hard : 0.f;
+            ax = fmaf(p, h ? dx.y : dx.x, ax);
+            ay = fmaf(p, h ? dy.y : dy.x, ay);
+            az = fmaf(p, h ? dz.y : dz.x, az);
+          }
+        }
+      }
+      const float g0 = -ax, g1 = -ay, g2 = -az;  // d loss / d vertex (exact zeros for a lane past the end)
+      gs[0] += g0;
+      gs[1] += g1;
+      gs[2] += g2;
+      tq += rx * g1 - ry * g0;
+      // d v_posed = T^R^T g, then the blend-shape path of the shape gradient
+      const float dv0 = fmaf(T2[4].x, g2, fmaf(T2[2].x, g1, T2[0].x * g0));
+      const float dv1 = fmaf(T2[4].y, g2, fmaf(T2[2].y, g1, T2[0].y * g0));
+      const float dv2 = fmaf(T2[5].x, g2, fmaf(T2[3].x, g1, T2[1].x * g0));
+      const float* svf = reinterpret_cast<const float*>(sv);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) db[k] += fmaf(svf[20 + k], dv2, fmaf(svf[10 + k], dv1, svf[k] * dv0));
+      // joint forces into this lane's LDS column (an unused weight slot is joint 0 with weight 0: adds exact zeros)
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float* col = sF + ((pj >> (8 * n)) & 0xFFu) * 64u + tid;
+        col[0] += wv[n] * g0;
+        col[64] += wv[n] * g1;
+        col[128] += wv[n] * g2;
+      }
+    }
+  }
+  // ---- the frame's record
+  float* pre = a.pre + (size_t)f * UUO_PRE;
+  const float r1 = wave_sum_fast(gs[0]), r2 = wave_sum_fast(gs[1]), r3 = wave_sum_fast(gs[2]), r14 = wave_sum_fast(tq);
+  float rb[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) rb[k] = wave_sum_fast(db[k]);
+  if (tid == 0) {
+    pre[0] = loss;
+    pre[1] = r1;
+    pre[2] = r2;
+    pre[3] = r3;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) pre[4 + k] = rb[k];
+    pre[14] = r14;
+    pre[15] = 0.f;
+  }
+  __syncthreads();
+  for (int t = tid; t < UUO_NUM_JOINTS * 3; t += 64) {  // lane t sums entry t over the lanes' columns, rotated: no bank conflict
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) acc += sF[t * 64 + ((i + t) & 63)];
+    pre[16 + t] = acc;
+  }
+}
+template <int QB>
+__global__ __launch_bounds__(64) void k_part_soft(PartSoftArgs a) {
+  const int f = (int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7);
+  if (f >= a.F) return;
+  part_soft_body<QB>(a, f);
+}
+template <int QB>
+__global__ __launch_bounds__(64) void k_part_soft_b(const PartSoftArgs* __restrict__ batch, int count) {
+  const int r = (int)(blockIdx.x >> 3);
+  const PartSoftArgs a = batch[r % count];
+  const int f = (r / count) * 8 + (int)(blockIdx.x & 7);
+  if (f >= a.F) return;
+  part_soft_body<QB>(a, f);
+}
+
+int uuo_launch_part_soft(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
+                         const float* trans, const int32_t* subset, int n_subset, const float* markers,
+                         unsigned long long* packed, float* pre, float w_hard, float w_soft, float tau) {
+  UUO_REQUIRE(P1 >= 1 && P1 <= NNQ_MAX && subset && n_subset > 0 && F > 0 && pre, "uuo_launch_part_soft: bad arguments");
+  UUO_REQUIRE(tau > 0.f && w_soft != 0.f, "uuo_launch_part_soft: needs a positive temperature and a soft weight");
+  const double fm = (double)F * (double)P1;
+  PartSoftArgs a{{F, P1}, F, m->V, n_subset, P1, subset, cache, sb, A, trans, markers, m->ST, packed, pre,
+                 (float)(1.4426950408889634 / (double)tau), (float)((double)tau * 0.6931471805599453), w_hard, w_soft,
+                 (float)(2.0 * (double)w_hard / fm), (float)(2.0 * (double)w_soft / fm)};
+  if (uuo_record(UUO_OP_PART_SOFT, F, P1, a)) return 0;
+  const dim3 grid(8 * ((F + 7) / 8));
+  switch (P1) {
+#define PSO_CASE(Q) case Q: hipLaunchKernelGGL(k_part_soft<Q>, grid, dim3(64), 0, s, a); break;
+    PSO_CASE(1) PSO_CASE(2) PSO_CASE(3) PSO_CASE(4) PSO_CASE(5) PSO_CASE(6) PSO_CASE(7) PSO_CASE(8)
+    PSO_CASE(9) PSO_CASE(10) PSO_CASE(11) PSO_CASE(12) PSO_CASE(13) PSO_CASE(14) PSO_CASE(15) PSO_CASE(16)
+#undef PSO_CASE
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 static int fill_keys(hipStream_t s, unsigned long long* packed, size_t count) {
   FillArgs f{{(int)((count + 255) / 256), 1}, packed, (int)count};
   if (uuo_record(UUO_OP_FILL, f.h.gx, 1, f)) return 0;
@@ -646,6 +929,16 @@ int uuo_batched_launch_nn(int op, hipStream_t s, const void* d_args, int count, 
       PFW_CASE(9) PFW_CASE(10) PFW_CASE(11) PFW_CASE(12) PFW_CASE(13) PFW_CASE(14) PFW_CASE(15) PFW_CASE(16)
 #undef PFW_CASE
       default: UUO_REQUIRE(false, "batched k_part_fwd: markers per frame out of range");
+    }
+  } else if (op == UUO_OP_PART_SOFT) {  // as UUO_OP_PART_FWD
+    const dim3 grid(8 * ((gx + 7) / 8) * count);
+    const PartSoftArgs* pa = (const PartSoftArgs*)d_args;
+    switch (gy) {
+#define PSO_CASE(Q) case Q: hipLaunchKernelGGL(k_part_soft_b<Q>, grid, dim3(64), 0, s, pa, count); break;
+      PSO_CASE(1) PSO_CASE(2) PSO_CASE(3) PSO_CASE(4) PSO_CASE(5) PSO_CASE(6) PSO_CASE(7) PSO_CASE(8)
+      PSO_CASE(9) PSO_CASE(10) PSO_CASE(11) PSO_CASE(12) PSO_CASE(13) PSO_CASE(14) PSO_CASE(15) PSO_CASE(16)
+#undef PSO_CASE
+      default: UUO_REQUIRE(false, "batched k_part_soft: markers per frame out of range");
     }
   } else {
     return 1;

@@ -16,6 +16,8 @@
 #define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
 #define UUO_LEVEL_W 5     // joints per tree level the level-parallel sweeps support (SMPL: 1,3,3,3,5,3,2,2,2)
 #define UUO_FP 24         // floats per frame of the closure's partial-sum block
+#define UUO_PRE 96        // floats per frame of the soft part closure's record (k_part_soft -> k_bwd_part): 0 weighted data-loss
+                          // sum, 1..3 d trans, 4..13 d beta (blend-shape path), 14 torque_z about trans_f, 16..87 joint forces [24][3]
 
 void uuo_set_error(const std::string& msg);
 
@@ -142,6 +144,7 @@ struct uuo_fit {
   float* bbox = nullptr;            // [F][ceil(V/16)][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
   void* slab = nullptr;             // the one device allocation every buffer below (but pose_cache) is carved from
   float* part_sb = nullptr;         // [V][8] per-vertex constants of a part-stage candidate (k_pose_prep -> k_part_fwd)
+  float* soft_pre = nullptr;        // [F][UUO_PRE] per-frame sums of the soft part closure (k_part_soft -> k_bwd_part)
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
@@ -167,6 +170,9 @@ int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPose
 int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
                         const float* trans, const int32_t* subset, int n_subset, const float* markers,
                         unsigned long long* packed);
+int uuo_launch_part_soft(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
+                         const float* trans, const int32_t* subset, int n_subset, const float* markers,
+                         unsigned long long* packed, float* pre, float w_hard, float w_soft, float tau);
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox);
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
@@ -259,6 +265,7 @@ enum {
   UUO_OP_SKIN,             // k_skin / k_skin2: whole-GPU kernels, issued one problem after the other
   UUO_OP_SKIN_CACHED,
   UUO_OP_PART_FWD,         // k_part_fwd: skinning of a candidate's vertices fused with the nearest-vertex search
+  UUO_OP_PART_SOFT,        // k_part_soft: the same with a soft assignment (extension) + the dense backward's per-frame sums
   UUO_OP_FILL,             // hipMemsetAsync
   UUO_OP_NN,
   UUO_OP_NN_FEWQ,

@@ -642,6 +642,10 @@ class MarkerProblem(_StageProblem):
                 x[207 * F + 10:216 * F + 10].reshape(F, 1, 3, 3), x[216 * F + 10:].reshape(F, 3))
 
 
+#: most markers per frame the fused soft-assignment part closure (k_part_soft) is instantiated for
+PART_SOFT_MAX_MARKERS = 16
+
+
 class PartProblem(_StageProblem):
     """closure_fit_subtree (reference markers/markers_utils.py:454-562); x = [z 1 | trans 3F | betas 10]."""
 
@@ -649,8 +653,9 @@ class PartProblem(_StageProblem):
 
     def __init__(self, smpl_inference, markers, pose_body, o_betas, root_orient, vertex_indices, config,
                  own_workspace: bool = True):
-        losses = config["stages"]["part"]["losses"]
-        unsupported = set(losses) - {"chamfer", "reg_betas"}
+        st = config["stages"]["part"]
+        losses = st["losses"]
+        unsupported = set(losses) - {"chamfer", "reg_betas", "soft_chamfer"}
         if unsupported:
             raise NotImplementedError("part-stage losses outside the shipped configs: %s" % sorted(unsupported))
         super().__init__(smpl_inference.device_model, markers, pose_body, o_betas, root_orient,
@@ -658,6 +663,16 @@ class PartProblem(_StageProblem):
                          subset=vertex_indices, own_workspace=own_workspace)
         # the body pose is a constant of this problem: let the library compute its pose-corrective blend once
         self.problem.pose_cache_id = next(_POSE_CACHE_IDS)
+        # EXTENSION (not in the reference): soft assignment of every marker to the candidate's vertices, fused (k_part_soft)
+        w_soft = float(losses.get("soft_chamfer", 0.0))
+        if w_soft != 0.0:
+            if self.M > PART_SOFT_MAX_MARKERS:
+                raise NotImplementedError("the fused soft-assignment part closure takes at most %d markers per frame"
+                                          % PART_SOFT_MAX_MARKERS)
+            self.problem.w_soft = w_soft
+            self.problem.soft_tau = float(st.get("soft_tau", 2.5e-4))
+            if not self.problem.soft_tau > 0.0:
+                raise ValueError("stages.part.soft_tau must be positive")
 
     def pack(self, z_angle, trans, betas):
         return torch.cat([_f32(z_angle, "z").reshape(-1), _f32(trans, "trans").reshape(-1),

@@ -17,7 +17,7 @@ import torch
 
 from .body_model import SMPL_JOINT_NAMES
 from .device_lbfgs import DeviceLBFGS
-from .engine import _f32, PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
+from .engine import _f32, PART_SOFT_MAX_MARKERS, PartProblem, set_workspace_group, set_workspace_slot, worker_pool, worker_streams, workspace_group
 from .losses import chamfer_distance, soft_chamfer_distance
 from .transforms import compute_root_orient_z
 
@@ -26,7 +26,8 @@ LAST_STATS: Dict[str, list] = {}
 # how independent solves are scheduled on the device (never what they compute); see find_best_part_fits /
 # multimodal_video_mocap.  These were environment variables in round 2: the product path reads no environment now.
 EXECUTION_DEFAULTS = {"subtree_lockstep": True, "subtree_batch": 256, "subtree_threads": 4,
-                      "hypothesis_lockstep": False, "hypothesis_threads": 4, "batch_trivial_hypotheses": True}
+                      "hypothesis_lockstep": False, "hypothesis_threads": 4, "batch_trivial_hypotheses": True,
+                      "part_soft_fused": True}
 
 
 def merge_execution(config: Dict, execution: Dict = None) -> Dict:
@@ -252,6 +253,10 @@ def find_best_part_fits(
         raise NotImplementedError("part-stage losses the reference does not define: %s" % sorted(unknown))
     extra = {k for k in st["losses"] if k in (_PART_OPTIONAL_LOSSES | _PART_EXTENSION_LOSSES) and
              (k not in _PART_EXTENSION_LOSSES or float(st["losses"][k]) != 0.0)}
+    # the soft-assignment term has a fused closure of its own (k_part_soft) when it stands alone beside the reference's fused
+    # terms and the candidate markers fit its instantiations; execution["part_soft_fused"] = False keeps the operator-composed
+    # closure (the fused one's checker)
+    soft_fused = extra == {"soft_chamfer"} and markers.is_cuda and bool(exe["part_soft_fused"])
     if not any(float(st["losses"].get(k, 0.0)) != 0.0 for k in ("chamfer", "soft_chamfer")):
         raise ValueError("the part stage needs a data term: stages.part.losses.chamfer (reference) or soft_chamfer (extension)")
     if "reproject" in extra and any(v is None for v in (joints_2d_gt, focal_length, reproject_mask, camera_center,
@@ -273,6 +278,8 @@ def find_best_part_fits(
 
     indices = torch.from_numpy(np.concatenate([np.where(labels_mode_np == j)[0] for j in chain])).to(device)
     markers_subset = markers[:, indices].contiguous()
+    if soft_fused and int(markers_subset.shape[1]) <= PART_SOFT_MAX_MARKERS:
+        extra = set()
     if st.get("use_full_skeleton"):
         subtrees = [np.arange(0, hierarchy.shape[0]).tolist()]
     else:
@@ -405,6 +412,7 @@ def find_best_part_fits(
                 distance = chamfer_distance(markers_subset, verts[:, vertex_indices].contiguous(),
                                             single_directional=False)[0].item()
             res = {"stats": {"n_eval": n_eval[0], "n_iter": int(optimizer.state[params[0]].get("n_iter", 0)),
+                             "first_loss": optimizer.stats.get("first_loss"), "final_loss": optimizer.stats.get("final_loss"),
                              "device_ms": 0.0, "driver": optimizer.stats.get("driver", "device-lbfgs(host closure)")},
                    "distance": distance, "betas": betas_s.detach().clone(), "root_orient": z_root.clone(),
                    "trans": trans.detach().clone()}
