@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
-    ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation")
+    ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation | hmr_part_soft")
     ap.add_argument("--inflight", type=int, default=3,
                     help="sequences fitted concurrently per GPU (parallel.fit_many): independent sequences overlap on one "
                          "device -- each on its own host thread, stream and workspaces -- which is how a dataset is run; "
@@ -74,6 +74,9 @@ def parse():
                          "profiles/r1_roofline_kernel_stats.csv")
     ap.add_argument("--cpu-evals", type=int, default=20, help="closure evaluations per stage type timed on the CPU")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the hmr_full / hmr_part / mht_rotation legs")
+    ap.add_argument("--soft-operator-fit", action="store_true",
+                    help="also time ONE hmr_part_soft fit on the operator-composed closure (the fused soft closure's checker; "
+                         "~20 s): other_configs.hmr_part_soft.operator_composed_ms_per_step")
     ap.add_argument("--mode", default="sequences", choices=["sequences", "hypotheses", "shared_betas", "frames"],
                     help="how N ranks share the work (SURVEY.md 8e): sequences = independent sequences per rank, no data-path "
                          "collective (default; weak scaling); hypotheses = every step is ONE sequence whose yaw hypotheses "
@@ -106,7 +109,7 @@ TRANSPORT = "auto"
 REDUCERS = []
 
 
-def fit_once(smpl, seq, cfg, dev):
+def fit_once(smpl, seq, cfg, dev, execution=None):
     import contextlib
 
     from uuo_mocap_amd import parallel
@@ -124,7 +127,7 @@ def fit_once(smpl, seq, cfg, dev):
         if red is not None and hasattr(red, "stats") and red not in REDUCERS:
             REDUCERS.append(red)
         out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
-                                     save_stages=False, smpl_inference=smpl)
+                                     save_stages=False, smpl_inference=smpl, execution=execution)
     return out, copy.deepcopy(dict(last_run_stats()))
 
 
@@ -365,7 +368,7 @@ def main():
     smpl = SmplInference(dev, tables=tables)
     F, M = args.frames, args.markers
     n_seq = args.warmup + args.steps
-    limb = args.config == "hmr_part"
+    limb = args.config in ("hmr_part", "hmr_part_soft")
     # distinct seeds for every warm-up and timed sequence of every rank (the solves stop on tolerances, so time depends on
     # the data: a timed step must not repeat a warm-up step)
     seed_base = 0 if MODE in ("hypotheses", "frames") else rank * n_seq   # these modes: all ranks work on the SAME sequences
@@ -521,24 +524,6 @@ def main():
             for name in ("hmr_full", "hmr_part", "mht_rotation", "hmr_part_soft"):
                 cfg_o = packaged_config(name)
                 limb_o = name in ("hmr_part", "hmr_part_soft")
-                if name == "hmr_part_soft":
-                    # EXTENSION (soft-assignment data term in the part stage; operator-composed closures, one candidate after
-                    # the other): seconds per fit -- one fit, no warm-up fit of its own, no in-flight leg
-                    seq_s = make_sequence(tables, seed=1001, num_frames=F, num_markers=10, limb_only=True)
-                    with contextlib.redirect_stdout(io.StringIO()):
-                        torch.cuda.synchronize(dev)
-                        t1 = time.perf_counter()
-                        out_s, st_s = fit_once(smpl, seq_s, cfg_o, dev)
-                        torch.cuda.synchronize(dev)
-                        dt = time.perf_counter() - t1
-                    result["other_configs"][name] = {
-                        "value": F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 1, "sequences_in_flight": 1,
-                        "markers": 10, "closure_evals_per_step": sum(eval_counts(st_s).values()),
-                        "fit_quality_mean": fit_quality(smpl, seq_s, out_s, dev),
-                        "note": "EXTENSION, not a reference configuration: hmr_part.yaml with the soft-min data term "
-                                "(stages.part.losses.soft_chamfer, soft_tau 2.5e-4 m^2); closures composed from the HIP "
-                                "operators under the device L-BFGS driver, candidates one after the other"}
-                    continue
                 seqs_o = [make_sequence(tables, seed=1000 + i, num_frames=F, num_markers=10 if limb_o else M,
                                         limb_only=limb_o) for i in range(n_other + 1)]
                 with contextlib.redirect_stdout(io.StringIO()):
@@ -579,6 +564,21 @@ def main():
                 }
             result["other_configs"]["hmr_full"]["note"] = \
                 "hmr_full.yaml: part stage only (stages.chamfer / stages.marker num_iters 0)"
+            result["other_configs"]["hmr_part_soft"]["note"] = \
+                "EXTENSION, not a reference configuration (BASELINE configs[2] names a soft-assignment path): hmr_part.yaml " \
+                "with the soft-min data term (stages.part.losses.soft_chamfer 10, soft_tau 2.5e-4 m^2) on the FUSED closure " \
+                "(k_part_soft + k_bwd_part in pre mode), all candidates in one lock-step batch like hmr_part"
+            if args.soft_operator_fit:
+                # the fused closure's checker as a timing: the same fit with closures composed from the differentiable HIP
+                # operators, one candidate after the other (round 4's first route: ~23 s per fit)
+                seq_s = make_sequence(tables, seed=1001, num_frames=F, num_markers=10, limb_only=True)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    fit_once(smpl, seq_s, packaged_config("hmr_part_soft"), dev, execution={"part_soft_fused": False})
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t1
+                result["other_configs"]["hmr_part_soft"]["operator_composed_ms_per_step"] = 1e3 * dt
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cpu_budget())  # the CPU leg gets every CPU of the quota (nothing else runs now)
             result["cpu_baseline"] = cpu_baseline(tables, seqs[-1], cfg, n_eval, args.cpu_evals, host_cpu_budget())

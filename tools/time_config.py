@@ -31,7 +31,7 @@ dev = torch.device("cuda:0")
 tables = synthetic_smpl(0)
 smpl = SmplInference(dev, tables=tables)
 cfg = packaged_config(args.config)
-limb = args.config == "hmr_part"
+limb = args.config in ("hmr_part", "hmr_part_soft")
 seqs = [make_sequence(tables, seed=1000 + i, num_frames=args.frames, num_markers=10 if limb else args.markers, limb_only=limb)
         for i in range(args.fits)]
 for i, sq in enumerate(seqs):
