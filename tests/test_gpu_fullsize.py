@@ -765,3 +765,78 @@ def test_soft_assignment_part_stage_end_to_end(smpl, tables, dev, record_propert
     record_property("hmr_part_soft_vs_hard_label_agreement", agree)
     print("hmr_part_soft vs hmr_part: mean vertex distance %.4f m, labels equal %.2f" % (gap, agree))
     assert np.isfinite(gap) and gap < 0.25
+
+
+def test_dense_smpl_backward_at_baseline_size(smpl, oracle_smpl, dev, record_property):
+    """`uuo_smpl_backward` with an upstream gradient on every vertex (what torch autograd computes through smplx.lbs when a
+    caller differentiates SmplInference.forward, reference utils/smpl.py:29-50) runs both blend contractions on the matrix
+    pipe (csrc/dense_bwd.hip).  At 300 frames: against the sparse-gather kernel run over all 6 890 vertices (the route it
+    replaced; UUO_SMPL_BWD_GATHER=1 in the debug flavour) to 1e-5, against autograd through the oracle on a block of frames to
+    2e-4, and how long each takes."""
+    import os
+
+    from uuo_mocap_amd import _lib
+
+    F = 300
+    g = torch.Generator().manual_seed(7)
+    rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
+    betas = torch.randn(1, 10, generator=g)
+    trans = torch.randn(F, 3, generator=g)
+    wv = torch.randn(F, 6890, 3, generator=g)
+    wj = torch.randn(F, 45, 3, generator=g)
+    args = [t.to(dev) for t in (rot[:, 1:].contiguous(), betas, rot[:, :1].contiguous(), trans, wv, wj)]
+    dm = smpl.device_model
+
+    def run(reps):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        out = dm.smpl_backward(*args)   # (first call of a size allocates its scratch)
+        e0.record()
+        for _ in range(reps):
+            out = dm.smpl_backward(*args)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return out, e0.elapsed_time(e1) / reps
+
+    dense, ms_dense = run(10)
+    product = dm.lib
+    os.environ["UUO_SMPL_BWD_GATHER"] = "1"
+    try:
+        dm.lib = _lib.load_debug()
+        gather, ms_gather = run(5)
+    finally:
+        dm.lib = product
+        os.environ.pop("UUO_SMPL_BWD_GATHER", None)
+    for name, a, b in zip(("poses", "betas", "root", "trans"), dense, gather):
+        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        record_property("dense_vs_gather_rel_%s" % name, err)
+        assert err < 1e-5, (name, err)
+    record_property("smpl_backward_ms_dense", ms_dense)
+    record_property("smpl_backward_ms_gather", ms_gather)
+    print("uuo_smpl_backward at 300 frames: dense (matrix pipe) %.3f ms, gather over all vertices %.3f ms" % (ms_dense, ms_gather))
+    # autograd through the oracle IN FLOAT64 on the first 24 frames (a dense CPU backward of all 300 takes minutes): the
+    # distance of both routes from the exact gradient -- the matrix-pipe route must not be the less accurate one
+    import copy
+
+    n = 24
+    o64 = copy.deepcopy(oracle_smpl).double()
+    leaves = [(t[:n] if t.shape[0] == F else t).clone().double().requires_grad_(True) for t in (rot[:, 1:], betas, rot[:, :1], trans)]
+    out = o64(leaves[0], leaves[1].expand(n, 10), leaves[2], leaves[3])
+    ((out["vertices"] * wv[:n].double()).sum() + (out["joints"] * wj[:n].double()).sum()).backward()
+    sub_args = (args[0][:n].contiguous(), args[1], args[2][:n].contiguous(), args[3][:n].contiguous(),
+                args[4][:n].contiguous(), args[5][:n].contiguous())
+    sub_dense = dm.smpl_backward(*sub_args)
+    os.environ["UUO_SMPL_BWD_GATHER"] = "1"
+    try:
+        dm.lib = _lib.load_debug()
+        sub_gather = dm.smpl_backward(*sub_args)
+    finally:
+        dm.lib = product
+        os.environ.pop("UUO_SMPL_BWD_GATHER", None)
+    for name, a, c, b in zip(("poses", "betas", "root", "trans"), sub_dense, sub_gather, leaves):
+        ed = float((a.cpu().double() - b.grad).norm() / b.grad.norm().clamp_min(1e-30))
+        eg = float((c.cpu().double() - b.grad).norm() / b.grad.norm().clamp_min(1e-30))
+        record_property("smpl_backward_err_vs_f64_%s_dense" % name, ed)
+        record_property("smpl_backward_err_vs_f64_%s_gather" % name, eg)
+        print("uuo_smpl_backward vs float64 autograd, d %s: dense %.2e, gather %.2e" % (name, ed, eg))
+        assert ed < 2e-5 and ed < 3.0 * eg + 1e-7, (name, ed, eg)

@@ -65,8 +65,10 @@ struct BwdArgs {
                          // solver's compact packing: the third rows, whose gradient is identically zero, left out)
   uuo_gptr<const float> frames;  // optional: FrameLds of every frame as left by k_pose_prep of this closure
   uuo_gptr<const float> C;       // part stage (k_bwd_part): the cached template + pose-corrective blend [F][V][3]
-  uuo_gptr<const float> pre;     // part stage with a soft assignment (extension): [F][UUO_PRE] sums left by k_part_soft; the item
-                                 // loop is skipped and the kinematic tail runs on them (null: the reference's hard term)
+  uuo_gptr<const float> pre;     // sums of a DENSE backward formed by other kernels: the item loop is skipped and the kinematic tail
+                                 // runs on them (null: the sparse gather).  Part stage (k_bwd_part): [F][UUO_PRE] left by k_part_soft
+                                 // (soft assignment, extension).  General kernel: [F][UUO_PREG] left by uuo_dense_backward (dense_bwd.hip),
+  uuo_gptr<const float> dpf_part;  // with the partials [UUO_DPF_NCB][F][UUO_KP] of d [pose-feature | beta] of its matrix-pipe contraction
   // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
   // (+ the 21 vertex-picked joints) with dL/dv given, instead of markers with a residual
   uuo_gptr<const float> up_verts;   // [F][V][3] or null
@@ -272,8 +274,11 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 #define UUO_FIN_FUSED_BUILT 0
 #define BWD_FP_STORE(i_, v_) a.frame_part[(size_t)f * UUO_FP + (i_)] = (float)(v_)
 #endif
-template <bool PART = false, int NWV = BWD_NW>
+// DENSE (general kernel only): the sums of a dense backward come from dense_bwd.hip (BwdArgs.pre / dpf_part); a separate
+// instantiation, so that the sparse kernel of the fitted stages keeps its register allocation (168 VGPRs, no spill)
+template <bool PART = false, int NWV = BWD_NW, bool DENSE = false>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
+  static_assert(!(PART && DENSE), "the part stage's dense sums come through the runtime `pre` pointer");
   static_assert(NWV == BWD_NW || (PART && NWV == 1), "one-wave blocks exist for the part stage only");
   constexpr int NT = NWV * 64, SLOTS = NWV * 4;  // threads per block, (wave, 16-lane group) item slots
   // latency-bound kernel of a solve chain: do not queue behind co-resident MFMA waves.  (Not the one-wave part-stage form:
@@ -340,16 +345,33 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   BWD_STAMP(1);
   // soft part closure: k_part_soft has already summed the (dense) vertex gradients of this frame -- the joint forces are the
   // translation columns of dA, the rotation blocks are not needed (the yaw's gradient comes as a torque, below)
-  bool use_pre = false;
+  bool use_pre = DENSE;
   if constexpr (PART) use_pre = a.pre.get() != nullptr;  // block-uniform
   if (use_pre) {
-    const float* pr = a.pre.get() + (size_t)f * UUO_PRE;
-    for (int i = tid; i < UUO_NUM_JOINTS * 12; i += NT) {
-      const int jj = i / 12, e = i - jj * 12;
-      sdA[i] = ((e & 3) == 3) ? pr[16 + jj * 3 + (e >> 2)] : 0.f;
+    if constexpr (PART) {
+      const float* pr = a.pre.get() + (size_t)f * UUO_PRE;
+      for (int i = tid; i < UUO_NUM_JOINTS * 12; i += NT) {
+        const int jj = i / 12, e = i - jj * 12;
+        sdA[i] = ((e & 3) == 3) ? pr[16 + jj * 3 + (e >> 2)] : 0.f;
+      }
+      if (tid < 14) red[tid] = pr[tid];
+    } else if constexpr (DENSE) {
+      // dense backward (dense_bwd.hip): d A and d trans per frame from k_dA, d [pose-feature | beta] as the vertex chunks'
+      // partials of k_dpf, summed here in chunk order
+      const float* pr = a.pre.get() + (size_t)f * UUO_PREG;
+      for (int i = tid; i < UUO_NUM_JOINTS * 12; i += NT) sdA[i] = pr[16 + i];
+      if (tid < 4) red[tid] = pr[tid];
+      if (tid < UUO_NUM_POSE_FEATS + UUO_NUM_BETAS) {  // 217 of the block's 256 threads
+        float acc = 0.f;
+        const float* pp = a.dpf_part.get() + (size_t)f * UUO_KP + tid;
+        for (int cb = 0; cb < UUO_DPF_NCB; ++cb) acc += pp[(size_t)cb * F * UUO_KP];
+        if (tid < UUO_NUM_POSE_FEATS) sdpf[tid] = acc;
+        else red[4 + tid - UUO_NUM_POSE_FEATS] = acc;
+      } else if (tid == UUO_NUM_POSE_FEATS + UUO_NUM_BETAS) {
+        sdpf[UUO_NUM_POSE_FEATS] = 0.f;  // (padding entry of the 208-float row)
+      }
     }
-    if (tid < 14) red[tid] = pr[tid];
-  } else {
+  } else if constexpr (!DENSE) {
   float tr[3] = {0.f, 0.f, 0.f};
   if (a.src.trans) {
     tr[0] = a.src.trans[(size_t)f * 3];
@@ -850,6 +872,8 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
   UUO_BATCH_PICK(BwdArgs, batch)
   bwd_body<false>(a);
 }
+// the kinematic tail alone, on the sums of a dense backward (dense_bwd.hip)
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_dense(BwdArgs a) { bwd_body<false, BWD_NW, true>(a); }
 // part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
 // two forms: one wave per frame for <= 16 markers (the candidate search: four items per pass), four waves per frame above
 // that (hmr_full.yaml: 50 markers on the full skeleton would be 13 passes of one wave)
@@ -1418,6 +1442,25 @@ extern "C" int uuo_debug_fit_buffers(uuo_fit_t* fit, float* h_verts, float* h_bb
 #endif  // UUO_DEBUG_HOOKS
 
 
+// upstream gradient of the vertex-picked joints 24..44 (SMPL.forward's VertexJointSelector) added to their vertices'; the
+// picked ids are distinct, one thread each
+__global__ __launch_bounds__(64) void k_add_picked_joints(int V, const UuoTree* __restrict__ tree, const float* __restrict__ up_joints,
+                                                           float* __restrict__ gV) {
+  const int f = blockIdx.x, e = threadIdx.x;
+  if (e >= UUO_NUM_EXTRA_JOINTS) return;
+  const int v = tree->extra_vids[e];
+  for (int k = 0; k < e; ++k)
+    if (tree->extra_vids[k] == v) return;  // (a repeated id: its first occurrence adds all of them, below)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int k = e; k < UUO_NUM_EXTRA_JOINTS; ++k)
+    if (tree->extra_vids[k] == v) {
+      const float* pu = up_joints + ((size_t)f * 45 + UUO_NUM_JOINTS + k) * 3;
+      s0 += pu[0]; s1 += pu[1]; s2 += pu[2];
+    }
+  float* pg = gV + ((size_t)f * V + v) * 3;
+  pg[0] += s0; pg[1] += s1; pg[2] += s2;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // C ABI: backward of SmplInference.forward (reference utils/smpl.py:29-50 is differentiated by torch autograd
 // through smplx.lbs).  Same kernel as the fitted closures, in upstream-gradient mode: every vertex is an item.
@@ -1456,6 +1499,54 @@ extern "C" int uuo_smpl_backward(uuo_model_t* m, void* stream, int F, const floa
   a.frame_part = d_scratch;
   a.off_pose = a.off_root = a.off_z = a.off_trans = -1;
   a.gs_pose = a.gs_root = 9;
+  const int gather = UUO_ENV_INT("UUO_SMPL_BWD_GATHER", 0);  // debug flavour only: every vertex an item of the sparse gather
+  if (d_up_verts && !gather) {
+    // dense route (dense_bwd.hip): both blend contractions on the matrix pipe, the kinematic tail on their sums.  Scratch per
+    // stream, under the entry's mutex across reallocation and launches (as uuo_smpl_forward)
+    uuo_model::BwdScratch* scp;
+    {
+      std::lock_guard<std::mutex> lock(m->fwd_mutex);
+      scp = &m->bwd[s];
+    }
+    uuo_model::BwdScratch& sc = *scp;
+    std::lock_guard<std::mutex> entry_lock(sc.mu);
+    const int nFT = (F + UUO_FT - 1) / UUO_FT;
+    if (sc.capF != F) {
+      if (sc.pfaT) (void)hipFree(sc.pfaT);
+      if (sc.A) (void)hipFree(sc.A);
+      if (sc.frames) (void)hipFree(sc.frames);
+      if (sc.gcopy) (void)hipFree(sc.gcopy);
+      uuo_dense_ws_destroy(sc.ws);
+      sc.pfaT = sc.A = sc.frames = sc.gcopy = nullptr;
+      sc.ws = nullptr;
+      sc.capF = 0;
+      UUO_HIP_CHECK(hipMalloc((void**)&sc.pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&sc.A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&sc.frames, (size_t)F * sizeof(FrameLds)));
+      UUO_HIP_CHECK(hipMemsetAsync(sc.pfaT, 0, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float), s));
+      UUO_HIP_CHECK(hipMemsetAsync(sc.A, 0, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float), s));
+      int rc = uuo_dense_ws_create(m, s, F, &sc.ws);
+      if (rc) return rc;
+      sc.capF = F;
+    }
+    int rc = uuo_launch_pose_prep(m, s, F, a.src, sc.pfaT, sc.A, nullptr, sc.frames);
+    if (rc) return rc;
+    const float* gV = d_up_verts;
+    if (d_up_joints) {  // joints 24..44 are vertices picked by id: their upstream gradient joins the vertices'
+      if (!sc.gcopy) UUO_HIP_CHECK(hipMalloc((void**)&sc.gcopy, (size_t)F * m->V * 3 * sizeof(float)));
+      UUO_HIP_CHECK(hipMemcpyAsync(sc.gcopy, d_up_verts, (size_t)F * m->V * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_add_picked_joints, dim3(F), dim3(64), 0, s, m->V, m->tree, d_up_joints, sc.gcopy);
+      gV = sc.gcopy;
+    }
+    rc = uuo_dense_backward(m, s, F, sc.pfaT, sc.A, gV, sc.ws);
+    if (rc) return rc;
+    a.frames = sc.frames;
+    a.pre = sc.ws->pre;
+    a.dpf_part = sc.ws->part;
+    hipLaunchKernelGGL(k_bwd_dense, dim3(F), dim3(BWD_NW * 64), 0, s, a);
+    UUO_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_bwd_sparse, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;

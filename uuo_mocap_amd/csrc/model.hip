@@ -141,7 +141,38 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
     t.extra_vids[e] = (int)extra[e];
   }
 
+  // dense backward: the basis as the B operand of the transposed contraction (k_dpf), and the joints' vertex lists (k_dA)
+  std::vector<float> PB((size_t)nunits * ngroups * 3 * 256, 0.f);
+  for (int u = 0; u < nunits; ++u)
+    for (int jt = 0; jt < ngroups; ++jt)
+      for (int g = 0; g < 3; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int tt = 0; tt < 4; ++tt) {
+            const int vc = 16 * g + 4 * tt + (l >> 4), v = 16 * u + vc / 3, c = vc % 3;
+            PB[((((size_t)u * ngroups + jt) * 3 + g) * 64 + l) * 4 + tt] = (v < V) ? baug(16 * jt + (l & 15), v, c) : 0.f;
+          }
+  std::vector<int> JLoff(UUO_NUM_JOINTS + 1, 0), JLv;
+  std::vector<float> JLw;
+  for (int j = 0; j < UUO_NUM_JOINTS; ++j) {
+    JLoff[j] = (int)JLv.size();
+    for (int v = 0; v < V; ++v)
+      for (int n = 0; n < 4; ++n)
+        if (Wi[(size_t)v * 4 + n] == j && Ww[(size_t)v * 4 + n] != 0.f) {
+          JLv.push_back(v);
+          JLw.push_back(Ww[(size_t)v * 4 + n]);
+        }
+  }
+  JLoff[UUO_NUM_JOINTS] = (int)JLv.size();
+  if (JLv.empty()) {  // (a model without any skin weight: keep the uploads non-empty)
+    JLv.push_back(0);
+    JLw.push_back(0.f);
+  }
+
   int rc = 0;
+  rc |= upload(&m->PB, PB);
+  rc |= upload(&m->JLoff, JLoff);
+  rc |= upload(&m->JLv, JLv);
+  rc |= upload(&m->JLw, JLw);
   rc |= upload(&m->P3, P3);
   rc |= upload(&m->vt3, vt3);
   rc |= upload(&m->PT, PT);
@@ -167,9 +198,16 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
 
 extern "C" int uuo_model_destroy(uuo_model_t* m) {
   if (!m) return 0;
-  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->Wi, m->Ww, m->tree};
+  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->Wi, m->Ww, m->tree, m->PB, m->JLoff, m->JLv, m->JLw};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& kv : m->bwd) {
+    if (kv.second.pfaT) (void)hipFree(kv.second.pfaT);
+    if (kv.second.A) (void)hipFree(kv.second.A);
+    if (kv.second.frames) (void)hipFree(kv.second.frames);
+    if (kv.second.gcopy) (void)hipFree(kv.second.gcopy);
+    uuo_dense_ws_destroy(kv.second.ws);
+  }
   for (auto& kv : m->fwd) {
     if (kv.second.pfaT) (void)hipFree(kv.second.pfaT);
     if (kv.second.A) (void)hipFree(kv.second.A);

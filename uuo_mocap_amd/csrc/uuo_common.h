@@ -107,6 +107,23 @@ struct uuo_model {
   float* Ww = nullptr;    // [VP][4]
   UuoTree* tree = nullptr;  // device copy
   UuoTree h_tree;
+  // dense backward (dense_bwd.hip): the transposed blend contraction on the matrix pipe
+  float* PB = nullptr;    // [VP/16][14][3][64][4]  augmented basis as the B operand of d pose-feature = d v_posed . P^T:
+                          //   lane l's 4 values of (unit u, feature tile jt, K group g) = Baug[16 jt + (l&15)][coordinate 16 g + 4 t + (l>>4) of the unit]
+  int* JLoff = nullptr;   // [25] joint j's (vertex, weight) pairs are entries JLoff[j] .. JLoff[j+1] of JLv / JLw (vertices ascending)
+  int* JLv = nullptr;
+  float* JLw = nullptr;
+  // scratch of the dense backward, one set per stream (as `fwd`)
+  struct BwdScratch {
+    std::mutex mu;
+    int capF = 0;
+    float* pfaT = nullptr;
+    float* A = nullptr;
+    float* frames = nullptr;
+    struct UuoDenseWs* ws = nullptr;
+    float* gcopy = nullptr;  // [F][V][3] upstream gradient + the vertex-picked joints' (only when up_joints is given)
+  };
+  std::map<hipStream_t, BwdScratch> bwd;
   // scratch of uuo_smpl_forward, one set per stream; `mu` serialises callers that hold the same stream handle
   struct FwdScratch {
     std::mutex mu;
@@ -162,6 +179,26 @@ struct uuo_fit {
   float mask_sum = 0.f;  // host copy of sum(mask) (chamfer normaliser), refreshed by uuo_ensure_mask
   bool shared_pose_cache = false;  // pose_cache belongs to a uuo_batch (not freed with the fit)
 };
+
+// ---- dense backward of the skinning (dense_bwd.hip) ---------------------------------------------------------------------
+// Given dL/dvertices for EVERY vertex (a soft assignment, or a caller differentiating SmplInference.forward), the backward
+// is no longer a gather of <= M items per frame: d pose-feature = d v_posed . P^T is the transposed 207 x 20 670 contraction
+// and runs on the matrix pipe like the forward.  Workspace for F frames:
+struct UuoDenseWs {
+  int F = 0, nFT = 0;
+  float* A_id = nullptr;   // [nFT*16][24][12] identity skinning matrices (v_posed = the forward blend with them)
+  float* vp = nullptr;     // [F][V][3] v_posed = template + pose-corrective + shape blend
+  float* dvpT = nullptr;   // [nFT][VP/16][3][64][4] d v_posed in MFMA A-operand order (frames past F: zeros)
+  float* part = nullptr;   // [UUO_DPF_NCB][F][UUO_KP] partial d[pose-feature | beta] per vertex chunk
+  float* pre = nullptr;    // [F][UUO_PREG]: 0 data-loss sum, 1..3 d trans, 16..303 d A [24][12]
+};
+#define UUO_DPF_NCB 14     // vertex chunks of the transposed contraction (one block per (frame tile, chunk))
+#define UUO_PREG 304
+int uuo_dense_ws_create(const uuo_model* m, hipStream_t s, int F, UuoDenseWs** out);
+void uuo_dense_ws_destroy(UuoDenseWs* ws);
+// pfaT / A: this evaluation's operand tiles and skinning matrices (k_pose_prep); gV [F][V][3].  Fills ws->pre (but entry 0)
+// and ws->part; the caller then runs k_bwd_sparse with BwdArgs.pre = ws->pre, dpf_part = ws->part.
+int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
