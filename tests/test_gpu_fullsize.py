@@ -840,3 +840,62 @@ def test_dense_smpl_backward_at_baseline_size(smpl, oracle_smpl, dev, record_pro
         record_property("smpl_backward_err_vs_f64_%s_gather" % name, eg)
         print("uuo_smpl_backward vs float64 autograd, d %s: dense %.2e, gather %.2e" % (name, ed, eg))
         assert ed < 2e-5 and ed < 3.0 * eg + 1e-7, (name, ed, eg)
+
+
+@pytest.mark.parametrize("F,M,seed,w_hard", [(300, 50, 0, 0.0), (30, 41, 11, 0.0), (30, 41, 11, 4.0)])
+def test_fused_soft_chamfer_closure_against_float64(smpl, oracle_smpl, tables, dev, record_property, F, M, seed, w_hard):
+    """EXTENSION: the chamfer stage's data term with a soft assignment of every marker to ALL 6 890 vertices
+    (`stages.chamfer.losses.soft_chamfer`, masked and normalised like `weighted_chamfer_distance`) on the FUSED closure --
+    forward kernels of the hard closure, soft-min kernels, the dense backward on the matrix pipe (csrc/dense_bwd.hip),
+    `k_bwd_sparse`'s kinematic tail -- against the same objective with the soft term in float64 over the oracle's SMPL forward
+    under autograd, at the BASELINE sizes and a perturbed point: value 2e-5, flat gradient [trans | yaw | shape | pose] 2e-4."""
+    import copy
+
+    from uuo_mocap_amd.engine import ChamferProblem
+
+    cfg = copy.deepcopy(packaged_config("video_mocap"))
+    lw = cfg["stages"]["chamfer"]["losses"]
+    lw["soft_chamfer"], tau = 10.0, 1e-3
+    cfg["stages"]["chamfer"]["soft_tau"] = tau
+    if w_hard == 0.0:
+        del lw["full_chamfer"]
+    else:
+        lw["full_chamfer"] = w_hard
+    _, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    t, z, b, p, _ = _perturbed(F, o_pose, o_betas, root, trans, 2)
+    leaves = [x.clone().requires_grad_(True) for x in (t, z, b, p)]
+    z_root = stages_ref.compute_root_orient_z(leaves[1]) @ root
+    out = stages_ref._smpl_repeat_betas(oracle_smpl, stages_ref.normalize_rot(leaves[3]), leaves[2], stages_ref.normalize_rot(z_root),
+                                        leaves[0])
+    mask = stages_ref.get_marker_mask(markers).double()
+    vs = out["vertices"].double()
+    ref = 0.0
+    for f0 in range(0, F, 20):   # float64 distances, a block of frames at a time
+        d2 = ((markers[f0:f0 + 20].double()[:, :, None] - vs[f0:f0 + 20][:, None]) ** 2).sum(-1)
+        term = 10.0 * (-tau * torch.logsumexp(-d2 / tau, dim=-1)) + w_hard * d2.min(-1)[0]
+        ref = ref + (term * mask[f0:f0 + 20]).sum() / mask.sum()
+    ref = ref + lw["reg_pose_body"] * ((leaves[3] - o_pose) ** 2).mean().double() + lw["reg_betas"] * ((leaves[2] - o_betas) ** 2).mean().double()
+    ref.backward()
+    ref_grad = torch.cat([x.grad.reshape(-1) for x in leaves]).numpy()
+    prob = ChamferProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), cfg)
+    assert prob.problem.w_soft == 10.0
+    x = prob.pack(t.to(dev), z.to(dev), b.to(dev), p.to(dev))
+    loss, grad, nn = prob.evaluate(x)
+    loss2, grad2, _ = prob.evaluate(x)
+    assert loss2 == loss and torch.equal(grad, grad2), "the fused soft closure must be bit-reproducible"
+    g = grad.cpu().numpy()
+    err = _rel_err(g.astype(np.float64), ref_grad.astype(np.float64))
+    record_property("soft_chamfer_closure_%dx%d_grad_rel_l2" % (F, M), err)
+    print("fused soft chamfer closure %dx%d (hard weight %g): loss %.8f vs %.8f, gradient rel-L2 %.2e" % (F, M, w_hard, loss, float(ref), err))
+    np.testing.assert_allclose(loss, float(ref), rtol=2e-5)
+    assert err < 2e-4
+    for name, sl in (("trans", slice(0, 3 * F)), ("yaw", slice(3 * F, 4 * F)), ("betas", slice(4 * F, 4 * F + 10)),
+                     ("pose", slice(4 * F + 10, None))):
+        assert _rel_err(g[sl].astype(np.float64), ref_grad[sl].astype(np.float64)) < 5e-4, name
+    # the assignment it reports is the hard closure's
+    hard = ChamferProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), packaged_config("video_mocap"))
+    _, _, nn_hard = hard.evaluate(x)
+    assert torch.equal(nn, nn_hard)
+    # and the solver runs on it
+    st = prob.solve(x.clone(), max_iter=8, lr=0.1)
+    assert st["final_loss"] < st["first_loss"] and st["n_eval"] >= 8

@@ -1721,7 +1721,17 @@ def test_soft_assignment_chamfer_extension(smpl, golden, dev):
                   root_orient=leaves[2], trans=leaves[3], img_mask=t("img_mask"), marker_labels=None, smpl_inference=smpl,
                   config=cfg)
     st = last_stats("chamfer")
-    assert st["driver"] == "device-lbfgs(host closure)" and st["loss_final"] < 0.7 * st["loss_first"]
+    assert "host closure" not in str(st.get("driver", "")) and st["final_loss"] < 0.7 * st["first_loss"]   # the fused closure (round 4)
+    # ... and its checker, the closure composed from the differentiable operators: same start, same kind of descent
+    cfg["execution"] = {"chamfer_soft_fused": False}
+    leaves2 = [t(k).clone().requires_grad_(True) for k in ("hmr_pose_body", "o_betas", "hmr_root_orient", "trans0")]
+    optim_chamfer(t("markers"), pose_body=leaves2[0], o_pose_body=t("hmr_pose_body"), betas=leaves2[1], o_betas=t("o_betas"),
+                  root_orient=leaves2[2], trans=leaves2[3], img_mask=t("img_mask"), marker_labels=None, smpl_inference=smpl,
+                  config=cfg)
+    so = last_stats("chamfer")
+    assert so["driver"] == "device-lbfgs(host closure)" and so["loss_final"] < 0.7 * so["loss_first"]
+    assert so["loss_first"] == pytest.approx(st["first_loss"], rel=2e-5)
+    assert so["loss_final"] == pytest.approx(st["final_loss"], rel=0.1)
 
 
 @pytest.mark.gpu

@@ -971,8 +971,9 @@ static int validate_problem(const uuo_fit* fit, const uuo_problem_t* p) {
   if (p->stage == UUO_STAGE_MARKER) UUO_REQUIRE(p->d_assign != nullptr, "closure: marker stage needs d_assign");
   if (p->stage == UUO_STAGE_PART)
     UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0 && p->n_subset <= fit->model->V, "closure: part stage needs a vertex subset");
-  UUO_REQUIRE(p->w_soft == 0.f || (p->stage == UUO_STAGE_PART && p->soft_tau > 0.f && p->pose_cache_id != 0 && p->M <= 16),
-              "closure: w_soft is the part stage's soft-assignment term (extension): needs soft_tau > 0, a pose cache id and M <= 16");
+  UUO_REQUIRE(p->w_soft == 0.f || (p->soft_tau > 0.f && p->stage != UUO_STAGE_MARKER), "closure: w_soft (soft-assignment data term, extension) needs soft_tau > 0 and the chamfer or part stage");
+  UUO_REQUIRE(p->w_soft == 0.f || p->stage != UUO_STAGE_PART || (p->pose_cache_id != 0 && p->M <= 16),
+              "closure: the part stage's soft-assignment term needs a pose cache id and M <= 16");
   return 0;
 }
 
@@ -1253,7 +1254,7 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
     denom = (double)fit->mask_sum;  // pytorch3d: div = weights.sum()
   else
     denom = (double)F * (double)M;  // mean over frames and markers
-  const bool soft = p->stage == UUO_STAGE_PART && p->w_soft != 0.f;
+  const bool soft = p->stage != UUO_STAGE_MARKER && p->w_soft != 0.f;
   // (soft part closure: k_part_soft weights its own terms -- w_data min + w_soft softmin -- so only 1 / (F M) is left here)
   const double data_c = (denom > 0.0) ? (soft ? 1.0 : (double)p->w_data) / denom : 0.0;
 
@@ -1318,6 +1319,26 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
       else
         hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
     }
+  } else if (soft && p->stage == UUO_STAGE_CHAMFER) {
+    // EXTENSION: soft-assignment data term of the chamfer stage.  The forward above has skinned the vertices and run the exact
+    // search (dmin, the hard assignment); the soft minimum gives EVERY vertex within reach of a marker a gradient, so the
+    // backward is the dense one: both blend contractions on the matrix pipe (dense_bwd.hip), then this kernel's kinematic
+    // tail (yaw, Gram-Schmidt backward, priors, the solver's statistics) on their sums.
+    UUO_REQUIRE(!uuo_recorder, "closure: the soft-assignment chamfer closure is not available inside a lock-step batch");
+    if (!fit->dense) {
+      rc = uuo_dense_ws_create(m, s, F, &fit->dense);
+      if (rc) return rc;
+      UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_gV, (size_t)F * m->V * 3 * sizeof(float)));
+      UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
+    }
+    rc = uuo_launch_soft_chamfer(s, F, M, m->V, p->d_markers, fit->verts, fit->mask, fit->mask_sum, fit->nn, p->w_data, p->w_soft,
+                                 p->soft_tau, fit->soft_sm, fit->soft_gV, fit->dense->pre, UUO_PREG);
+    if (rc) return rc;
+    rc = uuo_dense_backward(m, s, F, fit->pfaT, fit->A, fit->soft_gV, fit->dense);
+    if (rc) return rc;
+    a.pre = fit->dense->pre;
+    a.dpf_part = fit->dense->part;
+    hipLaunchKernelGGL(k_bwd_dense, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else {
     UUO_REQUIRE(!soft, "closure: the soft-assignment part closure runs on the cached pose blend only");
     // the general kernel finalizes by itself: its last block to finish sums the per-frame partials and reports (bwd_body)

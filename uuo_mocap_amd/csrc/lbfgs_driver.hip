@@ -738,6 +738,9 @@ extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (!fit) return 0;
   if (fit->slab) (void)hipFree(fit->slab);
   if (fit->pose_cache && !fit->shared_pose_cache) (void)hipFree(fit->pose_cache);
+  uuo_dense_ws_destroy(fit->dense);
+  if (fit->soft_gV) (void)hipFree(fit->soft_gV);
+  if (fit->soft_sm) (void)hipFree(fit->soft_sm);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);
   if (fit->ev1) (void)hipEventDestroy(fit->ev1);
   if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);

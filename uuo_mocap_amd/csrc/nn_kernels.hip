@@ -1199,6 +1199,66 @@ extern "C" int uuo_soft_nn_backward(void* stream, int N, int P1, int P2, const f
   return 0;
 }
 
+// ---- the chamfer stage's data term with a soft assignment (EXTENSION), on the fused closure's buffers -------------------------
+//   loss_data = (1 / W) sum_{f,m} mask_fm (w_hard dmin_fm + w_soft softmin_fm),   W = sum mask   (weighted_chamfer_distance's
+// normalisation, losses/chamfer_distance.py:5-21).  dmin and the hard assignment come from the closure's own exact search
+// (keys); the vertices' gradient -- every vertex within reach of a marker gets one -- goes to gV [F][V][3] for the dense
+// backward (dense_bwd.hip), the frame's weighted loss sum to entry 0 of its record.
+__global__ __launch_bounds__(256) void k_softc_prepare(int count, const unsigned long long* __restrict__ keys,
+                                                       const float* __restrict__ mask, float scale, float* __restrict__ dmin,
+                                                       float* __restrict__ gsm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  dmin[i] = __uint_as_float((unsigned)(keys[i] >> 32));
+  gsm[i] = scale * mask[i];  // d loss / d softmin_fm
+}
+__global__ __launch_bounds__(64) void k_softc_finish(int M, int V, const unsigned long long* __restrict__ keys,
+                                                     const float* __restrict__ mask, const float* __restrict__ softmin,
+                                                     const float* __restrict__ x, const float* __restrict__ verts,
+                                                     float w_hard, float w_soft, float c_hard, float* __restrict__ gV,
+                                                     float* __restrict__ pre, int pre_stride) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.f;
+  for (int m = lane; m < M; m += 64) {
+    const size_t o = (size_t)f * M + m;
+    acc += mask[o] * (w_hard * __uint_as_float((unsigned)(keys[o] >> 32)) + w_soft * softmin[o]);
+  }
+  acc = wave_sum_fast(acc);
+  if (lane == 0) {
+    pre[(size_t)f * pre_stride] = acc;
+    if (c_hard != 0.f) {  // the hard term's gradient joins the winners' (markers one after the other: several may share a vertex)
+      for (int m = 0; m < M; ++m) {
+        const size_t o = (size_t)f * M + m;
+        const unsigned idx = (unsigned)(keys[o] & 0xFFFFFFFFull);
+        if (idx >= (unsigned)V) continue;
+        const float sc = -c_hard * mask[o];
+        const float* pv = verts + ((size_t)f * V + idx) * 3;
+        float* pg = gV + ((size_t)f * V + idx) * 3;
+        pg[0] += sc * (x[o * 3] - pv[0]);
+        pg[1] += sc * (x[o * 3 + 1] - pv[1]);
+        pg[2] += sc * (x[o * 3 + 2] - pv[2]);
+      }
+    }
+  }
+}
+// sm: 4 * F * M floats of scratch (dmin | d loss / d softmin | softmin | sum of exp)
+int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* markers, const float* verts, const float* mask,
+                            float mask_sum, const unsigned long long* keys, float w_hard, float w_soft, float tau, float* sm,
+                            float* gV, float* pre, int pre_stride) {
+  UUO_REQUIRE(markers && verts && mask && keys && sm && gV && pre && tau > 0.f, "uuo_launch_soft_chamfer: bad arguments");
+  UUO_REQUIRE(!uuo_recorder, "the soft-assignment chamfer closure is not available inside a lock-step batch");
+  const int n = F * M;
+  float *dmin = sm, *gsm = sm + n, *softmin = sm + 2 * (size_t)n, *sumexp = sm + 3 * (size_t)n;
+  const double inv_w = mask_sum > 0.f ? 1.0 / (double)mask_sum : 0.0;
+  hipLaunchKernelGGL(k_softc_prepare, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, mask, (float)((double)w_soft * inv_w), dmin, gsm);
+  hipLaunchKernelGGL(k_soft_fwd, dim3(M, F), dim3(64), 0, s, M, V, markers, verts, dmin, 1.f / tau, tau, softmin, sumexp);
+  hipLaunchKernelGGL(k_soft_bwd_y, dim3((V + 255) / 256, F), dim3(256), 0, s, M, V, markers, verts, dmin, sumexp, gsm, 1.f / tau, gV);
+  hipLaunchKernelGGL(k_softc_finish, dim3(F), dim3(64), 0, s, M, V, keys, mask, softmin, markers, verts, w_hard, w_soft,
+                     (float)(2.0 * (double)w_hard * inv_w), gV, pre, pre_stride);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Closest point on the body surface (the reference's barycentric placement: igl.signed_distance followed by
 // trimesh.triangles.points_to_barycentric, optimization.py:494-500,519-523).  Brute force over the faces with the

@@ -162,6 +162,9 @@ struct uuo_fit {
   void* slab = nullptr;             // the one device allocation every buffer below (but pose_cache) is carved from
   float* part_sb = nullptr;         // [V][8] per-vertex constants of a part-stage candidate (k_pose_prep -> k_part_fwd)
   float* soft_pre = nullptr;        // [F][UUO_PRE] per-frame sums of the soft part closure (k_part_soft -> k_bwd_part)
+  struct UuoDenseWs* dense = nullptr;  // soft chamfer closure (extension): workspace of the dense backward, its vertex gradient
+  float* soft_gV = nullptr;            // [F][V][3] and [4][F][M] floats of soft-min scratch; allocated on first use
+  float* soft_sm = nullptr;
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics
@@ -199,6 +202,10 @@ void uuo_dense_ws_destroy(UuoDenseWs* ws);
 // pfaT / A: this evaluation's operand tiles and skinning matrices (k_pose_prep); gV [F][V][3].  Fills ws->pre (but entry 0)
 // and ws->part; the caller then runs k_bwd_sparse with BwdArgs.pre = ws->pre, dpf_part = ws->part.
 int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws);
+// the chamfer stage's data term with a soft assignment (nn_kernels.hip); sm: 4 F M floats of scratch
+int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* markers, const float* verts, const float* mask,
+                            float mask_sum, const unsigned long long* keys, float w_hard, float w_soft, float tau, float* sm,
+                            float* gV, float* pre, int pre_stride);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,

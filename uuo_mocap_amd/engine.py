@@ -599,13 +599,21 @@ class ChamferProblem(_StageProblem):
 
     def __init__(self, smpl_inference, markers, o_pose_body, o_betas, root_orient, config):
         losses = config["stages"]["chamfer"]["losses"]
-        unsupported = set(losses) - {"full_chamfer", "reg_pose_body", "reg_betas"}
+        unsupported = set(losses) - {"full_chamfer", "reg_pose_body", "reg_betas", "soft_chamfer"}
         if unsupported:
             raise NotImplementedError("chamfer-stage losses outside the shipped configs: %s" % sorted(unsupported))
         if not config["stages"]["chamfer"]["yaw_lock"]:
             raise NotImplementedError("stages.chamfer.yaw_lock False is not a shipped configuration")
         wd, wp, wb = _cfg_weights(losses, "full_chamfer")
         super().__init__(smpl_inference.device_model, markers, o_pose_body, o_betas, root_orient, wd, wp, wb)
+        # EXTENSION (not in the reference): soft assignment of every marker to the body's vertices, fused closure with the dense
+        # backward on the matrix pipe (csrc/dense_bwd.hip); not available inside lock-step batches
+        w_soft = float(losses.get("soft_chamfer", 0.0))
+        if w_soft != 0.0:
+            self.problem.w_soft = w_soft
+            self.problem.soft_tau = float(config["stages"]["chamfer"].get("soft_tau", 1e-3))
+            if not self.problem.soft_tau > 0.0:
+                raise ValueError("stages.chamfer.soft_tau must be positive")
 
     def pack(self, trans, z_angle, betas, pose_body):
         return torch.cat([_f32(trans, "trans").reshape(-1), _f32(z_angle, "z").reshape(-1),

@@ -59,7 +59,13 @@ def optim_chamfer(
     """Chamfer (pose fitting) stage: L-BFGS over [trans, z_angle, betas, pose_body], lr 0.1.  Mutates
     trans / betas / pose_body in place and applies the optimised yaw to root_orient in place."""
     st = config["stages"]["chamfer"]
-    if (set(st["losses"]) - _CHAMFER_FUSED_LOSSES) or not st["yaw_lock"]:
+    fused_losses = _CHAMFER_FUSED_LOSSES
+    if float(st["losses"].get("soft_chamfer", 0.0)) != 0.0 and markers.is_cuda and \
+            bool((config.get("execution") or {}).get("chamfer_soft_fused", True)):
+        # EXTENSION: the soft-assignment data term has a fused closure (dense backward on the matrix pipe, csrc/dense_bwd.hip);
+        # execution.chamfer_soft_fused: False keeps the operator-composed closure, its checker
+        fused_losses = _CHAMFER_FUSED_LOSSES | {"soft_chamfer"}
+    if (set(st["losses"]) - fused_losses) or not st["yaw_lock"]:
         return _optim_chamfer_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, marker_labels,
                                       smpl_inference, config, initial_angle, repeat, verbose, iter_fn)
     from .parallel import frame_shard
