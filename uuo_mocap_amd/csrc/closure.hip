@@ -1332,7 +1332,8 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
       UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
     }
     rc = uuo_launch_soft_chamfer(s, F, M, m->V, p->d_markers, fit->verts, fit->mask, fit->mask_sum, fit->nn, p->w_data, p->w_soft,
-                                 p->soft_tau, fit->soft_sm, fit->soft_gV, fit->dense->pre, UUO_PREG);
+                                 p->soft_tau, fit->soft_sm, fit->soft_gV, fit->dense->pre, UUO_PREG,
+                                 ((m->VP / 16) <= 512 && M <= 512) ? fit->bbox : nullptr);  // (closure_forward's `cull` condition)
     if (rc) return rc;
     rc = uuo_dense_backward(m, s, F, fit->pfaT, fit->A, fit->soft_gV, fit->dense);
     if (rc) return rc;

@@ -18,141 +18,200 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- d v_posed = T^R^T g, in the A-operand order of k_dpf ----------------------------------------------------------------
 // element (frame f, vertex v, coordinate c): frame tile ft = f / 16, row i = f % 16, unit u = v / 16, K index
-// vc = 3 (v % 16) + c inside the unit: group vc / 16, lane (vc % 4) * 16 + i, slot (vc / 4) % 4   (cf. pose_prep's `put`)
+// vc = 3 (v % 16) + c inside the unit: group vc / 16, lane (vc % 4) * 16 + i, slot (vc / 4) % 4   (cf. pose_prep's `put`).
+// Block = (frame tile, 4 units): the 16 x 64 (frame, vertex) pairs are computed four per thread into an LDS image of the
+// block's 12 KB of tiles, which then leaves as 768 coalesced 16-byte stores (element-wise 4-byte stores from one block per
+// frame, the first version, left every 64-byte line to be assembled from 16 blocks: 27 us; frames past F write zeros).
+#define DVP_UNITS 4
 __global__ __launch_bounds__(256) void k_dvp(int F, int V, int VP, const float* __restrict__ A, const int* __restrict__ Wi,
                                              const float* __restrict__ Ww, const float* __restrict__ gV,
                                              float* __restrict__ dvpT) {
-  __shared__ float sA[UUO_NUM_JOINTS * 12];
-  const int f = blockIdx.y, tid = threadIdx.x;
-  for (int i = tid; i < UUO_NUM_JOINTS * 12; i += 256) sA[i] = A[(size_t)f * UUO_NUM_JOINTS * 12 + i];
-  __syncthreads();
-  const int v = blockIdx.x * 256 + tid;
-  if (v >= VP) return;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  if (v < V) {
-    const float* pg = gV + ((size_t)f * V + v) * 3;
-    g0 = pg[0]; g1 = pg[1]; g2 = pg[2];
+  __shared__ __align__(16) float sA[UUO_FT * UUO_NUM_JOINTS * 12];
+  __shared__ __align__(16) float sT[DVP_UNITS * 3 * 256];
+  const int ft = blockIdx.y, ub = blockIdx.x * DVP_UNITS, tid = threadIdx.x;
+  {
+    const float4* src = reinterpret_cast<const float4*>(A + (size_t)ft * UUO_FT * UUO_NUM_JOINTS * 12);  // (A holds whole tiles)
+    for (int i = tid; i < UUO_FT * UUO_NUM_JOINTS * 3; i += 256) reinterpret_cast<float4*>(sA)[i] = src[i];
   }
+  const int vl64 = tid & 63, v = ub * 16 + vl64;  // < VP: the grid covers whole units
   const int4 wi = *reinterpret_cast<const int4*>(Wi + (size_t)v * 4);
   const float4 ww = *reinterpret_cast<const float4*>(Ww + (size_t)v * 4);
   const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
   const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
-  float T[9];
+  float g[4][3];
 #pragma unroll
-  for (int e = 0; e < 9; ++e) T[e] = 0.f;
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const float* pa = sA + wj[n] * 12;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(wv[n], pa[r * 4 + c], T[r * 3 + c]);
+  for (int k = 0; k < 4; ++k) {
+    const int f = ft * UUO_FT + (tid >> 6) + 4 * k;
+    const bool on = f < F && v < V;
+    const float* pg = gV + ((size_t)(on ? f : 0) * V + (on ? v : 0)) * 3;
+    g[k][0] = on ? pg[0] : 0.f;
+    g[k][1] = on ? pg[1] : 0.f;
+    g[k][2] = on ? pg[2] : 0.f;
   }
+  __syncthreads();
+  const int ul = vl64 >> 4, vl = vl64 & 15;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = (tid >> 6) + 4 * k;
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float* pa = sA + (i * UUO_NUM_JOINTS + wj[n]) * 12;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(wv[n], pa[r * 4 + c], T[r * 3 + c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = fmaf(T[6 + c], g[k][2], fmaf(T[3 + c], g[k][1], T[c] * g[k][0]));
+      const int vc = 3 * vl + c;
+      sT[ul * 768 + (vc >> 4) * 256 + (((vc & 3) * 16 + i) << 2) + ((vc >> 2) & 3)] = d;
+    }
+  }
+  __syncthreads();
   const int nunits = VP / 16;
-  const int ft = f >> 4, i = f & 15, u = v >> 4, vl = v & 15;
-  float* tile = dvpT + ((size_t)ft * nunits + u) * 3 * 256;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float d = fmaf(T[6 + c], g2, fmaf(T[3 + c], g1, T[c] * g0));
-    const int vc = 3 * vl + c;
-    tile[(vc >> 4) * 256 + (((vc & 3) * 16 + i) << 2) + ((vc >> 2) & 3)] = d;
-  }
+  float4* dst = reinterpret_cast<float4*>(dvpT + ((size_t)ft * nunits + ub) * 3 * 256);
+  for (int i = tid; i < DVP_UNITS * 3 * 64; i += 256) dst[i] = reinterpret_cast<const float4*>(sT)[i];
 }
 
 // ---- d A_j = sum over the joint's vertices of w g [v_posed;1]^T; block 24 of a frame: d trans = sum_v g ------------------------
-__global__ __launch_bounds__(64) void k_dA(int F, int V, const int* __restrict__ JLoff, const int* __restrict__ JLv,
-                                           const float* __restrict__ JLw, const float* __restrict__ gV,
-                                           const float* __restrict__ vp, float* __restrict__ pre) {
-  const int j = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+// four waves per (frame, joint): lanes stride the joint's list, DPP wave sums, the waves' sums added in wave order
+#define DA_T 256
+__global__ __launch_bounds__(DA_T) void k_dA(int F, int V, const int* __restrict__ JLoff, const int* __restrict__ JLv,
+                                             const float* __restrict__ JLw, const float* __restrict__ gV,
+                                             const float* __restrict__ vp, float* __restrict__ pre) {
+  __shared__ float sw[DA_T / 64][12];
+  const int j = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* gf = gV + (size_t)f * V * 3;
   float* out = pre + (size_t)f * UUO_PREG;
-  if (j == UUO_NUM_JOINTS) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int v = lane; v < V; v += 64) {
-      s0 += gf[v * 3];
-      s1 += gf[v * 3 + 1];
-      s2 += gf[v * 3 + 2];
-    }
-    s0 = wave_sum_fast(s0);
-    s1 = wave_sum_fast(s1);
-    s2 = wave_sum_fast(s2);
-    if (lane == 0) {
-      out[1] = s0;
-      out[2] = s1;
-      out[3] = s2;
-    }
-    return;
-  }
-  const float* pf = vp + (size_t)f * V * 3;
   float acc[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-  const int e0 = JLoff[j], e1 = JLoff[j + 1];
-  for (int e = e0 + lane; e < e1; e += 64) {
-    const int v = JLv[e];
-    const float w = JLw[e];
-    const float g[3] = {w * gf[v * 3], w * gf[v * 3 + 1], w * gf[v * 3 + 2]};
-    const float p[3] = {pf[v * 3], pf[v * 3 + 1], pf[v * 3 + 2]};
+  if (j == UUO_NUM_JOINTS) {
+    for (int v = tid; v < V; v += DA_T) {
+      acc[0] += gf[v * 3];
+      acc[1] += gf[v * 3 + 1];
+      acc[2] += gf[v * 3 + 2];
+    }
+  } else {
+    const float* pf = vp + (size_t)f * V * 3;
+    const int e0 = JLoff[j], e1 = JLoff[j + 1];
+#pragma unroll 4
+    for (int e = e0 + tid; e < e1; e += DA_T) {
+      const int v = JLv[e];
+      const float w = JLw[e];
+      const float g[3] = {w * gf[v * 3], w * gf[v * 3 + 1], w * gf[v * 3 + 2]};
+      const float p[3] = {pf[v * 3], pf[v * 3 + 1], pf[v * 3 + 2]};
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      acc[r * 4 + 0] = fmaf(g[r], p[0], acc[r * 4 + 0]);
-      acc[r * 4 + 1] = fmaf(g[r], p[1], acc[r * 4 + 1]);
-      acc[r * 4 + 2] = fmaf(g[r], p[2], acc[r * 4 + 2]);
-      acc[r * 4 + 3] += g[r];
+      for (int r = 0; r < 3; ++r) {
+        acc[r * 4 + 0] = fmaf(g[r], p[0], acc[r * 4 + 0]);
+        acc[r * 4 + 1] = fmaf(g[r], p[1], acc[r * 4 + 1]);
+        acc[r * 4 + 2] = fmaf(g[r], p[2], acc[r * 4 + 2]);
+        acc[r * 4 + 3] += g[r];
+      }
     }
   }
 #pragma unroll
   for (int e = 0; e < 12; ++e) {
     const float t = wave_sum_fast(acc[e]);
-    if (lane == 0) out[16 + j * 12 + e] = t;
+    if (lane == 0) sw[wave][e] = t;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    const float t = ((sw[0][tid] + sw[1][tid]) + sw[2][tid]) + sw[3][tid];
+    if (j == UUO_NUM_JOINTS) {
+      if (tid < 3) out[1 + tid] = t;
+    } else {
+      out[16 + j * 12 + tid] = t;
+    }
   }
 }
 
 // ---- d [pose-feature | beta] = d v_posed . Baug^T on the matrix pipe -------------------------------------------------------------
 // D[16 frames x 16 features] += A[16 frames x 4 coordinates] . B[4 coordinates x 16 features]; a unit of 16 vertices is 12
-// K-steps, 14 feature tiles: 168 MFMAs, as many as the forward spends on it.  Block = (frame tile, one of 14 vertex chunks),
-// its 8 waves take the chunk's units round-robin and keep 14 accumulator tiles; the waves' tiles are summed through LDS in
-// wave order and written as the chunk's partial.  XCD x owns chunks x and x + 8: all frame tiles of a chunk share one L2
-// slice of the basis (1.3 MB).
-#define DPF_WAVES 8
+// K-steps, 14 feature tiles: 168 MFMAs, as many as the forward spends on it.  Block = (frame tile, one of 27 vertex chunks of
+// 16 units), its 4 waves take the chunk's units round-robin (4 each) and keep 14 accumulator tiles; the waves' tiles are summed
+// through LDS in wave order and written as the chunk's partial.  57 KB of LDS: two blocks per CU, so the 513 blocks of a
+// 300-frame launch are resident at once (the first version -- 8 waves, 114 KB, 266 blocks on 256 CUs -- ran ten CUs twice:
+// 58 us).  XCD x owns chunks x, x + 8, x + 16, x + 24: all frame tiles of a chunk share one L2 slice of the basis (0.7 MB).
+#define DPF_WAVES 4
 __global__ __launch_bounds__(DPF_WAVES * 64) void k_dpf(const float4* __restrict__ PB, const float4* __restrict__ dvpT,
                                                          float* __restrict__ part, int nFT, int nunits, int F) {
   __shared__ float red[DPF_WAVES][14 * 256];
   const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
-  const int cb = xcd + 8 * (pos & 1), ft = pos >> 1;
+  const int cb = xcd + 8 * (pos & 3), ft = pos >> 2;
   if (cb >= UUO_DPF_NCB || ft >= nFT) return;  // block-uniform
   const int u0 = (cb * nunits) / UUO_DPF_NCB, u1 = ((cb + 1) * nunits) / UUO_DPF_NCB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   f32x4 acc[14];
 #pragma unroll
   for (int jt = 0; jt < 14; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = u0 + wave; u < u1; u += DPF_WAVES) {
-    const float4* pa = dvpT + ((size_t)ft * nunits + u) * 3 * 64 + lane;
-    const float4 a0 = pa[0], a1 = pa[64], a2 = pa[128];
-    const float4* pb = PB + (size_t)u * 14 * 3 * 64 + lane;
-    float4 b[2][3];
-    b[0][0] = pb[0];
-    b[0][1] = pb[64];
-    b[0][2] = pb[128];
+  // The basis streams through a ring of 7 stages (one stage = the 3 K-groups of one feature tile), refilled DPF_LEAD tiles
+  // ahead and across the unit boundary; the next unit's d v_posed tiles are requested at tile 8 of the current one.
+  constexpr int DPF_RING = 7, DPF_LEAD = 4;
+  const int nu = (u1 - (u0 + wave) + DPF_WAVES - 1) / DPF_WAVES;  // units of this wave (<= 0: none)
+  if (nu > 0) {
+    float4 ring[DPF_RING][3];
+    auto pbase = [&](int ui) { return PB + (size_t)(u0 + wave + ui * DPF_WAVES) * 14 * 3 * 64 + lane; };
+    auto abase = [&](int ui) { return dvpT + ((size_t)ft * nunits + (u0 + wave + ui * DPF_WAVES)) * 3 * 64 + lane; };
+    {
+      const float4* pb = pbase(0);
 #pragma unroll
-    for (int jt = 0; jt < 14; ++jt) {
-      const int cur = jt & 1;
-      if (jt + 1 < 14) {
-        b[cur ^ 1][0] = pb[((jt + 1) * 3 + 0) * 64];
-        b[cur ^ 1][1] = pb[((jt + 1) * 3 + 1) * 64];
-        b[cur ^ 1][2] = pb[((jt + 1) * 3 + 2) * 64];
+      for (int st = 0; st < DPF_LEAD; ++st) {
+        ring[st][0] = pb[(st * 3 + 0) * 64];
+        ring[st][1] = pb[(st * 3 + 1) * 64];
+        ring[st][2] = pb[(st * 3 + 2) * 64];
       }
-      f32x4 d = acc[jt];
+    }
+    float4 an0, an1, an2;
+    {
+      const float4* pa = abase(0);
+      an0 = pa[0];
+      an1 = pa[64];
+      an2 = pa[128];
+    }
+    for (int ui = 0; ui < nu; ++ui) {
+      const float4 a0 = an0, a1 = an1, a2 = an2;
+      const float4* pb = pbase(ui);
+      const bool more = ui + 1 < nu;
+      const float4* pbn = pbase(more ? ui + 1 : ui);
+#pragma unroll
+      for (int jt = 0; jt < 14; ++jt) {
+        {  // refill the stage that tile jt + DPF_LEAD will read (this unit's, or the next unit's first tiles).  No branch
+          // anywhere in the unit's body: past the wave's last unit the refills re-read its own first tiles, so the compiler's
+          // vmcnt bookkeeping stays exact and the loads stay DPF_LEAD tiles ahead of the MFMAs that use them
+          const int jn = jt + DPF_LEAD;
+          const float4* src = (jn < 14) ? pb + (size_t)(jn * 3) * 64 : pbn + (size_t)((jn - 14) * 3) * 64;
+          ring[jn % DPF_RING][0] = src[0];
+          ring[jn % DPF_RING][1] = src[64];
+          ring[jn % DPF_RING][2] = src[128];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise gathers a unit's loads at its top and drains them before the back-edge)
+        if (jt == 8) {
+          const float4* pa = abase(more ? ui + 1 : ui);
+          an0 = pa[0];
+          an1 = pa[64];
+          an2 = pa[128];
+        }
+        // one accumulator chain per tile: back-to-back dependent MFMAs forward their accumulator (two alternating chains,
+        // dependent distance 2, measured 47 us against 40)
+        f32x4 d = acc[jt];
+        const float4 b0 = ring[jt % DPF_RING][0], b1 = ring[jt % DPF_RING][1], b2 = ring[jt % DPF_RING][2];
 #define DPF_STEP(av, bv)                                                  \
   d = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, d, 0, 0, 0);       \
   d = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, d, 0, 0, 0);       \
   d = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, d, 0, 0, 0);       \
   d = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, d, 0, 0, 0);
-      DPF_STEP(a0, b[cur][0])
-      DPF_STEP(a1, b[cur][1])
-      DPF_STEP(a2, b[cur][2])
+        DPF_STEP(a0, b0)
+        DPF_STEP(a1, b1)
+        DPF_STEP(a2, b2)
 #undef DPF_STEP
-      acc[jt] = d;
+        acc[jt] = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 #pragma unroll
@@ -214,9 +273,9 @@ int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pf
   // v_posed: the forward's own contraction with identity skinning matrices and no translation
   int rc = uuo_launch_skin(m, s, F, pfaT, ws->A_id, nullptr, ws->vp, nullptr);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_dvp, dim3((m->VP + 255) / 256, F), dim3(256), 0, s, F, m->V, m->VP, A, m->Wi, m->Ww, gV, ws->dvpT);
-  hipLaunchKernelGGL(k_dA, dim3(UUO_NUM_JOINTS + 1, F), dim3(64), 0, s, F, m->V, m->JLoff, m->JLv, m->JLw, gV, ws->vp, ws->pre);
-  hipLaunchKernelGGL(k_dpf, dim3(8 * 2 * ws->nFT), dim3(DPF_WAVES * 64), 0, s, reinterpret_cast<const float4*>(m->PB),
+  hipLaunchKernelGGL(k_dvp, dim3((m->VP / 16) / DVP_UNITS, ws->nFT), dim3(256), 0, s, F, m->V, m->VP, A, m->Wi, m->Ww, gV, ws->dvpT);
+  hipLaunchKernelGGL(k_dA, dim3(UUO_NUM_JOINTS + 1, F), dim3(DA_T), 0, s, F, m->V, m->JLoff, m->JLv, m->JLw, gV, ws->vp, ws->pre);
+  hipLaunchKernelGGL(k_dpf, dim3(8 * 4 * ws->nFT), dim3(DPF_WAVES * 64), 0, s, reinterpret_cast<const float4*>(m->PB),
                      reinterpret_cast<const float4*>(ws->dvpT), ws->part, ws->nFT, m->VP / 16, F);
   UUO_HIP_CHECK(hipGetLastError());
   return 0;

@@ -1241,18 +1241,128 @@ __global__ __launch_bounds__(64) void k_softc_finish(int M, int V, const unsigne
     }
   }
 }
-// sm: 4 * F * M floats of scratch (dmin | d loss / d softmin | softmin | sum of exp)
+// The same two soft-min kernels pruned by the unit boxes k_skin2 leaves (16 vertices each): a (marker, unit) pair whose box lies
+// farther than dmin + cut from the marker holds only vertices with exp((dmin - d2)/tau) < exp(-cut/tau) = 2^-36 -- six thousand of
+// them move the normaliser S >= 1 by less than 1e-7 -- and is skipped.  The box bound is k_nn_cull's (every operation monotone,
+// the distance's own summation order), so the unit of the nearest vertex always survives.
+__device__ __forceinline__ float softc_box_lb(const float* __restrict__ b, float x, float y, float z) {
+  const float dx = fmaxf(fmaxf(b[0] - x, x - b[3]), 0.f), dy = fmaxf(fmaxf(b[1] - y, y - b[4]), 0.f),
+              dz = fmaxf(fmaxf(b[2] - z, z - b[5]), 0.f);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+// forward: one wave per (frame, marker); surviving units listed in ascending order, four units per pass (16 lanes each)
+__global__ __launch_bounds__(256) void k_softc_fwd(int M, int V, int nur, const float* __restrict__ x, const float* __restrict__ verts,
+                                                   const float* __restrict__ bbox, const float* __restrict__ dmin, float inv_tau,
+                                                   float tau, float cut, float* __restrict__ softmin, float* __restrict__ sumexp) {
+  __shared__ unsigned short list[4][512];
+  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  const bool on = m < M;
+  const size_t o = (size_t)f * M + (on ? m : 0);
+  const float qx = x[o * 3], qy = x[o * 3 + 1], qz = x[o * 3 + 2], dm = dmin[o];
+  const float* bf = bbox + (size_t)f * nur * 6;
+  int n = 0;
+  for (int u0 = 0; u0 < nur; u0 += 64) {
+    const int u = u0 + lane;
+    const bool keep = on && u < nur && (softc_box_lb(bf + (size_t)u * 6, qx, qy, qz) - dm) <= cut;
+    const unsigned long long b = __ballot(keep);
+    if (keep) list[wave][n + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)u;
+    n += __popcll(b);
+  }
+  __syncthreads();
+  const float* vf = verts + (size_t)f * V * 3;
+  float s = 0.f;
+  for (int k = 0; k < n; k += 4) {
+    const int idx = k + (lane >> 4);
+    if (idx < n) {
+      const int v = (int)list[wave][idx] * 16 + (lane & 15);
+      if (v < V) s += __expf((dm - sqdist(qx, qy, qz, vf[v * 3], vf[v * 3 + 1], vf[v * 3 + 2])) * inv_tau);
+    }
+  }
+  s = wave_sum_fast(s);
+  if (on && lane == 0) {
+    sumexp[o] = s;
+    softmin[o] = dm - tau * __logf(s);
+  }
+}
+// backward: thread = vertex, block = 16 units; wave 0 lists the markers within reach of the block's boxes (ascending), all
+// threads then visit those only
+__global__ __launch_bounds__(256) void k_softc_bwd(int M, int V, int nur, const float* __restrict__ x, const float* __restrict__ verts,
+                                                   const float* __restrict__ bbox, const float* __restrict__ dmin,
+                                                   const float* __restrict__ sumexp, const float* __restrict__ gq, float inv_tau,
+                                                   float cut, float* __restrict__ gV) {
+  __shared__ float sq[64 * 5];
+  __shared__ float sb[16 * 6];
+  __shared__ int s_n;
+  const int f = blockIdx.y, tid = threadIdx.x, ub = blockIdx.x * 16;
+  const int j = ub * 16 + tid;
+  const float* vf = verts + (size_t)f * V * 3;
+  const bool on = j < V;
+  const float cx = on ? vf[j * 3] : 0.f, cy = on ? vf[j * 3 + 1] : 0.f, cz = on ? vf[j * 3 + 2] : 0.f;
+  if (tid < 16 * 6) {
+    const int u = ub + tid / 6;
+    sb[tid] = (u < nur) ? bbox[((size_t)f * nur + u) * 6 + tid % 6] : ((tid % 6 < 3) ? 3.0e38f : -3.0e38f);  // (an empty box: infinitely far)
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int q0 = 0; q0 < M; q0 += 64) {
+    __syncthreads();
+    if (tid < 64) {
+      const int q = q0 + tid;
+      const bool qon = q < M;
+      const size_t o = (size_t)f * M + (qon ? q : 0);
+      const float qx = x[o * 3], qy = x[o * 3 + 1], qz = x[o * 3 + 2], dm = dmin[o], g = qon ? gq[o] : 0.f;
+      float lb = 3.0e38f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) lb = fminf(lb, softc_box_lb(sb + u * 6, qx, qy, qz));
+      const bool keep = qon && g != 0.f && (lb - dm) <= cut;
+      const unsigned long long b = __ballot(keep);
+      if (keep) {
+        const int pos = __popcll(b & ((1ull << tid) - 1ull));
+        sq[pos * 5] = qx; sq[pos * 5 + 1] = qy; sq[pos * 5 + 2] = qz; sq[pos * 5 + 3] = dm;
+        sq[pos * 5 + 4] = g / sumexp[o];
+      }
+      if (tid == 0) s_n = __popcll(b);
+    }
+    __syncthreads();
+    const int nq = s_n;
+    for (int t = 0; t < nq; ++t) {
+      const float qx = sq[t * 5], qy = sq[t * 5 + 1], qz = sq[t * 5 + 2];
+      const float d2 = sqdist(qx, qy, qz, cx, cy, cz);
+      const float w = sq[t * 5 + 4] * __expf((sq[t * 5 + 3] - d2) * inv_tau);
+      a0 = fmaf(w, qx - cx, a0);
+      a1 = fmaf(w, qy - cy, a1);
+      a2 = fmaf(w, qz - cz, a2);
+    }
+  }
+  if (on) {
+    float* o = gV + ((size_t)f * V + j) * 3;
+    o[0] = -2.f * a0; o[1] = -2.f * a1; o[2] = -2.f * a2;
+  }
+}
+#define SOFTC_CUT_TAUS 24.953298500f  // 36 ln 2
+
+// sm: 4 * F * M floats of scratch (dmin | d loss / d softmin | softmin | sum of exp); bbox: k_skin2's unit boxes [F][ceil(V/16)][6]
+// of THESE vertices, or null (brute force over all vertices)
 int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* markers, const float* verts, const float* mask,
                             float mask_sum, const unsigned long long* keys, float w_hard, float w_soft, float tau, float* sm,
-                            float* gV, float* pre, int pre_stride) {
+                            float* gV, float* pre, int pre_stride, const float* bbox) {
   UUO_REQUIRE(markers && verts && mask && keys && sm && gV && pre && tau > 0.f, "uuo_launch_soft_chamfer: bad arguments");
   UUO_REQUIRE(!uuo_recorder, "the soft-assignment chamfer closure is not available inside a lock-step batch");
   const int n = F * M;
   float *dmin = sm, *gsm = sm + n, *softmin = sm + 2 * (size_t)n, *sumexp = sm + 3 * (size_t)n;
   const double inv_w = mask_sum > 0.f ? 1.0 / (double)mask_sum : 0.0;
   hipLaunchKernelGGL(k_softc_prepare, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, mask, (float)((double)w_soft * inv_w), dmin, gsm);
-  hipLaunchKernelGGL(k_soft_fwd, dim3(M, F), dim3(64), 0, s, M, V, markers, verts, dmin, 1.f / tau, tau, softmin, sumexp);
-  hipLaunchKernelGGL(k_soft_bwd_y, dim3((V + 255) / 256, F), dim3(256), 0, s, M, V, markers, verts, dmin, sumexp, gsm, 1.f / tau, gV);
+  const int nur = (V + 15) / 16;
+  if (bbox && nur <= 512) {
+    const float cut = SOFTC_CUT_TAUS * tau;
+    hipLaunchKernelGGL(k_softc_fwd, dim3((M + 3) / 4, F), dim3(256), 0, s, M, V, nur, markers, verts, bbox, dmin, 1.f / tau, tau, cut,
+                       softmin, sumexp);
+    hipLaunchKernelGGL(k_softc_bwd, dim3((nur + 15) / 16, F), dim3(256), 0, s, M, V, nur, markers, verts, bbox, dmin, sumexp, gsm,
+                       1.f / tau, cut, gV);
+  } else {
+    hipLaunchKernelGGL(k_soft_fwd, dim3(M, F), dim3(64), 0, s, M, V, markers, verts, dmin, 1.f / tau, tau, softmin, sumexp);
+    hipLaunchKernelGGL(k_soft_bwd_y, dim3((V + 255) / 256, F), dim3(256), 0, s, M, V, markers, verts, dmin, sumexp, gsm, 1.f / tau, gV);
+  }
   hipLaunchKernelGGL(k_softc_finish, dim3(F), dim3(64), 0, s, M, V, keys, mask, softmin, markers, verts, w_hard, w_soft,
                      (float)(2.0 * (double)w_hard * inv_w), gV, pre, pre_stride);
   UUO_HIP_CHECK(hipGetLastError());

@@ -195,7 +195,7 @@ struct UuoDenseWs {
   float* part = nullptr;   // [UUO_DPF_NCB][F][UUO_KP] partial d[pose-feature | beta] per vertex chunk
   float* pre = nullptr;    // [F][UUO_PREG]: 0 data-loss sum, 1..3 d trans, 16..303 d A [24][12]
 };
-#define UUO_DPF_NCB 14     // vertex chunks of the transposed contraction (one block per (frame tile, chunk))
+#define UUO_DPF_NCB 27     // vertex chunks of the transposed contraction (one block per (frame tile, chunk))
 #define UUO_PREG 304
 int uuo_dense_ws_create(const uuo_model* m, hipStream_t s, int F, UuoDenseWs** out);
 void uuo_dense_ws_destroy(UuoDenseWs* ws);
@@ -205,7 +205,7 @@ int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pf
 // the chamfer stage's data term with a soft assignment (nn_kernels.hip); sm: 4 F M floats of scratch
 int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* markers, const float* verts, const float* mask,
                             float mask_sum, const unsigned long long* keys, float w_hard, float w_soft, float tau, float* sm,
-                            float* gV, float* pre, int pre_stride);
+                            float* gV, float* pre, int pre_stride, const float* bbox);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
