@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
-    ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation | hmr_part_soft")
+    ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation | hmr_part_soft | video_mocap_soft")
     ap.add_argument("--inflight", type=int, default=3,
                     help="sequences fitted concurrently per GPU (parallel.fit_many): independent sequences overlap on one "
                          "device -- each on its own host thread, stream and workspaces -- which is how a dataset is run; "
@@ -521,7 +521,7 @@ def main():
             # config (one yaw hypothesis)
             result["other_configs"] = {}
             n_other = min(args.steps, 4)
-            for name in ("hmr_full", "hmr_part", "mht_rotation", "hmr_part_soft"):
+            for name in ("hmr_full", "hmr_part", "mht_rotation", "hmr_part_soft", "video_mocap_soft"):
                 cfg_o = packaged_config(name)
                 limb_o = name in ("hmr_part", "hmr_part_soft")
                 seqs_o = [make_sequence(tables, seed=1000 + i, num_frames=F, num_markers=10 if limb_o else M,
@@ -568,6 +568,10 @@ def main():
                 "EXTENSION, not a reference configuration (BASELINE configs[2] names a soft-assignment path): hmr_part.yaml " \
                 "with the soft-min data term (stages.part.losses.soft_chamfer 10, soft_tau 2.5e-4 m^2) on the FUSED closure " \
                 "(k_part_soft + k_bwd_part in pre mode), all candidates in one lock-step batch like hmr_part"
+            result["other_configs"]["video_mocap_soft"]["note"] = \
+                "EXTENSION, not a reference configuration (the north star names a soft-assignment Chamfer distance): " \
+                "video_mocap.yaml with the chamfer stage's data term soft over all 6 890 vertices (soft_chamfer 10, soft_tau 1e-3 " \
+                "m^2) on the fused closure: box-pruned soft-min kernels + the dense backward on the matrix pipe (csrc/dense_bwd.hip)"
             if args.soft_operator_fit:
                 # the fused closure's checker as a timing: the same fit with closures composed from the differentiable HIP
                 # operators, one candidate after the other (round 4's first route: ~23 s per fit)

@@ -899,3 +899,28 @@ def test_fused_soft_chamfer_closure_against_float64(smpl, oracle_smpl, tables, d
     # and the solver runs on it
     st = prob.solve(x.clone(), max_iter=8, lr=0.1)
     assert st["final_loss"] < st["first_loss"] and st["n_eval"] >= 8
+
+
+def test_soft_assignment_chamfer_stage_end_to_end(smpl, tables, dev, record_property):
+    """EXTENSION: `video_mocap_soft.yaml` (the full method with the chamfer stage's data term soft over all vertices, fused
+    closure) fits a 60 x 30 sequence through the orchestrator and recovers the synthetic ground truth about as well as the
+    reference's hard term does."""
+    import copy
+
+    from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
+
+    seq = make_sequence(tables, seed=5, num_frames=60, num_markers=30)
+    errs = {}
+    for name in ("video_mocap", "video_mocap_soft"):
+        cfg = packaged_config(name)
+        out = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[],
+                                     save_stages=False, smpl_inference=smpl)
+        st = copy.deepcopy(dict(last_run_stats()))
+        assert len(st["chamfer"]) == cfg["num_root_orient_angles"]
+        assert not any("host closure" in str(s_.get("driver", "")) for s_ in st["chamfer"])
+        v = smpl(out["pose_body"].to(dev), out["betas"].to(dev), out["root_orient"].to(dev), out["trans"].to(dev))["vertices"]
+        gt = torch.from_numpy(seq.gt["verts"]).float().to(dev)
+        errs[name] = float((v - gt).norm(dim=-1).mean())
+        record_property("e2e_60x30_%s_v2v_m" % name, errs[name])
+    print("60 x 30 full method, mean vertex error: hard %.4f m, soft chamfer stage %.4f m" % (errs["video_mocap"], errs["video_mocap_soft"]))
+    assert errs["video_mocap_soft"] < max(2.0 * errs["video_mocap"], 0.02)
