@@ -4,6 +4,25 @@
 //  * dot products accumulate in fp64,
 //  * every kernel has two launch forms over one device body: k_X(XArgs) and k_X_b(const XArgs* batch) (uuo_common.h).
 #include "lbfgs.h"
+
+// a 16-byte read of the history: NON-TEMPORAL -- a pass streams its 36 MB exactly once, and with twelve solves in flight what
+// those bytes displace from the L2s are the skinning kernel's basis slices and the backward's posedirs rows.  Same values,
+// same arithmetic (bit-identical fits); alternating builds in one call, three rounds of 12 fits each: 5.305 / 5.442 / 5.354
+// -> 5.429 / 5.477 / 5.382 M frame-evaluations/s, and with k_skin2's vertex stores non-temporal as well 5.437 / 5.322 / 5.365
+// -> 5.441 / 5.466 / 5.487 (those stores alone: no change, left as they were) -- +1-2 % (profiles/r4_ab_nontemporal.log).
+// -DLB_NT=0 restores plain loads.
+#ifndef LB_NT
+#define LB_NT 1
+#endif
+typedef float lb_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lb_ld_hist(const float* p) {
+#if LB_NT
+  const lb_f4 v = __builtin_nontemporal_load(reinterpret_cast<const lb_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
 #include "frame_math.h"
 
 #ifndef LB_PASS_PRIO
@@ -203,7 +222,7 @@ __device__ __forceinline__ void lb_dots_body(int n, int cap, int capL, int head,
     np_ = *reinterpret_cast<const float4*>(gp + i);
     nd = *reinterpret_cast<const float4*>(d + i);
 #pragma unroll
-    for (int q = 0; q < LB_DRW; ++q) nr[q] = *reinterpret_cast<const float4*>(rptr[q] + cboff);
+    for (int q = 0; q < LB_DRW; ++q) nr[q] = lb_ld_hist(rptr[q] + cboff);
   };
   const int hb0 = cb0 * 2, hb1 = cb1 * 2;
   if (hb0 < hb1) issue(hb0);
@@ -604,8 +623,8 @@ __device__ __forceinline__ void lb_direction_body(int n, int cap, int capL, cons
 #pragma unroll
       for (int u = 0; u < 8; ++u) {  // zero coefficients beyond k; slot 0 is a valid row to read
         const size_t off = (size_t)sslot[j0 + u] * LB_CW;
-        yv[buf][u] = *reinterpret_cast<const float4*>(Yb + off);
-        sv[buf][u] = *reinterpret_cast<const float4*>(Sb + off);
+        yv[buf][u] = lb_ld_hist(Yb + off);
+        sv[buf][u] = lb_ld_hist(Sb + off);
       }
     };
     lbf2 alo{0.f, 0.f}, ahi{0.f, 0.f};

@@ -154,6 +154,11 @@ __device__ __forceinline__ float row16_max(float v) {
   return fmaxf(v, dpp_row<0x121>(v));
 }
 #define UUO_BIG 3.0e38f
+// cache policy of k_skin2's vertex stores (buffer instruction aux bits; 2 = nt: 25 MB written once per launch and read back
+// only in part by the pruned search need not displace the basis slices from the L2s) -- A/B builds
+#ifndef SK2_ST_AUX
+#define SK2_ST_AUX 0
+#endif
 #ifndef SKIN_WAVES
 #define SKIN_WAVES 8  // waves per block of the skinning kernels (4: A/B builds only, one wave per SIMD)
 #endif
@@ -453,7 +458,7 @@ __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& 
       E.o[0] += E.tr.x; E.o[1] += E.tr.y; E.o[2] += E.tr.z;
       u32x3 o = {__builtin_bit_cast(unsigned, E.o[0]), __builtin_bit_cast(unsigned, E.o[1]),
                  __builtin_bit_cast(unsigned, E.o[2])};
-      __builtin_amdgcn_raw_buffer_store_b96(o, rv, E.vo + e * v12, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b96(o, rv, E.vo + e * v12, 0, SK2_ST_AUX);
     } else if (BBOX && k == 5) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) E.bx[c] = E.bx[3 + c] = E.o[c];
