@@ -61,7 +61,10 @@ int uuo_smpl_forward(uuo_model_t* model, void* stream, int F, const float* d_pos
  * caller differentiates SmplInference.forward itself, e.g. a user-written closure; reference utils/smpl.py:29-50).
  *   d_up_verts  [F,6890,3] dL/dvertices or NULL,  d_up_joints [F,45,3] dL/djoints or NULL (at least one)
  *   d_g_poses [F,23,3,3], d_g_betas [F,10] (per frame: sum the rows if betas had one row), d_g_root [F,1,3,3],
- *   d_g_trans [F,3];  d_scratch: F*24 floats of device scratch.  Asynchronous on `stream`. */
+ *   d_g_trans [F,3];  d_scratch: F*24 floats of device scratch.  Asynchronous on `stream`.
+ * With d_up_verts the backward is dense (every vertex carries a gradient): v_posed and the transposed 207 x 20670 blend
+ * contraction run on the matrix pipe (csrc/dense_bwd.hip); the library keeps ~80 MB of scratch per stream and frame count
+ * for it (allocated on first use, freed with the model). */
 int uuo_smpl_backward(uuo_model_t* model, void* stream, int F, const float* d_poses, const float* d_betas,
                       int betas_rows, const float* d_root, const float* d_trans, const float* d_up_verts,
                       const float* d_up_joints, float* d_g_poses, float* d_g_betas, float* d_g_root, float* d_g_trans,
@@ -141,11 +144,15 @@ typedef struct {
   uint64_t pose_cache_id;    /* part stage: non-zero = the body pose d_o_pose is constant for every evaluation that
                                 carries this id, so the pose-corrective blend (207 x 20670 contraction, 70 % of the
                                 forward's arithmetic) is computed once and re-used; 0 = recompute every evaluation */
-  /* EXTENSION (not reference behaviour; BASELINE configs[2] "hmr_part.yaml, soft-assignment path"): the part stage's data
-   * term with the hard minimum over the candidate's vertices (markers/markers_utils.py:471-475) joined or replaced by the
-   * soft minimum  -tau log sum_v exp(-|x - v|^2 / tau):  loss_data = (1 / (F M)) sum_{f,m} (w_data min_v d2 + w_soft softmin).
-   * Fused closure (k_part_soft): needs pose_cache_id != 0 and M <= 16.  w_soft = 0: the reference's term alone. */
-  float w_soft;              /* stages.part.losses.soft_chamfer (0 = absent) */
+  /* EXTENSION (not reference behaviour; BASELINE's north star names a soft-assignment Chamfer distance, configs[2] a
+   * "soft-assignment path" of hmr_part.yaml): the data term's hard minimum over the vertices joined or replaced by the soft
+   * minimum  -tau log sum_v exp(-|x - v|^2 / tau).  w_soft = 0: the reference's term alone.
+   *   UUO_STAGE_PART    loss_data = (1 / (F M)) sum_{f,m} (w_data min_v d2 + w_soft softmin) over the candidate's vertices
+   *                     (markers/markers_utils.py:471-475); fused closure k_part_soft: needs pose_cache_id != 0 and M <= 16
+   *   UUO_STAGE_CHAMFER loss_data = (1 / sum mask) sum_{f,m} mask_fm (w_data min_v d2 + w_soft softmin) over all vertices
+   *                     (losses/chamfer_distance.py:5-21); soft-min kernels + the dense backward on the matrix pipe; not
+   *                     available inside lock-step batches (uuo_batch_*) */
+  float w_soft;              /* stages.<stage>.losses.soft_chamfer (0 = absent) */
   float soft_tau;            /* temperature in m^2 (> 0 when w_soft != 0) */
 } uuo_problem_t;
 
