@@ -393,3 +393,45 @@ def test_header_is_plain_c(tmp_path):
 
     for lang, std, cc in (("c", "-std=c99", "gcc"), ("c++", "-std=c++11", "g++")):
         subprocess.check_call([cc, "-x", lang, std, "-Wall", "-Werror", "-fsyntax-only", _lib.HEADER_PATH])
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The Python mirror binds the C ABI with hand-written ctypes structures: their sizes and the offsets of their last
+    members must be what a C compiler makes of include/uuo_hip.h (uuo_problem_t grew two members in round 4)."""
+    import ctypes
+    import subprocess
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd._lib import UuoLbfgsOptions, UuoLbfgsStats, UuoProblem, UuoReprojectionProblem
+
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n'
+                   '  printf("%%zu %%zu %%zu\\n", sizeof(uuo_problem_t), offsetof(uuo_problem_t, w_soft), offsetof(uuo_problem_t, soft_tau));\n'
+                   '  printf("%%zu %%zu\\n", sizeof(uuo_lbfgs_options_t), offsetof(uuo_lbfgs_options_t, verbose));\n'
+                   '  printf("%%zu %%zu\\n", sizeof(uuo_lbfgs_stats_t), offsetof(uuo_lbfgs_stats_t, device_ms));\n'
+                   '  printf("%%zu %%zu\\n", sizeof(uuo_reprojection_problem_t), offsetof(uuo_reprojection_problem_t, w_chamfer));\n'
+                   '  return 0;\n}\n' % _lib.HEADER_PATH)
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    rows = [[int(x) for x in line.split()] for line in subprocess.check_output([str(exe)]).decode().splitlines()]
+    assert rows[0] == [ctypes.sizeof(UuoProblem), UuoProblem.w_soft.offset, UuoProblem.soft_tau.offset]
+    assert rows[1] == [ctypes.sizeof(UuoLbfgsOptions), UuoLbfgsOptions.verbose.offset]
+    assert rows[2] == [ctypes.sizeof(UuoLbfgsStats), UuoLbfgsStats.device_ms.offset]
+    assert rows[3] == [ctypes.sizeof(UuoReprojectionProblem), UuoReprojectionProblem.w_chamfer.offset]
+
+
+def test_soft_assignment_options_are_validated_on_the_host(tables):
+    """EXTENSION plumbing that needs no GPU: the packaged soft configurations resolve their parents, the part stage's fused
+    soft closure is limited to 16 markers per frame by construction, and the new execution switches are known options."""
+    from uuo_mocap_amd.config import packaged_config
+    from uuo_mocap_amd.engine import PART_SOFT_MAX_MARKERS
+    from uuo_mocap_amd.markers_utils import EXECUTION_DEFAULTS, merge_execution
+
+    part = packaged_config("hmr_part_soft")["stages"]["part"]
+    assert part["losses"]["soft_chamfer"] == 10.0 and part["losses"]["chamfer"] == 0.0 and part["soft_tau"] == 2.5e-4
+    cham = packaged_config("video_mocap_soft")["stages"]["chamfer"]
+    assert cham["losses"]["soft_chamfer"] == 10.0 and cham["losses"]["full_chamfer"] == 0.0 and cham["soft_tau"] == 1e-3
+    assert cham["losses"]["reg_pose_body"] == 1.0 and cham["num_iters"] == 10000      # inherited from video_mocap.yaml
+    assert PART_SOFT_MAX_MARKERS == 16
+    assert EXECUTION_DEFAULTS["part_soft_fused"] is True and EXECUTION_DEFAULTS["chamfer_soft_fused"] is True
+    assert merge_execution({"execution": {"chamfer_soft_fused": False}})["chamfer_soft_fused"] is False

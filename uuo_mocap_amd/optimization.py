@@ -72,6 +72,9 @@ def optim_chamfer(
 
     fs = frame_shard()
     if fs is not None and fs.active:
+        if "soft_chamfer" in fused_losses:
+            raise NotImplementedError("stages.chamfer.losses.soft_chamfer (extension) is not built for frame-block sharding "
+                                      "(parallel.shard_frames); set execution.chamfer_soft_fused: False or use another mode")
         return _optim_chamfer_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans,
                                             smpl_inference, config, iter_fn)
     prob = ChamferProblem(smpl_inference, markers, o_pose_body, o_betas, root_orient, config)
