@@ -924,3 +924,59 @@ def test_soft_assignment_chamfer_stage_end_to_end(smpl, tables, dev, record_prop
         record_property("e2e_60x30_%s_v2v_m" % name, errs[name])
     print("60 x 30 full method, mean vertex error: hard %.4f m, soft chamfer stage %.4f m" % (errs["video_mocap"], errs["video_mocap_soft"]))
     assert errs["video_mocap_soft"] < max(2.0 * errs["video_mocap"], 0.02)
+
+
+def test_soft_closures_edge_cases(smpl, oracle_smpl, tables, dev):
+    """Edge cases of the fused soft closures (extension): one frame / one marker / a candidate smaller than a wave for the part
+    stage; missing markers (exact zeros are masked out, reference optimization.py:703-715) and the all-missing sequence (the
+    data term vanishes: priors only, as weighted_chamfer_distance returns 0 for a zero weight sum) for the chamfer stage; a very
+    small temperature (the soft minimum degenerates to the hard one without overflow)."""
+    import copy
+
+    from uuo_mocap_amd.engine import ChamferProblem, PartProblem
+
+    vlabels = torch.argmax(oracle_smpl.get_lbs_weights(), dim=-1)
+    # ---- part stage: (F, M, joints of the candidate)
+    for F, M, joints in ((1, 1, [22]), (3, 16, [20, 22]), (5, 2, [10])):
+        cfg = copy.deepcopy(packaged_config("hmr_part_soft"))
+        seq = make_sequence(tables, seed=40 + F, num_frames=F, num_markers=max(M, 4), limb_only=True)
+        markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float()[:, :M].contiguous()
+        o_pose, root = seq.img_smpl.pose_body.clone(), seq.img_smpl.root_orient.clone()
+        o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).clone()
+        vidx = torch.cat([(vlabels == j).nonzero(as_tuple=True)[0] for j in joints])
+        assert 0 < vidx.numel()
+        z = torch.full((1, 1, 1), -0.2, requires_grad=True)
+        t = torch.median(markers, dim=1)[0].clone().requires_grad_(True)
+        b = (o_betas + 0.1).requires_grad_(True)
+        ref, ref_grad, _ = _soft_part_reference(markers, o_pose, b, o_betas, root, t, z, vidx, oracle_smpl, 0.0, 10.0, 0.1, 2.5e-4)
+        prob = PartProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), vidx.to(dev), cfg)
+        loss, grad, _ = prob.evaluate(prob.pack(z.detach().to(dev), t.detach().to(dev), b.detach().to(dev)))
+        np.testing.assert_allclose(loss, ref, rtol=2e-5)
+        assert _rel_err(grad.cpu().numpy().astype(np.float64), ref_grad.astype(np.float64)) < 2e-4, (F, M)
+    # ---- chamfer stage: missing markers, all missing, tiny temperature
+    F, M = 6, 9
+    seq = make_sequence(tables, seed=77, num_frames=F, num_markers=M)
+    pts = np.nan_to_num(seq.markers.get_points()).astype(np.float32)
+    pts[2] = 0.0          # a frame without any marker
+    pts[:, 4] = 0.0       # a marker that is never seen
+    o_pose, root = seq.img_smpl.pose_body.clone(), seq.img_smpl.root_orient.clone()
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).clone()
+    for case, tau in (("missing", 1e-3), ("all_missing", 1e-3), ("tiny_tau", 1e-7)):
+        cfg = copy.deepcopy(packaged_config("video_mocap_soft"))
+        cfg["stages"]["chamfer"]["soft_tau"] = tau
+        markers = torch.from_numpy(pts if case != "all_missing" else np.zeros_like(pts))
+        trans = torch.from_numpy(np.median(pts, axis=1)).float()
+        prob = ChamferProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), cfg)
+        x = prob.pack(trans.to(dev), torch.full((F, 1, 1), 0.1, device=dev), (o_betas + 0.2).to(dev), (o_pose + 0.01).to(dev))
+        loss, grad, _ = prob.evaluate(x)
+        assert np.isfinite(loss) and bool(torch.isfinite(grad).all()), case
+        if case == "all_missing":
+            priors = 1.0 * float(((o_pose + 0.01 - o_pose) ** 2).mean()) + 1.0 * float((((o_betas + 0.2) - o_betas) ** 2).mean())
+            assert loss == pytest.approx(priors, rel=1e-5)
+            assert float(grad[:4 * F].abs().max()) == 0.0      # translations and yaw: no data term, no gradient
+        if case == "tiny_tau":
+            hard_cfg = copy.deepcopy(packaged_config("video_mocap"))
+            hard = ChamferProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), root.to(dev), hard_cfg)
+            lh, gh, _ = hard.evaluate(x)
+            assert loss == pytest.approx(lh, rel=1e-4)
+            assert _rel_err(grad.cpu().numpy(), gh.cpu().numpy()) < 1e-3
