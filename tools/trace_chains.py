@@ -162,3 +162,32 @@ print("  all chains: kernel %.1f %%, host %.1f %%, wait %.1f %% of %.1f chain-ms
 print("\n%-30s %8s %9s %10s %10s" % ("kernel", "calls", "avg us", "wait us", "host us"))
 for name, (c, d, w, h) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:14]:
     print("%-30s %8d %9.1f %10.1f %10.1f" % (name, c, d / c / 1e3, w / c / 1e3, h / c / 1e3))
+
+
+# ---- per kernel: how much of the window has at least one / at least two of its dispatches running (a dispatch's interval
+# includes the time its blocks wait for room on the CUs, so the SUM of durations says little about a kernel that cannot share a CU
+# with another launch of itself: k_skin2)
+def depth_times(iv):
+    ev = []
+    for s_, e_ in iv:
+        ev.append((s_, 1))
+        ev.append((e_, -1))
+    ev.sort()
+    t_prev, d, acc = None, 0, collections.defaultdict(int)
+    for t, k in ev:
+        if t_prev is not None and d > 0:
+            acc[min(d, 4)] += t - t_prev
+        d += k
+        t_prev = t
+    return acc
+
+
+by_k = collections.defaultdict(list)
+for i in keep:
+    by_k[rows[i]["Kernel_Name"].split("(")[0].replace("void ", "")[:28]].append((st[i], en[i]))
+print("\nkernel                          union %   >=2 at once %   >=3 %   sum of durations %")
+for k, iv in sorted(by_k.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:9]:
+    acc = depth_times(iv)
+    tot = sum(acc.values())
+    print("%-30s %7.1f %12.1f %10.1f %14.1f" % (k, 100.0 * tot / span, 100.0 * (tot - acc[1]) / span,
+                                              100.0 * (acc[3] + acc[4]) / span, 100.0 * sum(e - s for s, e in iv) / span))
