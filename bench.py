@@ -54,12 +54,12 @@ def part_flops_per_frame_eval(n_subset, n_markers):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=8)  # two full rounds of --inflight 4
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--markers", type=int, default=50)
     ap.add_argument("--config", default="video_mocap", help="video_mocap | hmr_full | hmr_part | mht_rotation | hmr_part_soft | video_mocap_soft")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="sequences fitted concurrently per GPU (parallel.fit_many): independent sequences overlap on one "
                          "device -- each on its own host thread, stream and workspaces -- which is how a dataset is run; "
                          "1 = one sequence at a time (latency of a single fit)")
