@@ -1246,6 +1246,8 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
     import uuo_mocap_amd.markers_utils as mod
     real = mod.DeviceLBFGS
 
+    first_grad = []
+
     class Rec(real):
         def step(self, closure):
             losses = []
@@ -1253,6 +1255,9 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
 
             def wrapped():
                 l = closure()
+                if not first_grad:   # candidate 0, first evaluation: the flat gradient in the order of the reference's params list
+                    first_grad.append(torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1)
+                                                 for p_ in self.params]).cpu().numpy().copy())
                 losses.append(float(l.detach()))
                 return l
             return super().step(wrapped)
@@ -1267,6 +1272,10 @@ def test_part_stage_optional_losses_match_reference(smpl, golden, dev):
         mod.DeviceLBFGS = real
     assert len(runs) == int(g["n_subtrees"])
     np.testing.assert_allclose([r[0] for r in runs], g["first_losses"], rtol=2e-4)
+    # the reference's own autograd gradient of candidate 0 at its starting point (all five optional terms on)
+    gerr = _rel_err(first_grad[0], g["first_grad0"])
+    print("OBS part-stage optional losses: first gradient of candidate 0 rel-L2 %.2e" % gerr)
+    assert first_grad[0].shape == g["first_grad0"].shape and gerr < 2e-4
     # trajectories: the first evaluations follow the reference's, the converged values agree (the evaluation count of
     # a solve with relu / norm terms depends on the last bits of the loss, see the oracle test)
     for k in range(2):
@@ -1371,10 +1380,14 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
     import uuo_mocap_amd.optimization as mod
     real = mod.DeviceLBFGS
 
+    first_grad = []
+
     class Rec(real):
         def step(self, closure):
             def wrapped():
                 l = closure()
+                if not first_grad:
+                    first_grad.append(torch.cat([p_.grad.reshape(-1) for p_ in self.params]).cpu().numpy().copy())
                 losses.append(float(l.detach()))
                 return l
             return super().step(wrapped)
@@ -1389,6 +1402,24 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
     finally:
         mod.DeviceLBFGS = real
     ref = g["losses"]
+    # the reference's own autograd gradient at its starting point [pose | betas | root | trans] (three-corner placement).  The
+    # backward of the Gram-Schmidt normalisation divides by |a2 - (b1.a2) b1|: a raw rotation whose first two rows are nearly
+    # parallel (the fixture holds one: frame 1, joint 19, 5e-4) amplifies the last bits of the incoming gradient by its inverse,
+    # in the reference's fp32 autograd as here -- such rotations are found on the data and compared at a looser bar
+    raw = pose.detach().cpu().numpy().reshape(F, 23, 3, 3)
+    b1 = raw[:, :, 0] / np.linalg.norm(raw[:, :, 0], axis=-1, keepdims=True)
+    u2 = np.linalg.norm(raw[:, :, 1] - (b1 * raw[:, :, 1]).sum(-1, keepdims=True) * b1, axis=-1)          # [F, 23]
+    touchy = np.argwhere(u2 < 1e-2)
+    keep = np.ones(1656, dtype=bool)
+    for f_, j_ in touchy:
+        keep[(f_ * 23 + j_) * 9:(f_ * 23 + j_ + 1) * 9] = False
+    blocks = {"pose": slice(0, 1656), "betas": slice(1656, 1666), "root": slice(1666, 1738), "trans": slice(1738, 1762)}
+    errs = {k: _rel_err(first_grad[0][v], g["first_grad"][v]) for k, v in blocks.items()}
+    err_pose_rest = _rel_err(first_grad[0][:1656][keep], g["first_grad"][:1656][keep])
+    print("OBS barycentric marker stage, first gradient vs the reference's: %s; nearly degenerate raw rotations (frame, joint - 1): %s; "
+          "pose block without them %.1e" % ({k: "%.1e" % v for k, v in errs.items()}, touchy.tolist(), err_pose_rest))
+    assert errs["betas"] < 2e-4 and errs["root"] < 2e-4 and errs["trans"] < 2e-4 and err_pose_rest < 2e-4
+    assert errs["pose"] < 5e-3 and len(touchy) <= 2
     np.testing.assert_allclose(losses[:20], ref[:20], rtol=2e-3)
     # (the end of a capped, unconverged solve: two fp32 trajectories -- observed 1.1 % apart with the gather backward of
     # round 3, 2.2 % BELOW the reference's with the matrix-pipe backward of round 4)
