@@ -980,3 +980,49 @@ def test_soft_closures_edge_cases(smpl, oracle_smpl, tables, dev):
             lh, gh, _ = hard.evaluate(x)
             assert loss == pytest.approx(lh, rel=1e-4)
             assert _rel_err(grad.cpu().numpy(), gh.cpu().numpy()) < 1e-3
+
+
+def test_dense_paths_at_a_long_sequence(smpl, tables, dev):
+    """701 frames (44 frame tiles: the skinning kernel covers at most 31 per launch, the dense backward's grids grow with the
+    tiles, the last tile holds 13 frames): `uuo_smpl_backward` dense against the gather route (debug flavour), and the fused
+    soft chamfer closure against the same closure composed from the operators."""
+    import copy
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd.engine import ChamferProblem
+    from uuo_mocap_amd.losses import soft_weighted_chamfer_distance
+    from uuo_mocap_amd.transforms import compute_root_orient_z, normalize_rot
+
+    F = 701
+    g = torch.Generator().manual_seed(F)
+    rot = p3d_ref.rotation_6d_to_matrix(torch.randn(F, 24, 6, generator=g))
+    args = [t.to(dev) for t in (rot[:, 1:].contiguous(), torch.randn(1, 10, generator=g), rot[:, :1].contiguous(),
+                                torch.randn(F, 3, generator=g), torch.randn(F, 6890, 3, generator=g), torch.randn(F, 45, 3, generator=g))]
+    dm = smpl.device_model
+    dense = dm.smpl_backward(*args)
+    product = dm.lib
+    os.environ["UUO_SMPL_BWD_GATHER"] = "1"
+    try:
+        dm.lib = _lib.load_debug()
+        gather = dm.smpl_backward(*args)
+    finally:
+        dm.lib = product
+        os.environ.pop("UUO_SMPL_BWD_GATHER", None)
+    for name, a, b in zip(("poses", "betas", "root", "trans"), dense, gather):
+        assert float((a - b).norm() / b.norm()) < 1e-5, name
+    seq = make_sequence(tables, seed=3, num_frames=F, num_markers=23)
+    markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float().to(dev)
+    o_pose, root = seq.img_smpl.pose_body.to(dev), seq.img_smpl.root_orient.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, copy.deepcopy(packaged_config("video_mocap_soft")))
+    x = prob.pack(torch.median(markers, dim=1)[0], torch.full((F, 1, 1), 0.2, device=dev), o_betas + 0.1, o_pose + 0.01)
+    loss, grad, _ = prob.evaluate(x)
+    tr, z, b, p = (t.clone().requires_grad_(True) for t in prob.unpack(x))
+    out = smpl(normalize_rot(p), b.expand(F, 10), normalize_rot(compute_root_orient_z(z) @ root), tr)
+    mask = (markers.abs().sum(-1) != 0).float()
+    ref = 10.0 * soft_weighted_chamfer_distance(markers, out["vertices"], mask, 1e-3)[0] + ((p - o_pose) ** 2).mean() + ((b - o_betas) ** 2).mean()
+    ref.backward()
+    g2 = torch.cat([q.grad.reshape(-1) for q in (tr, z, b, p)])
+    assert loss == pytest.approx(float(ref.detach()), rel=2e-5)
+    assert float((grad - g2).norm() / g2.norm()) < 2e-5
