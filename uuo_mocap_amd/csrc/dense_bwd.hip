@@ -155,7 +155,10 @@ __global__ __launch_bounds__(DPF_WAVES * 64) void k_dpf(const float4* __restrict
   for (int jt = 0; jt < 14; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // The basis streams through a ring of 7 stages (one stage = the 3 K-groups of one feature tile), refilled DPF_LEAD tiles
   // ahead and across the unit boundary; the next unit's d v_posed tiles are requested at tile 8 of the current one.
-  constexpr int DPF_RING = 7, DPF_LEAD = 4;
+#ifndef DPF_LEAD_N
+#define DPF_LEAD_N 4
+#endif
+  constexpr int DPF_RING = 7, DPF_LEAD = DPF_LEAD_N;
   const int nu = (u1 - (u0 + wave) + DPF_WAVES - 1) / DPF_WAVES;  // units of this wave (<= 0: none)
   if (nu > 0) {
     float4 ring[DPF_RING][3];
