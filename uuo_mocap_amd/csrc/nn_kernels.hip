@@ -386,6 +386,8 @@ struct PartSoftArgs {
   float c_hard, c_soft;       // 2 w / (F M)
 };
 #define PSO_U 2  // vertices per lane in flight
+#define PSO_EXP(x_) __builtin_amdgcn_exp2f(x_)  // (ablation of the round: without the exponentials the kernel is 1 % shorter, without
+                                                // pass 2's per-vertex sums 25 %: it is bound by vector issue, not by the transcendental unit)
 // the candidate's vertex c (clamped id cl) of frame f: position o, blended transform T2 (3x4 row-major, as pairs)
 __device__ __forceinline__ void pso_skin(const float* __restrict__ Cf, const float4* __restrict__ SB4, const float* sA,
                                          const float* sTr, unsigned v, unsigned cl, float* o, pf2* T2, float4& ww, unsigned& pj) {
@@ -450,9 +452,15 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
     ps[q] = 0.f;
     pi[q] = 0xFFFFFFFFu;
   }
+  // reach mask: bit `it` = the 64 * PSO_U vertices of iteration `it` may carry a non-zero weight.  A weight exp2((M - d) k) is an
+  // exact zero once (d - M) k > 150; M <= every lane's running minimum, so an iteration in which (d - running minimum) k > 160 for
+  // every lane and marker holds exact zeros only and pass 2 skips it whole (conservative, the sums are unchanged)
+  unsigned long long reach = 0ull;
+  const float cutd = 160.f / kexp;
   for (int base = 0; base < a.ns; base += 64 * PSO_U) {
     float o[PSO_U][3];
     unsigned cid[PSO_U];
+    float mdiff = 3.0e38f;
 #pragma unroll
     for (int u = 0; u < PSO_U; ++u) {
       const int c = base + tid + 64 * u;
@@ -479,7 +487,8 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
           if (q < QB) {
             const float d = h ? d2.y : d2.x;
             const float diff = d - pm[q];
-            const float e = __builtin_amdgcn_exp2f(-fabsf(diff) * kexp);
+            mdiff = fminf(mdiff, diff);  // (a new minimum makes it negative)
+            const float e = PSO_EXP(-fabsf(diff) * kexp);
             const bool lt = diff < 0.f;  // strict: ascending candidates per lane -> the first index is kept on ties
             ps[q] = lt ? fmaf(ps[q], e, 1.f) : ps[q] + e;
             pm[q] = lt ? d : pm[q];
@@ -488,6 +497,8 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
         }
       }
     }
+    const int it = base / (64 * PSO_U);
+    if (it < 64 && __any(mdiff <= cutd)) reach |= 1ull << it;
   }
   // ---- merge over the wave (fixed order): minimum and first candidate as k_part_fwd, the sums rescaled to the wave's minimum
   float uM[QB], uW[QB];
@@ -514,6 +525,10 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
   for (int k = 0; k < 10; ++k) db[k] = 0.f;
   const float c_hard = a.c_hard;
   for (int base = 0; base < a.ns; base += 64 * PSO_U) {
+    {
+      const int it = base / (64 * PSO_U);
+      if (it < 64 && !((reach >> it) & 1ull)) continue;  // wave-uniform: nothing but exact zeros in this iteration
+    }
 #pragma unroll
     for (int u = 0; u < PSO_U; ++u) {
       const int c = base + tid + 64 * u;
@@ -543,7 +558,7 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
           const int q = 2 * k + h;
           if (q < QB) {
             const float d = h ? d2.y : d2.x;
-            float p = __builtin_amdgcn_exp2f((uM[q] - d) * kexp) * uW[q];
+            float p = PSO_EXP((uM[q] - d) * kexp) * uW[q];
             p += (cidv == uI[q]) ? c_hard : 0.f;
             ax = fmaf(p, h ? dx.y : dx.x, ax);
             ay = fmaf(p, h ? dy.y : dy.x, ay);
@@ -552,6 +567,9 @@ __device__ __forceinline__ void part_soft_body(const PartSoftArgs& a, int f) {
         }
       }
       const float g0 = -ax, g1 = -ay, g2 = -az;  // d loss / d vertex (exact zeros for a lane past the end)
+      // vertices out of every marker's reach carry an exact zero (their weights underflow): when that holds for the whole wave,
+      // everything below would add zeros -- skipped (wave-uniform branch; the sums are unchanged)
+      if (!__any((ax != 0.f) | (ay != 0.f) | (az != 0.f))) continue;
       gs[0] += g0;
       gs[1] += g1;
       gs[2] += g2;
