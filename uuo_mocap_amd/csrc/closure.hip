@@ -1325,12 +1325,13 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
     // backward is the dense one: both blend contractions on the matrix pipe (dense_bwd.hip), then this kernel's kinematic
     // tail (yaw, Gram-Schmidt backward, priors, the solver's statistics) on their sums.
     UUO_REQUIRE(!uuo_recorder, "closure: the soft-assignment chamfer closure is not available inside a lock-step batch");
+    // (allocated on the first soft evaluation of this workspace, each piece on its own: a failed allocation leaves the others usable)
     if (!fit->dense) {
       rc = uuo_dense_ws_create(m, s, F, &fit->dense);
       if (rc) return rc;
-      UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_gV, (size_t)F * m->V * 3 * sizeof(float)));
-      UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
     }
+    if (!fit->soft_gV) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_gV, (size_t)F * m->V * 3 * sizeof(float)));
+    if (!fit->soft_sm) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
     rc = uuo_launch_soft_chamfer(s, F, M, m->V, p->d_markers, fit->verts, fit->mask, fit->mask_sum, fit->nn, p->w_data, p->w_soft,
                                  p->soft_tau, fit->soft_sm, fit->soft_gV, fit->dense->pre, UUO_PREG,
                                  ((m->VP / 16) <= 512 && M <= 512) ? fit->bbox : nullptr);  // (closure_forward's `cull` condition)
