@@ -1026,3 +1026,41 @@ def test_dense_paths_at_a_long_sequence(smpl, tables, dev):
     g2 = torch.cat([q.grad.reshape(-1) for q in (tr, z, b, p)])
     assert loss == pytest.approx(float(ref.detach()), rel=2e-5)
     assert float((grad - g2).norm() / g2.norm()) < 2e-5
+
+
+def test_soft_chamfer_closure_forwards_v_posed_from_the_skinning_kernel(smpl, tables, dev):
+    """The soft chamfer closure lets the forward's skinning kernel store v_posed beside the vertices (`k_skin2<.., VPOUT>`) instead of
+    running the kernel a second time with identity transforms for the dense backward.  Against that second launch (debug
+    flavour, UUO_SOFT_NO_VPOUT=1): v_posed equal to an ulp, gradients to 1e-6.  (Regression test of a pitfall met on the way:
+    `__builtin_bit_cast(unsigned, vec[e])` on an ext_vector ELEMENT read element 0 whatever `e` was.)"""
+    import copy
+    import ctypes
+    import os
+
+    from uuo_mocap_amd import _lib
+    from uuo_mocap_amd.engine import ChamferProblem, _ptr, current_stream
+
+    F, M = 30, 41
+    seq = make_sequence(tables, seed=11, num_frames=F, num_markers=M)
+    markers = torch.from_numpy(np.nan_to_num(seq.markers.get_points())).float().to(dev)
+    o_pose, root = seq.img_smpl.pose_body.to(dev), seq.img_smpl.root_orient.to(dev)
+    o_betas = (seq.img_smpl.betas.sum(0, keepdim=True) / seq.img_smpl.img_mask.sum()).to(dev)
+    prob = ChamferProblem(smpl, markers, o_pose, o_betas, root, copy.deepcopy(packaged_config("video_mocap_soft")))
+    x = prob.pack(torch.median(markers, dim=1)[0], torch.full((F, 1, 1), 0.2, device=dev), o_betas + 0.1, o_pose + 0.01)
+    dbg = _lib.load_debug()
+    dbg.uuo_debug_dense_vp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    res = {}
+    for tag, env in (("forwarded", "0"), ("own", "1")):
+        os.environ["UUO_SOFT_NO_VPOUT"] = env
+        try:
+            loss = torch.empty(1, device=dev)
+            grad = torch.empty(prob.n, device=dev)
+            assert dbg.uuo_closure_eval(prob.fit, current_stream(dev), ctypes.byref(prob.problem), _ptr(x), _ptr(loss), _ptr(grad), None) == 0
+            vp = np.empty((F, 6890, 3), dtype=np.float32)
+            assert dbg.uuo_debug_dense_vp(prob.fit, vp.ctypes.data) == 0
+        finally:
+            os.environ.pop("UUO_SOFT_NO_VPOUT", None)
+        res[tag] = (float(loss), grad.clone(), vp)
+    assert res["forwarded"][0] == res["own"][0]
+    np.testing.assert_allclose(res["forwarded"][2], res["own"][2], rtol=0, atol=2.5e-7)
+    assert float((res["forwarded"][1] - res["own"][1]).norm() / res["own"][1].norm()) < 1e-6

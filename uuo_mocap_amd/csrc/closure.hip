@@ -1016,7 +1016,9 @@ static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay,
 // forward half shared by uuo_closure_eval and uuo_time_closure
 // `need_verts`: the caller reads fit->verts afterwards (candidate scores); a closure evaluation does not (the backward
 // kernel re-skins the winners), which lets the part stage keep its vertices in registers (k_part_fwd)
-static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src, bool need_verts) {
+// `vp_out` (soft chamfer closure): the skinning kernel also leaves v_posed there, for the dense backward; *vp_done says whether it did
+static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src, bool need_verts,
+                           float* vp_out = nullptr, bool* vp_done = nullptr) {
   if (p->stage == UUO_STAGE_MARKER) return 0;  // gather-LBS: the backward kernel re-skins the M vertices itself
   const uuo_model* m = fit->model;
   int rc = 0;
@@ -1075,7 +1077,16 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
     return uuo_launch_nn(s, p->F, p->M, m->V, p->d_markers, fit->verts, p->d_subset, p->n_subset, fit->nn);
   }
   const bool cull = (p->d_subset == nullptr) && (m->VP / 16) <= 512 && p->M <= 512;
-  rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
+  {
+    // (v_posed rides along only on the k_skin2 path with unit boxes; otherwise the dense backward skins it itself)
+    const bool with_vp = cull && vp_out && !uuo_recorder;
+    rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr, with_vp ? vp_out : nullptr);
+    if (rc == -22 && with_vp) {  // (the generic skinning kernel was needed: again without the extra output)
+      rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
+    } else if (rc == 0 && vp_done) {
+      *vp_done = with_vp;
+    }
+  }
   if (rc) return rc;
   if (cull)  // exact search pruned by per-unit bounding boxes and the previous closure's assignment (kept in fit->nn)
     return uuo_launch_nn_cull(s, p->F, p->M, m->V, (m->V + 15) / 16, p->d_markers, fit->verts, fit->bbox, fit->nn, fit->nn_flags);
@@ -1242,7 +1253,21 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
   const StageLayout lay = stage_layout(p->stage, F);            // the parameters: always the reference's packing
   const StageLayout gl = stage_layout(p->stage, F, compact);    // gradient and direction: the solver's packing
   const UuoPoseSrc src = stage_pose_src(p, lay, d_x);
-  rc = closure_forward(fit, s, p, src, false);
+  const bool soft_chamfer = p->stage == UUO_STAGE_CHAMFER && p->w_soft != 0.f;
+  bool have_vp = false;
+  if (soft_chamfer) {
+    // EXTENSION (below): the workspace of the dense backward, allocated on the first soft evaluation of this fit workspace, each
+    // piece on its own (a failed allocation leaves the others usable); the forward's skinning kernel leaves v_posed in it
+    UUO_REQUIRE(!uuo_recorder, "closure: the soft-assignment chamfer closure is not available inside a lock-step batch");
+    if (!fit->dense) {
+      rc = uuo_dense_ws_create(m, s, F, &fit->dense);
+      if (rc) return rc;
+    }
+    if (!fit->soft_gV) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_gV, (size_t)F * m->V * 3 * sizeof(float)));
+    if (!fit->soft_sm) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
+  }
+  const int no_vpout = UUO_ENV_INT("UUO_SOFT_NO_VPOUT", 0);  // debug flavour only: v_posed by the dense backward's own skinning launch
+  rc = closure_forward(fit, s, p, src, false, (soft_chamfer && !no_vpout) ? fit->dense->vp : nullptr, &have_vp);
   if (rc) return rc;
   if (d_nn_idx && p->stage != UUO_STAGE_MARKER) {
     rc = uuo_launch_nn_unpack(s, F * M, fit->nn, nullptr, d_nn_idx);
@@ -1324,19 +1349,11 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
     // search (dmin, the hard assignment); the soft minimum gives EVERY vertex within reach of a marker a gradient, so the
     // backward is the dense one: both blend contractions on the matrix pipe (dense_bwd.hip), then this kernel's kinematic
     // tail (yaw, Gram-Schmidt backward, priors, the solver's statistics) on their sums.
-    UUO_REQUIRE(!uuo_recorder, "closure: the soft-assignment chamfer closure is not available inside a lock-step batch");
-    // (allocated on the first soft evaluation of this workspace, each piece on its own: a failed allocation leaves the others usable)
-    if (!fit->dense) {
-      rc = uuo_dense_ws_create(m, s, F, &fit->dense);
-      if (rc) return rc;
-    }
-    if (!fit->soft_gV) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_gV, (size_t)F * m->V * 3 * sizeof(float)));
-    if (!fit->soft_sm) UUO_HIP_CHECK(hipMalloc((void**)&fit->soft_sm, (size_t)4 * F * M * sizeof(float)));
     rc = uuo_launch_soft_chamfer(s, F, M, m->V, p->d_markers, fit->verts, fit->mask, fit->mask_sum, fit->nn, p->w_data, p->w_soft,
                                  p->soft_tau, fit->soft_sm, fit->soft_gV, fit->dense->pre, UUO_PREG,
                                  ((m->VP / 16) <= 512 && M <= 512) ? fit->bbox : nullptr);  // (closure_forward's `cull` condition)
     if (rc) return rc;
-    rc = uuo_dense_backward(m, s, F, fit->pfaT, fit->A, fit->soft_gV, fit->dense);
+    rc = uuo_dense_backward(m, s, F, fit->pfaT, fit->A, fit->soft_gV, fit->dense, have_vp);
     if (rc) return rc;
     a.pre = fit->dense->pre;
     a.dpf_part = fit->dense->part;
@@ -1449,6 +1466,14 @@ extern "C" int uuo_debug_bwd_stamps(unsigned long long* h_out) {
 extern "C" int uuo_debug_nn_flags(uuo_fit_t* fit, int* h_out) {
   UUO_REQUIRE(fit && h_out, "uuo_debug_nn_flags: null argument");
   UUO_HIP_CHECK(hipMemcpy(h_out, fit->nn_flags, (size_t)fit->F * 8 * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// debug/test hook: v_posed as the last soft chamfer evaluation left it for the dense backward ([F][V][3])
+extern "C" int uuo_debug_dense_vp(uuo_fit_t* fit, float* h_out) {
+  UUO_REQUIRE(fit && h_out && fit->dense, "uuo_debug_dense_vp: no dense workspace");
+  UUO_HIP_CHECK(hipDeviceSynchronize());
+  UUO_HIP_CHECK(hipMemcpy(h_out, fit->dense->vp, (size_t)fit->F * fit->model->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -274,12 +274,15 @@ void uuo_dense_ws_destroy(UuoDenseWs* ws) {
   delete ws;
 }
 
-int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws) {
+int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws,
+                       bool have_vp) {
   UUO_REQUIRE(m && pfaT && A && gV && ws && ws->F == F, "uuo_dense_backward: bad arguments / workspace of another size");
   UUO_REQUIRE(!uuo_recorder, "uuo_dense_backward: not available inside a lock-step batch");
   // v_posed: the forward's own contraction with identity skinning matrices and no translation
-  int rc = uuo_launch_skin(m, s, F, pfaT, ws->A_id, nullptr, ws->vp, nullptr);
-  if (rc) return rc;
+  if (!have_vp) {
+    const int rc = uuo_launch_skin(m, s, F, pfaT, ws->A_id, nullptr, ws->vp, nullptr);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_dvp, dim3((m->VP / 16) / DVP_UNITS, ws->nFT), dim3(256), 0, s, F, m->V, m->VP, A, m->Wi, m->Ww, gV, ws->dvpT);
   hipLaunchKernelGGL(k_dA, dim3(UUO_NUM_JOINTS + 1, F), dim3(DA_T), 0, s, F, m->V, m->JLoff, m->JLv, m->JLw, gV, ws->vp, ws->pre);
   hipLaunchKernelGGL(k_dpf, dim3(8 * 4 * ws->nFT), dim3(DPF_WAVES * 64), 0, s, reinterpret_cast<const float4*>(m->PB),

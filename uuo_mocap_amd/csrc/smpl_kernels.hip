@@ -408,11 +408,12 @@ struct Sk2Epi {      // registers of the epilogue that runs in the shadow of the
 // instructions: LDS addresses are per-unit bases plus immediate offsets, matrix rows are blended as register pairs
 // (v_pk_fma_f32 on adjacent registers), frames past F fall outside the buffers' ranges by construction and padding
 // vertices duplicate the last real one (model.hip), so neither needs a select.
-template <bool BBOX>
+// VPOUT: also store v_posed (the blend, before skinning) in the vertices' layout -- the dense backward needs it (dense_bwd.hip)
+template <bool BBOX, bool VPOUT = false>
 __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& E, const float4& ww, const f32x4& p0,
                                           const f32x4& p1, const f32x4& p2, const char* sTb, const char* sTrb,
                                           const unsigned v12, const unsigned n24, __amdgpu_buffer_rsrc_t rv,
-                                          __amdgpu_buffer_rsrc_t rb) {
+                                          __amdgpu_buffer_rsrc_t rb, __amdgpu_buffer_rsrc_t rvp) {
   const int e = piece / 3, part = piece - 3 * e;
   if (part < 2) {
     if (k == 0 || k == 5) {
@@ -459,6 +460,12 @@ __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& 
       u32x3 o = {__builtin_bit_cast(unsigned, E.o[0]), __builtin_bit_cast(unsigned, E.o[1]),
                  __builtin_bit_cast(unsigned, E.o[2])};
       __builtin_amdgcn_raw_buffer_store_b96(o, rv, E.vo + e * v12, 0, SK2_ST_AUX);
+      if constexpr (VPOUT) {  // v_posed of the same (frame, vertex), same offset in its own buffer
+        // (through float temporaries: __builtin_bit_cast applied to the vector ELEMENT p0[e] itself reads element 0 whatever e is)
+        const float vx = p0[e], vy = p1[e], vz = p2[e];
+        u32x3 pv = {__builtin_bit_cast(unsigned, vx), __builtin_bit_cast(unsigned, vy), __builtin_bit_cast(unsigned, vz)};
+        __builtin_amdgcn_raw_buffer_store_b96(pv, rvp, E.vo + e * v12, 0, 0);
+      }
     } else if (BBOX && k == 5) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) E.bx[c] = E.bx[3 + c] = E.o[c];
@@ -503,12 +510,13 @@ __device__ unsigned long long g_sk2_stamps[2048 * 16];  // debug flavour (UUO_SK
 __device__ unsigned long long g_sk2_stamps[16];  // product: only the VAR = 0 instantiations exist, nothing ever indexes this
 #endif
 
-template <bool BBOX, int VAR>
+template <bool BBOX, int VAR, bool VPOUT = false>
 __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_skin2(const float4* __restrict__ P3v, const float* __restrict__ vt3,
                                                             const int* __restrict__ Wi, const float* __restrict__ Ww,
                                                             const float* __restrict__ pfaT, const float* __restrict__ A,
                                                             const float* __restrict__ trans, float* __restrict__ verts,
-                                                            float* __restrict__ bbox, int F, int V, int VP, int nFT) {
+                                                            float* __restrict__ bbox, int F, int V, int VP, int nFT,
+                                                            float* __restrict__ vp_out) {
   __shared__ float4 sA[2 * UUO_KP * UUO_FT / 4];               // [slot][14][64]
   __shared__ f32x4 sT[2 * UUO_FT * UUO_NUM_JOINTS * 3];        // [slot][i][j][3]
   __shared__ float4 sTr[2 * UUO_FT];                            // [slot][i] translation
@@ -546,6 +554,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(verts, 0, F * V * 12, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(bbox, 0, BBOX ? F * nur * 24 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvp = VPOUT ? __builtin_amdgcn_make_buffer_rsrc(vp_out, 0, F * V * 12, 0x00020000) : rv;
   // the blend basis, template and skin weights are addressed through buffer resources: one address VGPR each,
   // everything else scalar
   const unsigned cplane = (unsigned)nunits * SKIN_GROUPS * 1024u;  // bytes per coordinate plane
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu
         } else {
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rbuf[2][st][ks], acc2, 0, 0, 0);
         }
-        if (!(VAR & 1) && g < 12) sk2_slice<BBOX>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb);
+        if (!(VAR & 1) && g < 12) sk2_slice<BBOX, VPOUT>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rvp);
         if (k == k_aread && g + 1 < SKIN_GROUPS) ra[(g + 1) & 1] = pa[(g + 1) * 64];
         if (g == 2 && k == 11) {  // the claim has landed: decode the next task (or keep re-reading this one)
           const int t_n = __builtin_amdgcn_readfirstlane(claimed);
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
   for (int g = 0; g < 12; ++g) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) sk2_slice<BBOX>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb);
+    for (int k = 0; k < 12; ++k) sk2_slice<BBOX, VPOUT>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rvp);
   }
   if ((VAR & 8) && lane == 0) {
     unsigned long long* o = g_sk2_stamps + (size_t)(blockIdx.x * SKIN_WAVES + wave) * 16;
@@ -771,7 +780,8 @@ struct SkinCallArgs {  // UUO_OP_SKIN: a whole-GPU kernel; a lock-step batch rep
 };
 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
-                    float* verts, float* bbox) {
+                    float* verts, float* bbox, float* vp_out) {
+  UUO_REQUIRE(!vp_out || (bbox && !uuo_recorder), "uuo_launch_skin: v_posed output goes with the unit boxes, outside lock-step batches");
   {
     SkinCallArgs c{{1, 1}, m, F, pfaT, A, trans, verts, bbox};
     if (uuo_record(UUO_OP_SKIN, 1, 1, c)) return 0;
@@ -779,13 +789,19 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
   static const int force_v1 = UUO_ENV_INT("UUO_SKIN_V1", 0);  // ablation / comparison only
   const int nur = (m->V + 15) / 16;  // units with vertices = stride of the box table
   const int npos = 1 << SK2_NPOS_LOG2;  // 8 XCDs x 32 CUs, one 8-wave block per CU
-  if (force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+  if (force_v1 || (size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) {
+    UUO_REQUIRE(!vp_out, "uuo_launch_skin: v_posed output needs the k_skin2 path");
+    return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+  }
   const int nFT_all = (F + UUO_FT - 1) / UUO_FT;
   for (int ft0 = 0; ft0 < nFT_all; ft0 += SK2_MAX_FT) {
     const int nFT = (nFT_all - ft0 < SK2_MAX_FT) ? nFT_all - ft0 : SK2_MAX_FT;
     const int f0 = ft0 * UUO_FT;
     const int Fl = (F - f0 < nFT * UUO_FT) ? F - f0 : nFT * UUO_FT;
-    if (!sk2_fits(nFT, nur, npos)) return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+    if (!sk2_fits(nFT, nur, npos)) {
+      UUO_REQUIRE(!vp_out, "uuo_launch_skin: v_posed output needs the k_skin2 path");
+      return uuo_launch_skin_v1(m, s, F, pfaT, A, trans, verts, bbox);
+    }
     const float* pf = pfaT + (size_t)ft0 * UUO_KP * UUO_FT;
     const float* pA = A + (size_t)f0 * UUO_NUM_JOINTS * 12;
     const float* pt = trans ? trans + (size_t)f0 * 3 : nullptr;
@@ -794,8 +810,12 @@ int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT,
 #define SK2_LAUNCH(BB, VAR)                                                                             \
   hipLaunchKernelGGL((k_skin2<BB, VAR>), dim3(8 * npos), dim3(SKIN_WAVES * 64), 0, s,                   \
                      reinterpret_cast<const float4*>(m->P3), m->vt3, m->Wi, m->Ww, pf, pA, pt, pv,      \
-                     (BB) ? bbox + (size_t)f0 * nur * 6 : (float*)nullptr, Fl, m->V, m->VP, nFT)
+                     (BB) ? bbox + (size_t)f0 * nur * 6 : (float*)nullptr, Fl, m->V, m->VP, nFT, (float*)nullptr)
     if (!bbox) SK2_LAUNCH(false, 0);
+    else if (vp_out)
+      hipLaunchKernelGGL((k_skin2<true, 0, true>), dim3(8 * npos), dim3(SKIN_WAVES * 64), 0, s,
+                         reinterpret_cast<const float4*>(m->P3), m->vt3, m->Wi, m->Ww, pf, pA, pt, pv,
+                         bbox + (size_t)f0 * nur * 6, Fl, m->V, m->VP, nFT, vp_out + (size_t)f0 * m->V * 3);
 #ifdef UUO_DEBUG_HOOKS  // timing ablations (MFMAs off, epilogue off, refills off, cycle stamps): never in the product binary
     else if (var2 == 1) SK2_LAUNCH(true, 1);
     else if (var2 == 2) SK2_LAUNCH(true, 2);

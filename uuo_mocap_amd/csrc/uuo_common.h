@@ -201,7 +201,9 @@ int uuo_dense_ws_create(const uuo_model* m, hipStream_t s, int F, UuoDenseWs** o
 void uuo_dense_ws_destroy(UuoDenseWs* ws);
 // pfaT / A: this evaluation's operand tiles and skinning matrices (k_pose_prep); gV [F][V][3].  Fills ws->pre (but entry 0)
 // and ws->part; the caller then runs k_bwd_sparse with BwdArgs.pre = ws->pre, dpf_part = ws->part.
-int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws);
+// have_vp: ws->vp already holds v_posed of this evaluation (written by the forward's k_skin2 with vp_out)
+int uuo_dense_backward(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* gV, UuoDenseWs* ws,
+                       bool have_vp = false);
 // the chamfer stage's data term with a soft assignment (nn_kernels.hip); sm: 4 F M floats of scratch
 int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* markers, const float* verts, const float* mask,
                             float mask_sum, const unsigned long long* keys, float w_hard, float w_soft, float tau, float* sm,
@@ -217,8 +219,9 @@ int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const 
 int uuo_launch_part_soft(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
                          const float* trans, const int32_t* subset, int n_subset, const float* markers,
                          unsigned long long* packed, float* pre, float w_hard, float w_soft, float tau);
+// vp_out (optional, with bbox): v_posed [F][V][3] as well (the dense backward's input: saves its own skinning launch)
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
-                    const float* trans, float* verts, float* bbox);
+                    const float* trans, float* verts, float* bbox, float* vp_out = nullptr);
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
                            const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts,
                            float* bbox_compact = nullptr);
