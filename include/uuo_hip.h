@@ -36,6 +36,7 @@ typedef struct uuo_model uuo_model_t; /* device copies of the SMPL tables */
 typedef struct uuo_fit uuo_fit_t;     /* per-sequence workspace (F frames, M markers) */
 
 const char* uuo_last_error(void);
+/* 2 since uuo_problem_t grew `w_soft` / `soft_tau` (round 4); a binding checks it before it hands structures over */
 int uuo_abi_version(void);
 
 /* ---- model ------------------------------------------------------------------------------------
