@@ -14,6 +14,10 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "uuo_hip.h")
 UUO_STAGE_CHAMFER, UUO_STAGE_MARKER, UUO_STAGE_PART = 0, 1, 2
 
 
+#: uuo_abi_version() of the library these bindings are written for
+ABI_VERSION = 2
+
+
 class UuoProblem(ctypes.Structure):
     _fields_ = [
         ("stage", c_int32), ("F", c_int32), ("M", c_int32),
@@ -156,6 +160,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.uuo_abi_version() != ABI_VERSION:  # the ctypes structures below mirror include/uuo_hip.h of THIS version
+        raise RuntimeError("libuuo_hip.so has ABI version %d, this package binds version %d: rebuild it "
+                           "(python __graft_entry__.py)" % (lib.uuo_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
