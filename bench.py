@@ -347,7 +347,7 @@ def main():
     from uuo_mocap_amd.body_model import synthetic_smpl
     from uuo_mocap_amd.config import packaged_config
     from uuo_mocap_amd.engine import ChamferProblem
-    from uuo_mocap_amd.parallel import host_cpu_budget, limit_host_threads
+    from uuo_mocap_amd.parallel import auto_wait_sleep_us, host_cpu_budget, limit_host_threads
     from uuo_mocap_amd.smpl import SmplInference
     from uuo_mocap_amd.synthetic import make_sequence
 
@@ -483,8 +483,8 @@ def main():
             # host side of the timed region (this process' cgroup): CPU seconds burnt by the polling / orchestrating threads
             # and whether the CPU quota throttled them (parallel.limit_host_threads explains why that matters)
             "host": {"cpu_quota": host_cpu_budget(), "torch_threads": host_threads,
-                     "wait_policy": ("sleep 20 us after 10 us of spinning while sequences are in flight (parallel.fit_many)"
-                                     if fit_wait == "auto" and args.inflight > 1 else
+                     "wait_policy": ("sleep %g us after 10 us of spinning while sequences are in flight (parallel.fit_many)"
+                                     % auto_wait_sleep_us() if fit_wait == "auto" and args.inflight > 1 else
                                      "spin" if args.wait_sleep_us <= 0 else "sleep %g us" % args.wait_sleep_us),
                      "cpu_seconds_timed": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 if cg0 else None,
                      "nr_throttled_timed": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 else None,

@@ -175,6 +175,15 @@ def fit_sharded(sequence_ids: Sequence[int], fit_fn: Callable[[int], Dict], devi
     return merged, elapsed
 
 
+def auto_wait_sleep_us() -> float:
+    """How long the sleeping waits of `fit_many(wait_policy="auto")` sleep at a time: 20 us where the rank has four or more CPUs of
+    its own (16 waiting threads then cost ~2 CPUs), 50 / 100 us on tighter budgets -- eight ranks inside ONE 16-CPU quota have two
+    CPUs each, and a throttled cgroup stalls every thread of every rank for the rest of its 100-ms period."""
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    per_rank = host_cpu_budget() / local_world
+    return 20.0 if per_rank >= 4 else (50.0 if per_rank >= 3 else 100.0)
+
+
 def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None, wait_policy: str = "auto") -> List:
     """Fits independent sequences `fit_fn(item)` on ONE GPU with up to `inflight` of them in progress at a time
     (each on its own host thread, HIP stream and workspace group).  Sequences are independent in the reference
@@ -199,7 +208,7 @@ def fit_many(items: Sequence, fit_fn: Callable, inflight: int = 1, device=None, 
         global _wait_auto_users
         with _wait_lock:
             if _wait_auto_users == 0:
-                _apply_wait_policy(10.0, 20.0)
+                _apply_wait_policy(10.0, auto_wait_sleep_us())
             _wait_auto_users += 1
         try:
             return fit_many(items, fit_fn, inflight, device, wait_policy="keep")
