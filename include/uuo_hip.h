@@ -36,7 +36,8 @@ typedef struct uuo_model uuo_model_t; /* device copies of the SMPL tables */
 typedef struct uuo_fit uuo_fit_t;     /* per-sequence workspace (F frames, M markers) */
 
 const char* uuo_last_error(void);
-/* 2 since uuo_problem_t grew `w_soft` / `soft_tau` (round 4); a binding checks it before it hands structures over */
+/* 3 since uuo_problem_t grew `w_soft` / `soft_tau` (2) and `n_corners` / `d_bary` (3), round 4; a binding checks it before it
+ * hands structures over */
 int uuo_abi_version(void);
 
 /* ---- model ------------------------------------------------------------------------------------
@@ -155,6 +156,13 @@ typedef struct {
    *                     available inside lock-step batches (uuo_batch_*) */
   float w_soft;              /* stages.<stage>.losses.soft_chamfer (0 = absent) */
   float soft_tau;            /* temperature in m^2 (> 0 when w_soft != 0) */
+  /* Marker stage on a three-corner (barycentric) placement -- compute_locations.use_barycentric of the reference
+   * (optimization.py:494-523; the closure's virtual markers are `placement @ vertices`, :345-351, every row of the placement
+   * holding the barycentric coordinates of a surface point at its face's three corners).  n_corners = 3: d_assign is
+   * [M][3] vertex ids, d_bary [M][3] their weights, virtual marker m = sum_k d_bary[m][k] v[d_assign[m][k]].
+   * n_corners = 0 or 1: the one-hot placement of the shipped configs, d_assign [M], d_bary unused. */
+  int32_t n_corners;
+  const float* d_bary;
 } uuo_problem_t;
 
 int uuo_fit_create(uuo_model_t* model, int F, int M, uuo_fit_t** out);

@@ -15,7 +15,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert len(names) >= 14
     for name in names:
         assert hasattr(lib, name), name
-    assert lib.uuo_abi_version() == 2
+    assert lib.uuo_abi_version() == 3
     assert set(_lib._SIGNATURES) == set(names), "ctypes signature table and include/uuo_hip.h disagree"
 
 

@@ -157,6 +157,61 @@ def test_marker_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, s
 
 
 @pytest.mark.parametrize("F,M,seed", SIZES)
+def test_three_corner_marker_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, F, M, seed):
+    """The fused marker closure on a three-corner (barycentric) placement, k_bary_fwd + k_bwd_items (n_corners = 3), against the
+    oracle's closure on the dense placement matrix (reference optimization.py:345-351: virtual markers = coords @ vertices):
+    random surface points on the model's own triangles, rows with one and two non-zeros among them, a hidden marker, and
+    bit-reproducibility of the evaluation."""
+    from uuo_mocap_amd.engine import MarkerProblem
+    from uuo_mocap_amd.optimization import placement_corners
+
+    cfg = packaged_config("video_mocap")
+    seq, markers, o_pose, o_betas, root, trans = _inputs(tables, F, M, seed)
+    t, _, b, p, r = _perturbed(F, o_pose, o_betas, root, trans, 3)
+    gen = torch.Generator().manual_seed(seed + 17)
+    faces = torch.from_numpy(np.asarray(tables.faces).astype(np.int64))
+    vids = torch.from_numpy(np.asarray(seq.gt["marker_vids"])).long()
+    coords = torch.zeros(M, 6890)
+    for m in range(M):  # a triangle that holds the marker's true vertex, a random point on it
+        hit = (faces == vids[m]).any(1).nonzero()
+        tri = faces[hit[0, 0]] if len(hit) else torch.tensor([int(vids[m]), (int(vids[m]) + 1) % 6890, (int(vids[m]) + 2) % 6890])
+        w = torch.rand(3, generator=gen) + 0.05
+        if m % 7 == 1:
+            w[1] = 0.0  # on an edge: two non-zeros
+        if m % 7 == 2:
+            w = (tri == vids[m]).float()  # on a corner: one non-zero
+        coords[m, tri] = w / w.sum()
+    markers = markers.clone()
+    markers[F // 2, 1] = 0.0  # a marker hidden on one frame (get_marker_mask)
+    leaves = [x.clone().requires_grad_(True) for x in (p, b, r, t)]
+    lo, _ = stages_ref.marker_stage_loss(markers, leaves[0], o_pose, leaves[1], o_betas, leaves[2], leaves[3], coords, oracle_smpl, cfg)
+    lo.backward()
+    ref_grad = torch.cat([x.grad.reshape(-1) for x in leaves]).numpy()
+    i3, b3 = placement_corners(coords.to(dev))
+    assert i3.shape == (M, 3) and bool((i3[:, 1:] > i3[:, :-1]).all())
+    prob = MarkerProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), i3, cfg, bary=b3)
+    x = prob.pack(p.to(dev), b.to(dev), r.to(dev), t.to(dev))
+    loss, grad, _ = prob.evaluate(x)
+    np.testing.assert_allclose(loss, lo.item(), rtol=2e-5)
+    g = grad.cpu().numpy()
+    blocks = {"pose": slice(0, 207 * F), "betas": slice(207 * F, 207 * F + 10), "root": slice(207 * F + 10, 216 * F + 10),
+              "trans": slice(216 * F + 10, 219 * F + 10)}
+    for k, sl in blocks.items():
+        assert _rel_err(g[sl], ref_grad[sl]) < 2e-4, k
+    loss2, grad2, _ = prob.evaluate(x)
+    assert loss2 == loss and torch.equal(grad2, grad)
+    # a one-hot placement given as three corners (weights 1, 0, 0) is the one-hot closure of the shipped configs
+    one = torch.zeros(M, 6890)
+    one[torch.arange(M), vids] = 1.0
+    i1, b1 = placement_corners(one.to(dev))
+    pa = MarkerProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), i1, cfg, bary=b1)
+    pb = MarkerProblem(smpl, markers.to(dev), o_pose.to(dev), o_betas.to(dev), vids.to(dev), cfg)
+    la, ga, _ = pa.evaluate(x)
+    lb, gb, _ = pb.evaluate(x)
+    assert la == pytest.approx(lb, rel=2e-6) and _rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("F,M,seed", SIZES)
 @pytest.mark.parametrize("subtree", ["full", "leg"])
 def test_part_closure_at_baseline_size(smpl, oracle_smpl, tables, dev, record_property, F, M, seed, subtree):
     from uuo_mocap_amd.engine import PartProblem

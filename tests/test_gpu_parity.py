@@ -37,7 +37,7 @@ def test_native_library_loaded():
     from uuo_mocap_amd import _lib
 
     lib = _lib.load()
-    assert lib.uuo_abi_version() == 2
+    assert lib.uuo_abi_version() == 3
     assert any("libuuo_hip.so" in line for line in open("/proc/self/maps"))
 
 
@@ -1375,7 +1375,38 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
                                smpl_inference=smpl, marker_labels=g["labels"], granularity="full",
                                img_mask=torch.ones(F, device=dev), device=dev, config=cfg3)
 
-    # marker stage on the reference's own matrix
+    # marker stage on the reference's own matrix.  (a) The FUSED three-corner closure (k_bary_fwd + k_bwd_items) at the reference's
+    # starting point: its loss and the reference's own autograd gradient (the degenerate raw rotation of the fixture aside, below)
+    from uuo_mocap_amd.engine import MarkerProblem
+    from uuo_mocap_amd.optimization import last_stats, placement_corners
+
+    i3, b3 = placement_corners(dense("full"))
+    assert int((b3 != 0).sum(1).max()) == 3 and torch.allclose(b3.sum(1), torch.ones(M, device=dev), atol=1e-5)
+    fprob = MarkerProblem(smpl, markers, t("o_pose_body"), t("o_betas"), i3, cfg, bary=b3)
+    floss, fgrad, _ = fprob.evaluate(fprob.pack(pose, betas, root, trans))
+    fgrad = fgrad.cpu().numpy()
+    assert floss == pytest.approx(float(g["losses"][0]), rel=1e-5)
+    raw_f = pose.detach().cpu().numpy().reshape(F, 23, 3, 3)
+    b1_f = raw_f[:, :, 0] / np.linalg.norm(raw_f[:, :, 0], axis=-1, keepdims=True)
+    u2_f = np.linalg.norm(raw_f[:, :, 1] - (b1_f * raw_f[:, :, 1]).sum(-1, keepdims=True) * b1_f, axis=-1)
+    keep_f = np.ones(1656, dtype=bool)
+    for f_, j_ in np.argwhere(u2_f < 1e-2):
+        keep_f[(f_ * 23 + j_) * 9:(f_ * 23 + j_ + 1) * 9] = False
+    ferr = {"pose": _rel_err(fgrad[:1656][keep_f], g["first_grad"][:1656][keep_f]), "betas": _rel_err(fgrad[1656:1666], g["first_grad"][1656:1666]),
+            "root": _rel_err(fgrad[1666:1738], g["first_grad"][1666:1738]), "trans": _rel_err(fgrad[1738:], g["first_grad"][1738:])}
+    print("OBS barycentric marker stage, FUSED closure: first loss %.8f (ref %.8f), first gradient vs the reference's %s"
+          % (floss, float(g["losses"][0]), {k: "%.1e" % v for k, v in ferr.items()}))
+    assert max(ferr.values()) < 2e-4
+    # (b) the stage through optim_markers takes the fused route by default and descends like the reference's run
+    fl = [x.clone().requires_grad_(True) for x in (pose, betas, root, trans)]
+    optim_markers(markers=markers, pose_body=fl[0], o_pose_body=t("o_pose_body"), betas=fl[1], o_betas=t("o_betas"),
+                  root_orient=fl[2], trans=fl[3], barycentric_coords_one_hot=dense("full"), img_mask=torch.ones(F, device=dev),
+                  smpl_inference=smpl, config=cfg)
+    fst = last_stats("marker")
+    assert "host closure" not in str(fst.get("driver", "")) and fst["first_loss"] == pytest.approx(float(g["losses"][0]), rel=1e-5)
+    assert fst["final_loss"] == pytest.approx(float(g["losses"][-1]), rel=4e-2)
+    # (c) its checker, the closure composed from the operators (execution.marker_bary_fused: False)
+    cfg["execution"] = {"marker_bary_fused": False}
     losses = []
     import uuo_mocap_amd.optimization as mod
     real = mod.DeviceLBFGS
@@ -1432,8 +1463,9 @@ def test_barycentric_placement_matches_reference(smpl, golden, dev):
 @pytest.mark.gpu
 def test_orchestrator_with_barycentric_placement(smpl, dev):
     """The whole fit with compute_locations.use_barycentric (off in every shipped config): every yaw hypothesis
-    places the markers on the surface and runs the general marker stage; the result must be finite and reproducible
-    and every marker solve must reduce its loss."""
+    places the markers on the surface and runs the marker stage on the three-corner placement -- the fused closure (k_bary_fwd +
+    k_bwd_items) under the device solver by default, the operator-composed closure with execution.marker_bary_fused False; the
+    result must be finite and reproducible, every marker solve must reduce its loss and the two routes start from the same loss."""
     from uuo_mocap_amd.multimodal import last_run_stats, multimodal_video_mocap
 
     cfg = packaged_config("video_mocap")
@@ -1448,10 +1480,20 @@ def test_orchestrator_with_barycentric_placement(smpl, dev):
         outs.append(multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0,
                                            print_options=[], save_stages=False, smpl_inference=smpl))
         st = last_run_stats()
-        assert len(st["marker"]) == 2 and all(s["driver"] == "device-lbfgs(host closure)" and s["n_eval"] >= 2 for s in st["marker"])
+        assert len(st["marker"]) == 2 and all("driver" not in s and s["n_eval"] >= 2 for s in st["marker"])  # the fused solver's record
+        assert all(s["final_loss"] < s["first_loss"] for s in st["marker"])
+    fused_first = [s["first_loss"] for s in st["marker"]]
     for k in ("trans", "pose_body", "root_orient", "betas"):
         assert torch.isfinite(outs[0][k]).all()
         np.testing.assert_array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy())
+    # the same fit on the operator-composed marker closure (the stages before it are the same launches: same starting loss)
+    cfg["execution"] = dict(cfg.get("execution") or {}, marker_bary_fused=False)
+    ops = multimodal_video_mocap(seq.img_smpl, copy.deepcopy(seq.markers), dev, cfg, offset=0, print_options=[], save_stages=False,
+                                 smpl_inference=smpl)
+    st = last_run_stats()
+    assert len(st["marker"]) == 2 and all(s["driver"] == "device-lbfgs(host closure)" and s["n_eval"] >= 2 for s in st["marker"])
+    assert [s["loss_first"] for s in st["marker"]] == pytest.approx(fused_first, rel=1e-5)
+    assert all(torch.isfinite(ops[k]).all() for k in ("trans", "pose_body", "root_orient", "betas"))
     # (no bound on the marker-to-surface distance: the synthetic model's face list is padded with fan triangles that
     # span the body, and a surface point placed on one of them on the last frame does not track the marker on the
     # others -- a property of the stand-in mesh, see scratch notes in DESIGN.md; the stage itself must make progress)

@@ -15,7 +15,7 @@ UUO_STAGE_CHAMFER, UUO_STAGE_MARKER, UUO_STAGE_PART = 0, 1, 2
 
 
 #: uuo_abi_version() of the library these bindings are written for
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class UuoProblem(ctypes.Structure):
@@ -25,7 +25,8 @@ class UuoProblem(ctypes.Structure):
         ("d_assign", c_void_p), ("d_subset", c_void_p), ("n_subset", c_int32),
         ("w_data", c_float), ("w_pose", c_float), ("w_betas", c_float), ("marker_distance", c_float),
         ("pose_cache_id", ctypes.c_uint64),
-        ("w_soft", c_float), ("soft_tau", c_float),   # EXTENSION: soft-assignment data term of the part stage
+        ("w_soft", c_float), ("soft_tau", c_float),   # EXTENSION: soft-assignment data term (part / chamfer stage)
+        ("n_corners", c_int32), ("d_bary", c_void_p),  # marker stage on a three-corner (barycentric) placement
     ]
 
 

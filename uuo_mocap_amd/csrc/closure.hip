@@ -69,6 +69,10 @@ struct BwdArgs {
                                  // runs on them (null: the sparse gather).  Part stage (k_bwd_part): [F][UUO_PRE] left by k_part_soft
                                  // (soft assignment, extension).  General kernel: [F][UUO_PREG] left by uuo_dense_backward (dense_bwd.hip),
   uuo_gptr<const float> dpf_part;  // with the partials [UUO_DPF_NCB][F][UUO_KP] of d [pose-feature | beta] of its matrix-pipe contraction
+  // item mode (k_bwd_items: the marker stage on a three-corner placement): item mm of a frame is vertex assign[mm] with the
+  // upstream gradient up_items[f][mm] (M = 3 x markers; k_bary_fwd formed them), the frame's data-loss sum comes with them
+  uuo_gptr<const float> up_items;   // [F][M][3]
+  uuo_gptr<const float> item_loss;  // [F]
   // upstream-gradient mode (stage UUO_STAGE_UPSTREAM, SmplInference.forward's backward): the items are ALL vertices
   // (+ the 21 vertex-picked joints) with dL/dv given, instead of markers with a residual
   uuo_gptr<const float> up_verts;   // [F][V][3] or null
@@ -276,9 +280,12 @@ __device__ unsigned long long g_bwd_stamps[4096 * BWD_NSTAMP];
 #endif
 // DENSE (general kernel only): the sums of a dense backward come from dense_bwd.hip (BwdArgs.pre / dpf_part); a separate
 // instantiation, so that the sparse kernel of the fitted stages keeps its register allocation (168 VGPRs, no spill)
-template <bool PART = false, int NWV = BWD_NW, bool DENSE = false>
+// ITEMS (general kernel only): the items are (vertex, upstream gradient) pairs handed over by another kernel; another separate
+// instantiation, for the same reason
+template <bool PART = false, int NWV = BWD_NW, bool DENSE = false, bool ITEMS = false>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   static_assert(!(PART && DENSE), "the part stage's dense sums come through the runtime `pre` pointer");
+  static_assert(!ITEMS || (!PART && !DENSE), "item mode belongs to the general sparse kernel");
   static_assert(NWV == BWD_NW || (PART && NWV == 1), "one-wave blocks exist for the part stage only");
   constexpr int NT = NWV * 64, SLOTS = NWV * 4;  // threads per block, (wave, 16-lane group) item slots
   // latency-bound kernel of a solve chain: do not queue behind co-resident MFMA waves.  (Not the one-wave part-stage form:
@@ -408,7 +415,11 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       float d2 = 0.f;
       int vi;
       float up0 = 0.f, up1 = 0.f, up2 = 0.f;
-      if (a.stage == UUO_STAGE_UPSTREAM) {
+      if constexpr (ITEMS) {
+        vi = a.assign[mm];
+        const float* pu = a.up_items + ((size_t)f * M + mm) * 3;
+        up0 = pu[0]; up1 = pu[1]; up2 = pu[2];
+      } else if (a.stage == UUO_STAGE_UPSTREAM) {
         if (mm < a.V) {
           vi = mm;
           if (a.up_verts) {
@@ -435,7 +446,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       if ((unsigned)vi >= (unsigned)a.V) vi = 0;  // never happens for a completed search; keeps the gather in bounds
       q.wgt = wgt;
       q.d2 = d2;
-      if (a.stage == UUO_STAGE_UPSTREAM) {
+      if (ITEMS || a.stage == UUO_STAGE_UPSTREAM) {
         q.x0 = up0; q.x1 = up1; q.x2 = up2;
       } else {
         const float* px = a.markers + ((size_t)f * M + mm) * 3;
@@ -512,7 +523,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
       const float dx = cur.x0 - vx, dy = cur.x1 - vy, dz = cur.x2 - vz;
       float g[3];
       float loss_item;
-      if (a.stage == UUO_STAGE_UPSTREAM) {
+      if (ITEMS || a.stage == UUO_STAGE_UPSTREAM) {
         loss_item = 0.f;
         g[0] = wgt * cur.x0; g[1] = wgt * cur.x1; g[2] = wgt * cur.x2;
       } else if (a.stage == UUO_STAGE_MARKER) {
@@ -833,7 +844,8 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a) {
   if (tid == 0) {
     float ps = 0.f;
     for (int jj = 1; jj < UUO_NUM_JOINTS; ++jj) ps += spsq[jj];
-    BWD_FP_STORE(0, red[0]);
+    if constexpr (ITEMS) BWD_FP_STORE(0, red[0] + a.item_loss[f]);  // (the items carry gradients; their frame's loss sum comes beside them)
+    else BWD_FP_STORE(0, red[0]);
     BWD_FP_STORE(2, ps);
     if (a.stage != UUO_STAGE_PART) BWD_FP_STORE(1, 0.f);
   }
@@ -874,6 +886,142 @@ __global__ __launch_bounds__(BWD_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 
 }
 // the kinematic tail alone, on the sums of a dense backward (dense_bwd.hip)
 __global__ __launch_bounds__(BWD_NW * 64) void k_bwd_dense(BwdArgs a) { bwd_body<false, BWD_NW, true>(a); }
+// the sparse kernel on (vertex, upstream gradient) items (the marker stage on a three-corner placement, k_bary_fwd before it)
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_items(BwdArgs a) { bwd_body<false, BWD_NW, false, true>(a); }
+
+// ----------------------------------------------------------------------------------------------------
+// Marker stage on a three-corner (barycentric) placement (reference optimization.py:345-351 with the placement of
+// compute_nearest_points' use_barycentric branch, :494-523): virtual marker vm = sum_k b_k v[i_k], loss term
+// w (|x - vm| - d0)^2.  The residual needs all three corners, so a forward pass re-skins the 3 M corner vertices of a frame
+// (gather-LBS: the arithmetic of the backward kernel's item loop, four corners at a time per wave), forms vm, the term
+// and d loss / d vm, and hands b_k d loss / d vm to the sparse backward as per-corner items (k_bwd_items).
+// Block = frame (4 waves); 16-lane group = one marker at a time, its corners one after the other.
+// ----------------------------------------------------------------------------------------------------
+struct BaryFwdArgs {
+  uuo_gptr<const float> PT, ST, vt, Ww;
+  uuo_gptr<const int> Wi;
+  uuo_gptr<const UuoTree> tree;
+  int V, F, M;  // M = markers
+  UuoPoseSrc src;
+  uuo_gptr<const float> markers, mask;
+  uuo_gptr<const int> assign3;   // [M][3]
+  uuo_gptr<const float> bary;    // [M][3]
+  float cg, d0;
+  uuo_gptr<float> frames;        // [F][FrameLds]: left for k_bwd_items of the same evaluation
+  uuo_gptr<float> up_items;      // [F][3 M][3]
+  uuo_gptr<float> item_loss;     // [F]
+};
+__global__ __launch_bounds__(BWD_NW * 64) void k_bary_fwd(BaryFwdArgs a) {
+  constexpr int NT = BWD_NW * 64, SLOTS = BWD_NW * 4;
+  __shared__ FrameLds L;
+  __shared__ float sA[UUO_NUM_JOINTS * 12];
+  __shared__ float spf[UUO_KB];
+  __shared__ float sloss[SLOTS];
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int M = a.M;
+  frame_forward(a.src, a.tree, f, L);  // (ends with a barrier)
+  if (tid < UUO_NUM_JOINTS) frame_skin_matrix(L, tid, sA + tid * 12);
+  if (tid < UUO_KB) {
+    float v = 0.f;
+    if (tid < UUO_NUM_POSE_FEATS) {
+      const int j = 1 + tid / 9, e = tid % 9;
+      v = L.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+    spf[tid] = v;
+  }
+  __syncthreads();
+  {  // the frame's state for the backward kernel of this evaluation
+    constexpr int NW = sizeof(FrameLds) / 4;
+    const float* src_l = reinterpret_cast<const float*>(&L);
+    for (int i = tid; i < NW; i += NT) a.frames[(size_t)f * NW + i] = src_l[i];
+  }
+  float tr[3] = {0.f, 0.f, 0.f};
+  if (a.src.trans) {
+    tr[0] = a.src.trans[(size_t)f * 3];
+    tr[1] = a.src.trans[(size_t)f * 3 + 1];
+    tr[2] = a.src.trans[(size_t)f * 3 + 2];
+  }
+  const int gq = lane >> 4, sl = lane & 15;
+  const int slot = wave * 4 + gq;
+  float fk[13];
+#pragma unroll
+  for (int t = 0; t < 13; ++t) fk[t] = spf[sl + 16 * t];
+  const float beta_s = (sl < 10) ? L.beta[sl] : 0.f;
+  auto row_sum = [](float v) {
+    v += dpp_rot<0x128>(v);
+    v += dpp_rot<0x124>(v);
+    v += dpp_rot<0x122>(v);
+    v += dpp_rot<0x121>(v);
+    return v;
+  };
+  float acc_loss = 0.f;
+  const int rounds = (M + SLOTS - 1) / SLOTS;
+  for (int r = 0; r < rounds; ++r) {
+    const int m = slot + SLOTS * r;
+    const bool in = m < M;
+    const int mm = in ? m : 0;
+    const float wgt = in ? a.mask[(size_t)f * M + mm] : 0.f;
+    float vm[3] = {0.f, 0.f, 0.f}, bk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int vi = a.assign3[mm * 3 + k];
+      if ((unsigned)vi >= (unsigned)a.V) vi = 0;
+      bk[k] = a.bary[mm * 3 + k];
+      const float* pt = a.PT + (size_t)vi * 3 * UUO_KB + sl;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        s0 = fmaf(pt[16 * t], fk[t], s0);
+        s1 = fmaf(pt[UUO_KB + 16 * t], fk[t], s1);
+        s2 = fmaf(pt[2 * UUO_KB + 16 * t], fk[t], s2);
+      }
+      const float* ps = a.ST + (size_t)vi * 30 + (sl < 10 ? sl : 0);
+      const float st0 = (sl < 10) ? ps[0] : 0.f, st1 = (sl < 10) ? ps[10] : 0.f, st2 = (sl < 10) ? ps[20] : 0.f;
+      float vp[3];
+      vp[0] = row_sum(s0) + (a.vt[(size_t)vi * 3] + row_sum(st0 * beta_s));
+      vp[1] = row_sum(s1) + (a.vt[(size_t)vi * 3 + 1] + row_sum(st1 * beta_s));
+      vp[2] = row_sum(s2) + (a.vt[(size_t)vi * 3 + 2] + row_sum(st2 * beta_s));
+      const int4 wi = *reinterpret_cast<const int4*>(a.Wi + (size_t)vi * 4);
+      const float4 w4 = *reinterpret_cast<const float4*>(a.Ww + (size_t)vi * 4);
+      const int wj[4] = {wi.x, wi.y, wi.z, wi.w};
+      const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+      float T[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float* pa = sA + wj[n] * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(ww[n], pa[e], T[e]);
+      }
+      const float vx = fmaf(T[2], vp[2], fmaf(T[1], vp[1], T[0] * vp[0])) + T[3] + tr[0];
+      const float vy = fmaf(T[6], vp[2], fmaf(T[5], vp[1], T[4] * vp[0])) + T[7] + tr[1];
+      const float vz = fmaf(T[10], vp[2], fmaf(T[9], vp[1], T[8] * vp[0])) + T[11] + tr[2];
+      vm[0] = fmaf(bk[k], vx, vm[0]);
+      vm[1] = fmaf(bk[k], vy, vm[1]);
+      vm[2] = fmaf(bk[k], vz, vm[2]);
+    }
+    const float* px = a.markers + ((size_t)f * M + mm) * 3;
+    const float dx = px[0] - vm[0], dy = px[1] - vm[1], dz = px[2] - vm[2];
+    const float rr = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float e = rr - a.d0;
+    acc_loss += wgt * (e * e);
+    const float sc = (rr > 0.f) ? (-a.cg * wgt * e / rr) : 0.f;
+    if (in && sl < 9) {  // sub-lane 3 k + c writes component c of corner k's item
+      const int k = sl / 3, c = sl - 3 * k;
+      const float gc = sc * ((c == 0) ? dx : ((c == 1) ? dy : dz));
+      const float b = (k == 0) ? bk[0] : ((k == 1) ? bk[1] : bk[2]);
+      a.up_items[((size_t)f * 3 * M + (size_t)m * 3 + k) * 3 + c] = b * gc;
+    }
+  }
+  if (sl == 0) sloss[slot] = acc_loss;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int s = 0; s < SLOTS; ++s) t += sloss[s];
+    a.item_loss[f] = t;
+  }
+}
 // part stage on its cached pose blend: a fraction of the registers and two thirds of the LDS of the general kernel
 // two forms: one wave per frame for <= 16 markers (the candidate search: four items per pass), four waves per frame above
 // that (hmr_full.yaml: 50 markers on the full skeleton would be 13 passes of one wave)
@@ -969,6 +1117,8 @@ static int validate_problem(const uuo_fit* fit, const uuo_problem_t* p) {
   UUO_REQUIRE(p->d_markers && p->d_o_pose && p->d_o_betas, "closure: markers / o_pose / o_betas required");
   if (p->stage != UUO_STAGE_MARKER) UUO_REQUIRE(p->d_root != nullptr, "closure: fixed root orientation required");
   if (p->stage == UUO_STAGE_MARKER) UUO_REQUIRE(p->d_assign != nullptr, "closure: marker stage needs d_assign");
+  UUO_REQUIRE(p->n_corners == 0 || p->n_corners == 1 || (p->n_corners == 3 && p->stage == UUO_STAGE_MARKER && p->d_bary != nullptr),
+              "closure: n_corners is 0 / 1 (one-hot placement) or 3 with d_bary (marker stage on a three-corner placement)");
   if (p->stage == UUO_STAGE_PART)
     UUO_REQUIRE(p->d_subset != nullptr && p->n_subset > 0 && p->n_subset <= fit->model->V, "closure: part stage needs a vertex subset");
   UUO_REQUIRE(p->w_soft == 0.f || (p->soft_tau > 0.f && p->stage != UUO_STAGE_MARKER), "closure: w_soft (soft-assignment data term, extension) needs soft_tau > 0 and the chamfer or part stage");
@@ -1344,6 +1494,33 @@ int uuo_closure_eval_impl(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, c
       else
         hipLaunchKernelGGL(k_bwd_part, dim3(F), dim3(BWD_NW * 64), 0, s, a);
     }
+  } else if (p->stage == UUO_STAGE_MARKER && p->n_corners == 3) {
+    // three-corner (barycentric) placement: a forward pass over the 3 M corner vertices forms the virtual markers, the loss and
+    // d loss / d corner; the sparse backward runs on those items (k_bwd_items)
+    UUO_REQUIRE(!uuo_recorder, "closure: the three-corner marker closure is not available inside a lock-step batch");
+    if (!fit->bary_items) UUO_HIP_CHECK(hipMalloc((void**)&fit->bary_items, ((size_t)F * 3 * M * 3 + F) * sizeof(float)));
+    float* items = fit->bary_items;
+    float* item_loss = fit->bary_items + (size_t)F * 3 * M * 3;
+    BaryFwdArgs b;
+    std::memset(&b, 0, sizeof(b));
+    b.PT = m->PT; b.ST = m->ST; b.vt = m->vt; b.Ww = m->Ww; b.Wi = m->Wi; b.tree = m->tree;
+    b.V = m->V; b.F = F; b.M = M;
+    b.src = src;
+    b.markers = p->d_markers;
+    b.mask = fit->mask;
+    b.assign3 = p->d_assign;
+    b.bary = p->d_bary;
+    b.cg = a.cg;
+    b.d0 = p->marker_distance;
+    b.frames = fit->frames;
+    b.up_items = items;
+    b.item_loss = item_loss;
+    hipLaunchKernelGGL(k_bary_fwd, dim3(F), dim3(BWD_NW * 64), 0, s, b);
+    a.M = 3 * M;
+    a.up_items = items;
+    a.item_loss = item_loss;
+    a.frames = fit->frames;
+    hipLaunchKernelGGL(k_bwd_items, dim3(F), dim3(BWD_NW * 64), 0, s, a);
   } else if (soft && p->stage == UUO_STAGE_CHAMFER) {
     // EXTENSION: soft-assignment data term of the chamfer stage.  The forward above has skinned the vertices and run the exact
     // search (dmin, the hard assignment); the soft minimum gives EVERY vertex within reach of a marker a gradient, so the

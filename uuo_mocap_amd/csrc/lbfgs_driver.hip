@@ -741,6 +741,7 @@ extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   uuo_dense_ws_destroy(fit->dense);
   if (fit->soft_gV) (void)hipFree(fit->soft_gV);
   if (fit->soft_sm) (void)hipFree(fit->soft_sm);
+  if (fit->bary_items) (void)hipFree(fit->bary_items);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);
   if (fit->ev1) (void)hipEventDestroy(fit->ev1);
   if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);

@@ -9,7 +9,7 @@ static thread_local std::string g_last_error;
 void uuo_set_error(const std::string& msg) { g_last_error = msg; }
 thread_local UuoRecorder* uuo_recorder = nullptr;  // non-null while a lock-step batch records its launches
 extern "C" const char* uuo_last_error(void) { return g_last_error.c_str(); }
-extern "C" int uuo_abi_version(void) { return 2; }
+extern "C" int uuo_abi_version(void) { return 3; }
 
 template <typename T>
 static int upload(T** dst, const std::vector<T>& src) {

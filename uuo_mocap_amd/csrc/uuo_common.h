@@ -165,6 +165,7 @@ struct uuo_fit {
   struct UuoDenseWs* dense = nullptr;  // soft chamfer closure (extension): workspace of the dense backward, its vertex gradient
   float* soft_gV = nullptr;            // [F][V][3] and [4][F][M] floats of soft-min scratch; allocated on first use
   float* soft_sm = nullptr;
+  float* bary_items = nullptr;         // marker stage on a three-corner placement: [F][3 M][3] corner items + [F] loss sums (first use)
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
   float* frame_part = nullptr;      // [F][UUO_FP]: loss, dz, pose sq, dbeta[10], gradient statistics

@@ -630,7 +630,9 @@ class MarkerProblem(_StageProblem):
 
     stage = UUO_STAGE_MARKER
 
-    def __init__(self, smpl_inference, markers, o_pose_body, o_betas, assign, config):
+    def __init__(self, smpl_inference, markers, o_pose_body, o_betas, assign, config, bary=None):
+        """`assign` [M] vertex ids (the one-hot placement of the shipped configs), or -- with `bary` [M, 3] -- [M, 3] corner
+        vertex ids of a three-corner (barycentric) placement: virtual marker m = sum_k bary[m, k] v[assign[m, k]]."""
         st = config["stages"]["marker"]
         unsupported = set(st["losses"]) - {"marker", "reg_pose_body", "reg_betas"}
         if unsupported:
@@ -639,6 +641,14 @@ class MarkerProblem(_StageProblem):
             raise NotImplementedError("stages.marker.use_sdf is off in every shipped config")
         wd, wp, wb = _cfg_weights(st["losses"], "marker")
         super().__init__(smpl_inference.device_model, markers, o_pose_body, o_betas, None, wd, wp, wb, assign=assign)
+        if bary is not None:
+            if self.assign.dim() != 2 or tuple(self.assign.shape) != (self.M, 3) or tuple(bary.shape) != (self.M, 3):
+                raise ValueError("a three-corner placement takes assign [M, 3] and bary [M, 3]")
+            self.bary = _f32(bary, "bary").to(self.device).contiguous()
+            self.problem.n_corners = 3
+            self.problem.d_bary = self.bary.data_ptr()
+        elif self.assign.dim() != 1 or self.assign.numel() != self.M:
+            raise ValueError("a one-hot placement takes assign [M]")
 
     def pack(self, pose_body, betas, root_orient, trans):
         return torch.cat([_f32(pose_body, "pose").reshape(-1), _f32(betas, "betas").reshape(-1),

@@ -27,7 +27,7 @@ LAST_STATS: Dict[str, list] = {}
 # multimodal_video_mocap.  These were environment variables in round 2: the product path reads no environment now.
 EXECUTION_DEFAULTS = {"subtree_lockstep": True, "subtree_batch": 256, "subtree_threads": 4,
                       "hypothesis_lockstep": False, "hypothesis_threads": 4, "batch_trivial_hypotheses": True,
-                      "part_soft_fused": True, "chamfer_soft_fused": True}
+                      "part_soft_fused": True, "chamfer_soft_fused": True, "marker_bary_fused": True}
 
 
 def merge_execution(config: Dict, execution: Dict = None) -> Dict:

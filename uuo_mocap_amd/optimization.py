@@ -232,6 +232,15 @@ def optim_markers_lockstep(markers, hyps, o_pose_bodies, o_betas, one_hots, smpl
     return stats
 
 
+def placement_corners(placement: torch.Tensor):
+    """A placement matrix [M, V] with at most three non-zeros per row (compute_nearest_points with use_barycentric) as
+    (corner vertex ids [M, 3] int32 in ascending order, their weights [M, 3]); rows with fewer non-zeros are padded with
+    zero-weight corners."""
+    _, i3 = torch.topk(placement.abs(), 3, dim=1)
+    i3, _ = torch.sort(i3, dim=1)  # ascending vertex order: a fixed summation order of the virtual marker
+    return i3.to(torch.int32), torch.gather(placement, 1, i3).to(torch.float32)
+
+
 def is_one_hot_placement(one_hot: torch.Tensor) -> bool:
     rows_nz = (one_hot != 0).sum(dim=1)
     return bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all())
@@ -373,18 +382,26 @@ def optim_markers(
     if one_hot.dim() != 2 or one_hot.shape[1] != smpl_inference.device_model.V:
         raise ValueError("barycentric_coords_one_hot must be [M, %d]" % smpl_inference.device_model.V)
     rows_nz = (one_hot != 0).sum(dim=1)
-    if not bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all()):
-        # barycentric placement (compute_locations.use_barycentric): up to three weighted vertices per marker
-        return _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
-                                      smpl_inference, config, verbose, iter_fn, initial_angle, repeat)
-    assign = torch.argmax(one_hot, dim=-1)
     from .parallel import frame_shard
 
     fs = frame_shard()
-    if fs is not None and fs.active:
+    sharded = fs is not None and fs.active
+    bary = None
+    if not bool(((rows_nz == 1) & (one_hot.sum(dim=1) == 1.0)).all()):
+        # barycentric placement (compute_locations.use_barycentric): up to three weighted vertices per marker.  Fused closure
+        # (k_bary_fwd + k_bwd_items) when it is that and nothing else; execution.marker_bary_fused: False, more than three
+        # non-zeros in a row, or frame-block sharding keep the closure composed from the operators
+        fused = (one_hot.is_cuda and int(rows_nz.max()) <= 3 and not sharded and
+                 bool((config.get("execution") or {}).get("marker_bary_fused", True)))
+        if not fused:
+            return _optim_markers_general(markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, one_hot,
+                                          smpl_inference, config, verbose, iter_fn, initial_angle, repeat)
+        bary = placement_corners(one_hot)
+    assign = bary[0] if bary is not None else torch.argmax(one_hot, dim=-1)
+    if sharded:
         return _optim_markers_frame_sharded(fs, markers, pose_body, o_pose_body, betas, o_betas, root_orient, trans, assign,
                                             smpl_inference, config, iter_fn)
-    prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config)
+    prob = MarkerProblem(smpl_inference, markers, o_pose_body, o_betas, assign, config, bary=None if bary is None else bary[1])
     x = prob.pack(pose_body, betas, root_orient, trans)
     point_cb = None
     if iter_fn is not None:
