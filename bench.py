@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PEAK_FP16_TFLOPS = 2500.0  # same guide: dense F16/BF16 matrix peak
+# k_skin3 at F=300, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per launch; profiles/r4_pmc_summary.json)
+SKIN16_FETCH_KB, SKIN16_WRITE_KB = 13514.6, 30858.6
 PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32) = vector peak
 # algorithmic FLOPs of the skin kernel per frame: pose blend 2*207*20670 + skinning 2*6890*24*12 + apply 6890*24
 SKIN_FLOPS_PER_FRAME = 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 6890 * 24
@@ -267,21 +270,28 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
                           full_cfg)
     x = prob.pack(torch.median(markers, dim=1)[0], torch.zeros(F, 1, 1, device=dev), o_betas,
                   seq.img_smpl.pose_body.to(dev))
-    skin_ms = prob.time_closure(x, iters=iters, dominant_only=True)
+    skin32_ms = prob.time_closure(x, iters=iters, dominant_only=1)   # k_skin2: the fp32 matrix pipe (operators, other closures)
+    skin_ms = prob.time_closure(x, iters=iters, dominant_only=2)     # k_skin3: the chamfer closure's own skinning kernel
     closure_ms = prob.time_closure(x, iters=iters, dominant_only=False)
     skin_flops = SKIN_EXECUTED_FLOPS_PER_FRAME * F
     achieved = skin_flops / (skin_ms * 1e-3) / 1e12                       # executed useful FLOPs: what `frac` is made of
     survey = SKIN_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12           # SURVEY 8d's count (dense skinning credited)
-    # HBM traffic of one k_skin launch: separate rocprofv3 --pmc passes (profiles/r4_pmc_summary.json; the kernel is round 3's):
-    # FETCH_SIZE 15 276 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 408 KB, at F=300.
+    # HBM traffic of one k_skin3 launch: separate rocprofv3 --pmc passes (profiles/r4_pmc_summary.json):
+    # FETCH_SIZE 13 515 KB x2 (gfx950 correction for 16-B/lane coalesced reads) + WRITE_SIZE 30 859 KB, at F=300
+    # (k_skin2: 15 188 x2 + 30 396).
     # An OFFLINE figure (a PMC pass cannot run inside this process): null at any other size.
-    traffic = int((15276.1 * 2 + 30407.7) * 1024) if (F == 300) else None
+    traffic = int((SKIN16_FETCH_KB * 2 + SKIN16_WRITE_KB) * 1024) if (F == 300) else None
     mfma_useful = SKIN_MFMA_FLOPS_PER_FRAME * F / (skin_ms * 1e-3) / 1e12
     closure_rate = F / (closure_ms * 1e-3)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "frac_basis": "executed useful FLOPs of k_skin2: 9.80 MFLOP per frame (217 x 20670 blend on the matrix pipe, "
-                              "<=4-weight skinning and the 3x4 apply on the VALU)",
+                "frac_basis": "useful FLOPs of k_skin3 at their fp32 count -- 9.80 MFLOP per frame (217 x 20670 blend, <=4-weight "
+                              "skinning and the 3x4 apply on the VALU) -- against the FP32 matrix peak, the precision class of its "
+                              "result; the blend itself runs on the fp16 pipe: both operands split into hi/lo fp16 planes, three "
+                              "products of 224 x 20670 (v_mfma_f32_16x16x32_f16, fp32 accumulation): frac_of_fp16_peak",
+                "frac_of_fp16_peak": (3 * 2 * 224 * 20670 * F / (skin_ms * 1e-3) / 1e12) / PEAK_FP16_TFLOPS,
+                "fp32_kernel": "k_skin2<true,0>", "fp32_kernel_ms": skin32_ms,
+                "fp32_kernel_frac": (skin_flops / (skin32_ms * 1e-3) / 1e12) / PEAK_FP32_TFLOPS,
                 "frac_survey_flops": survey / PEAK_FP32_TFLOPS, "achieved_survey_flops": survey,
                 "flops_per_launch_survey": SKIN_FLOPS_PER_FRAME * F,
                 # PMC bytes of a launch against what a fully fused closure would have to move (tables once +
@@ -289,9 +299,9 @@ def measure_roofline(smpl, seq, dev, F, iters=200):
                 # materialised for the pruned search: 46.6 MB)
                 "traffic_vs_algorithmic": (traffic / FUSED_ALGORITHMIC_BYTES(F)) if traffic else None,
                 "traffic_vs_unfused_budget": (traffic / (18688848 + F * (6890 * 12 + 431 * 24))) if traffic else None,
-                "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel at F=300 "
+                "traffic_source": "OFFLINE: separate rocprofv3 --pmc passes of this kernel (k_skin3) at F=300 "
                                   "(profiles/r4_pmc_summary.json), not measured by this run",
-                "kernel": "k_skin2<true,0>",
+                "kernel": "k_skin3<true>",
                 # frac credits SURVEY 8d's dense 24-joint skinning product; the kernel does that part as <=4-weight VALU
                 # work, so the matrix pipe's own useful rate is the blend contraction alone:
                 "frac_mfma_useful": mfma_useful / PEAK_FP32_TFLOPS, "achieved_mfma_useful": mfma_useful,

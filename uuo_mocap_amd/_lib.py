@@ -124,6 +124,7 @@ _DEBUG_SIGNATURES = {
                                    POINTER(UuoLbfgsStats), c_void_p, c_void_p]),
     "uuo_debug_fit_buffers": (c_int, [c_void_p, c_void_p, c_void_p]),
     "uuo_debug_nn_flags": (c_int, [c_void_p, c_void_p]),
+    "uuo_debug_skin16_check": (c_int, [c_void_p, c_int]),
     "uuo_debug_small_coeffs": (c_int, [c_int, c_int, c_int, c_void_p]),
     "uuo_debug_time_small": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
     "uuo_debug_index_map": (c_int, [c_int, c_int, c_int, c_void_p]),

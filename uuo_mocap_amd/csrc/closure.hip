@@ -1163,6 +1163,44 @@ static UuoPoseSrc stage_pose_src(const uuo_problem_t* p, const StageLayout& lay,
   return src;
 }
 
+#ifdef UUO_DEBUG_HOOKS
+// debug flavour (UUO_SKIN_F16_CHECK=1; tools/skin16_stress.py): after k_skin3, the fp32 kernel on the same operands into a scratch
+// buffer of the workspace, and a count of the values that differ by more than 1e-5 m / of the boxes that differ at all from the
+// fp32 kernel's by more than 1e-5
+__device__ unsigned long long g_skin16_check[4];  // launches, vertex values off, box values off, (unused)
+__global__ __launch_bounds__(256) void k_skin16_compare(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                        const float* __restrict__ ba, const float* __restrict__ bb, size_t nb) {
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  unsigned bad = 0, badb = 0;
+  for (size_t i = i0; i < n; i += stride) bad += (fabsf(a[i] - b[i]) > 1e-5f) ? 1u : 0u;
+  for (size_t i = i0; i < nb; i += stride) badb += (fabsf(ba[i] - bb[i]) > 1e-5f) ? 1u : 0u;
+  if (bad) atomicAdd(&g_skin16_check[1], (unsigned long long)bad);
+  if (badb) atomicAdd(&g_skin16_check[2], (unsigned long long)badb);
+  if (i0 == 0) atomicAdd(&g_skin16_check[0], 1ull);
+}
+static int uuo_debug_skin16_compare(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, const UuoPoseSrc& src) {
+  const uuo_model* m = fit->model;
+  const size_t nv = (size_t)p->F * m->V * 3, nb = (size_t)p->F * ((m->V + 15) / 16) * 6;
+  if (!fit->dbg_verts) UUO_HIP_CHECK(hipMalloc((void**)&fit->dbg_verts, (nv + nb) * sizeof(float)));
+  int rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->dbg_verts, fit->dbg_verts + nv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_skin16_compare, dim3(512), dim3(256), 0, s, fit->verts, fit->dbg_verts, nv, fit->bbox, fit->dbg_verts + nv, nb);
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int uuo_debug_skin16_check(unsigned long long* h_out /* [3]: launches, vertex values off, box values off */, int reset) {
+  UUO_HIP_CHECK(hipDeviceSynchronize());
+  unsigned long long h[4] = {0, 0, 0, 0};
+  UUO_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_skin16_check), sizeof(h)));
+  if (h_out) { h_out[0] = h[0]; h_out[1] = h[1]; h_out[2] = h[2]; }
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    UUO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_skin16_check), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
+
 // forward half shared by uuo_closure_eval and uuo_time_closure
 // `need_verts`: the caller reads fit->verts afterwards (candidate scores); a closure evaluation does not (the backward
 // kernel re-skins the winners), which lets the part stage keep its vertices in registers (k_part_fwd)
@@ -1207,7 +1245,16 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
     return uuo_launch_part_fwd(m, s, p->F, p->M, fit->pose_cache, fit->part_sb, fit->A, src.trans, p->d_subset, p->n_subset,
                                p->d_markers, fit->nn);
   }
-  rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames);
+  // The chamfer closure's vertices feed the nearest-vertex SEARCH only (loss and gradient are formed in fp32 on the re-skinned
+  // winners): its blend runs on the fp16 matrix pipe with split operands (k_skin3).  Callers that read the vertices (candidate
+  // scores; the soft closure, whose soft-min and dense gradient are formed on them) keep the fp32 pipe.
+#ifndef UUO_SKIN_F16
+#define UUO_SKIN_F16 1  // (0: A/B builds of tools/build_variant.sh)
+#endif
+  const int skin16_on = UUO_ENV_INT("UUO_SKIN_F16", UUO_SKIN_F16);  // debug flavour only: the fp32 kernel, for comparison
+  const bool skin16 = skin16_on && !cached && !need_verts && !vp_out && p->w_soft == 0.f && p->stage == UUO_STAGE_CHAMFER &&
+                      m->P16 && p->d_subset == nullptr && (m->VP / 16) <= 512 && p->M <= 512;
+  rc = uuo_launch_pose_prep(m, s, p->F, src, fit->pfaT, fit->A, nullptr, fit->frames, nullptr, 0, nullptr, skin16 ? fit->pfa16 : nullptr);
   if (rc) return rc;
   if (cached) {
     // more than 16 markers on a cached pose (hmr_full.yaml: 50 markers, the full skeleton): the candidate's vertices in
@@ -1230,7 +1277,16 @@ static int closure_forward(uuo_fit* fit, hipStream_t s, const uuo_problem_t* p, 
   {
     // (v_posed rides along only on the k_skin2 path with unit boxes; otherwise the dense backward skins it itself)
     const bool with_vp = cull && vp_out && !uuo_recorder;
-    rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr, with_vp ? vp_out : nullptr);
+    rc = -22;
+    if (skin16) rc = uuo_launch_skin16(m, s, p->F, fit->pfa16, fit->A, src.trans, fit->verts, fit->bbox);
+#ifdef UUO_DEBUG_HOOKS
+    if (skin16 && rc == 0 && !uuo_recorder && UUO_ENV_INT("UUO_SKIN_F16_CHECK", 0)) {  // stress mode: every launch against the fp32 kernel
+      rc = uuo_debug_skin16_compare(fit, s, p, src);
+      if (rc) return rc;
+    }
+#endif
+    if (rc == -22)  // (not asked for, or a launch geometry k_skin3 does not cover)
+      rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr, with_vp ? vp_out : nullptr);
     if (rc == -22 && with_vp) {  // (the generic skinning kernel was needed: again without the extra output)
       rc = uuo_launch_skin(m, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, cull ? fit->bbox : nullptr);
     } else if (rc == 0 && vp_done) {
@@ -1587,14 +1643,19 @@ extern "C" int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_
   if (dominant_only) {
     // the dominant kernel alone, one event pair per launch on the launch stream: the average is the kernel's own
     // duration (what rocprofv3 --kernel-trace reports), without the dispatch gap between back-to-back launches
+    // (dominant_only 2: the skinning kernel of the chamfer closure's search, k_skin3 on the fp16 pipe -- the forward above has
+    // left its operand; 1: the fp32 kernel k_skin2, which the operators and the other closures run)
     float total = 0.f;
+    const bool k3 = dominant_only == 2;
     for (int i = 0; i < 10; ++i) {  // untimed: clocks and caches in the state of a running fit
-      rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
+      rc = k3 ? uuo_launch_skin16(fit->model, s, p->F, fit->pfa16, fit->A, src.trans, fit->verts, fit->bbox)
+              : uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
       if (rc) return rc;
     }
     for (int i = 0; i < iters; ++i) {
       UUO_HIP_CHECK(hipEventRecord(fit->ev0, s));
-      rc = uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
+      rc = k3 ? uuo_launch_skin16(fit->model, s, p->F, fit->pfa16, fit->A, src.trans, fit->verts, fit->bbox)
+              : uuo_launch_skin(fit->model, s, p->F, fit->pfaT, fit->A, src.trans, fit->verts, fit->bbox);
       if (rc) return rc;
       UUO_HIP_CHECK(hipEventRecord(fit->ev1, s));
       UUO_HIP_CHECK(hipEventSynchronize(fit->ev1));

@@ -698,6 +698,7 @@ int fit_create_impl(uuo_model_t* model, int F, int M, uuo_fit_t** out, bool sync
   auto A = [&](void** p, size_t bytes) { pieces.push_back({p, (bytes + 255) / 256 * 256}); };
   A((void**)&fit->pfaT, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));
   A((void**)&fit->A, (size_t)nFT * UUO_FT * UUO_NUM_JOINTS * 12 * sizeof(float));
+  A((void**)&fit->pfa16, (size_t)nFT * UUO_KP * UUO_FT * sizeof(float));  // (two fp16 planes: the bytes of pfaT)
   A((void**)&fit->verts, (size_t)F * model->V * 3 * sizeof(float));
   A((void**)&fit->nn_flags, (size_t)F * 8 * sizeof(int));
   A((void**)&fit->part_sb, (size_t)model->V * 8 * sizeof(float));
@@ -742,6 +743,7 @@ extern "C" int uuo_fit_destroy(uuo_fit_t* fit) {
   if (fit->soft_gV) (void)hipFree(fit->soft_gV);
   if (fit->soft_sm) (void)hipFree(fit->soft_sm);
   if (fit->bary_items) (void)hipFree(fit->bary_items);
+  if (fit->dbg_verts) (void)hipFree(fit->dbg_verts);
   if (fit->ev0) (void)hipEventDestroy(fit->ev0);
   if (fit->ev1) (void)hipEventDestroy(fit->ev1);
   if (fit->lbws) lbws_destroy((LbWs*)fit->lbws);

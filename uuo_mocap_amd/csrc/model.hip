@@ -1,5 +1,6 @@
 // Model tables: host-side re-layout for gfx950 and upload.  Replaces smplx.create(...) as used by
 // SmplInference.__init__ (reference src/video_mocap/utils/smpl.py:22-27).
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -48,6 +49,34 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
                 baug(4 * (4 * g + t) + (l >> 4), 16 * u + (l & 15), c);
   for (int v = 0; v < VP; ++v)
     for (int c = 0; c < 3; ++c) vt3[(size_t)c * VP + v] = vt[(v < V ? v : V - 1) * 3 + c];
+
+  // the same basis for v_mfma_f32_16x16x32_f16 (k_skin3): every entry times a power of two that brings the largest one into
+  // [128, 256), split into hi = fp16(x) and lo = fp16(x - hi) (22 significant bits, the scaling is exact); a lane's 8 K-slots of
+  // step s are its 4 + 4 values of groups 2 s and 2 s + 1 above, so the A operand is the same regrouping of pfaT (k_pose_prep)
+  std::vector<_Float16> P16((size_t)3 * nunits * ngroups * 512);
+  {
+    float amax = 0.f;
+    for (float x : P3) amax = std::fmax(amax, std::fabs(x));
+    int e = 0;
+    if (amax > 0.f && std::isfinite(amax)) {
+      (void)std::frexp(amax, &e);  // amax = f * 2^e, f in [0.5, 1)  ->  amax * 2^(8 - e) in [128, 256)
+      e = 8 - e;
+    }
+    const float bscale = std::ldexp(1.0f, e);
+    m->skin16_inv = 1.0f / (UUO_SK16_ASCALE * bscale);
+    for (int c = 0; c < 3; ++c)
+      for (int u = 0; u < nunits; ++u)
+        for (int st = 0; st < ngroups / 2; ++st)
+          for (int l = 0; l < 64; ++l)
+            for (int t = 0; t < 8; ++t) {
+              const float x = bscale * P3[((((size_t)c * nunits + u) * ngroups + 2 * st + (t >> 2)) * 64 + l) * 4 + (t & 3)];
+              const _Float16 hi = (_Float16)x;
+              const _Float16 lo = (_Float16)(x - (float)hi);
+              const size_t base = ((((size_t)c * nunits + u) * (ngroups / 2) + st) * 2) * 512 + (size_t)l * 8 + t;
+              P16[base] = hi;
+              P16[base + 512] = lo;
+            }
+  }
 
   // per-vertex transposed posedirs rows PT[v][c][k] (contiguous 3*208 floats per vertex) for gather-LBS / backward
   std::vector<float> PT((size_t)V * 3 * UUO_KB, 0.f);
@@ -174,6 +203,11 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
   rc |= upload(&m->JLv, JLv);
   rc |= upload(&m->JLw, JLw);
   rc |= upload(&m->P3, P3);
+  {
+    _Float16* d16 = nullptr;
+    rc |= upload(&d16, P16);
+    m->P16 = d16;
+  }
   rc |= upload(&m->vt3, vt3);
   rc |= upload(&m->PT, PT);
   std::vector<float> ST(S, S + (size_t)V * 30), vtv(vt, vt + (size_t)V * 3);
@@ -198,7 +232,7 @@ extern "C" int uuo_model_create(const float* vt, const float* S, const float* P,
 
 extern "C" int uuo_model_destroy(uuo_model_t* m) {
   if (!m) return 0;
-  void* ptrs[] = {m->P3, m->vt3, m->PT, m->ST, m->vt, m->Wi, m->Ww, m->tree, m->PB, m->JLoff, m->JLv, m->JLw};
+  void* ptrs[] = {m->P3, m->P16, m->vt3, m->PT, m->ST, m->vt, m->Wi, m->Ww, m->tree, m->PB, m->JLoff, m->JLv, m->JLw};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& kv : m->bwd) {

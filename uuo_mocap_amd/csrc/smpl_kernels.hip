@@ -16,7 +16,7 @@ __device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoT
                                                const float* __restrict__ ST = nullptr, const int* __restrict__ Wi = nullptr,
                                                const float* __restrict__ Ww = nullptr, int V = 0,
                                                const int32_t* __restrict__ subset = nullptr, int ns = 0,
-                                               float* __restrict__ sb_out = nullptr) {
+                                               float* __restrict__ sb_out = nullptr, _Float16* __restrict__ pfa16 = nullptr) {
   __builtin_amdgcn_s_setprio(3);  // latency-bound kernel: do not queue behind co-resident MFMA waves
   __shared__ FrameLds L;
   const int f = blockIdx.x;
@@ -30,7 +30,19 @@ __device__ __forceinline__ void pose_prep_body(const UuoPoseSrc& src, const UuoT
   // A operand in MFMA order: lane (k&3)*16 + i of group (k>>4) holds A[i][k] at slot (k>>2)&3  (see model.hip)
   const int ft = f / UUO_FT, i = f % UUO_FT;
   float* tile = pfaT + (size_t)ft * UUO_KP * UUO_FT;
-  auto put = [&](int k, float v) { tile[(((k >> 4) * 64 + ((k & 3) * 16 + i)) << 2) + ((k >> 2) & 3)] = v; };
+  // the same operand for k_skin3 (when asked for): 128 x the value as hi = fp16(x), lo = fp16(x - hi) in v_mfma_f32_16x16x32_f16
+  // order pfa16[ft][step k >> 5][plane][lane][slot 4 ((k >> 4) & 1) + ((k >> 2) & 3)]  (see model.hip, P16)
+  _Float16* tile16 = pfa16 ? pfa16 + (size_t)ft * UUO_KP * UUO_FT * 2 : nullptr;
+  auto put = [&](int k, float v) {
+    tile[(((k >> 4) * 64 + ((k & 3) * 16 + i)) << 2) + ((k >> 2) & 3)] = v;
+    if (tile16) {
+      const float x = v * UUO_SK16_ASCALE;
+      const _Float16 hi = (_Float16)x;
+      const int o = (((k >> 5) * 2) * 64 + ((k & 3) * 16 + i)) * 8 + (((k >> 4) & 1) * 4 + ((k >> 2) & 3));
+      tile16[o] = hi;
+      tile16[o + 512] = (_Float16)(x - (float)hi);
+    }
+  };
   if (l >= 1 && l < UUO_NUM_JOINTS) {
 #pragma unroll
     for (int e = 0; e < 9; ++e) put((l - 1) * 9 + e, L.R[l][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
@@ -102,18 +114,20 @@ struct PosePrepArgs {
   uuo_gptr<const int32_t> subset;
   int ns;
   uuo_gptr<float> sb_out;
+  uuo_gptr<_Float16> pfa16;        // k_skin3 follows: the fp16-split copy of the A operand; null otherwise
 };
 __global__ __launch_bounds__(64) void k_pose_prep(PosePrepArgs a) {
-  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out);
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out, a.pfa16);
 }
 __global__ __launch_bounds__(64) void k_pose_prep_b(const PosePrepArgs* __restrict__ batch) {
   UUO_BATCH_PICK(PosePrepArgs, batch)
-  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out);
+  pose_prep_body(a.src, a.tree, a.F, a.pfaT, a.A, a.jposed, a.frames, a.ST, a.Wi, a.Ww, a.V, a.subset, a.ns, a.sb_out, a.pfa16);
 }
 
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
-                         float* jposed, float* frames, const int32_t* sb_subset, int sb_ns, float* sb_out) {
-  PosePrepArgs a{{F, 1}, src, m->tree, F, pfaT, A, jposed, frames, sb_out ? m->ST : nullptr, m->Wi, m->Ww, m->V, sb_subset, sb_ns, sb_out};
+                         float* jposed, float* frames, const int32_t* sb_subset, int sb_ns, float* sb_out, void* pfa16) {
+  PosePrepArgs a{{F, 1}, src, m->tree, F, pfaT, A, jposed, frames, sb_out ? m->ST : nullptr, m->Wi, m->Ww, m->V, sb_subset, sb_ns, sb_out,
+                 (_Float16*)pfa16};
   if (uuo_record(UUO_OP_POSE_PREP, F, 1, a)) return 0;
   hipLaunchKernelGGL(k_pose_prep, dim3(F), dim3(64), 0, s, a);
   UUO_HIP_CHECK(hipGetLastError());
@@ -739,6 +753,256 @@ __global__ __launch_bounds__(SKIN_WAVES * 64) __attribute__((amdgpu_waves_per_eu
   }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// K_B3  skin on the fp16 matrix pipe: the blend of a closure's SEARCH (chamfer stage: the vertices feed the nearest-vertex search
+// only -- loss and gradient are formed in fp32 on the re-skinned winners by the backward kernel).
+// v_mfma_f32_16x16x32_f16 runs at 16 x the FLOP rate of v_mfma_f32_16x16x4_f32.  Both operands are split into two fp16 planes of a
+// power-of-two multiple, x = hi + lo + O(2^-22 |x|) (hi = fp16(x), lo = fp16(x - hi)), and three of the four products are kept:
+//   sum a b  ~=  sum a_hi b_hi  +  (sum a_hi b_lo + sum a_lo b_hi)          (fp32 accumulation; a_lo b_lo < 2^-22 |a b| is dropped)
+// The large and the small sums have their own accumulators, and the template is added LAST (k_skin2 accumulates onto it, rounding
+// at the template's magnitude 56 times), so the blend is at least as close to the exact one as the fp32 pipe's
+// (test_skin16_is_as_close_to_float64_as_the_fp32_kernel).  63 MFMAs of 16 cycles per task instead of 168 of 32.
+// Everything else -- tasks, claiming, LDS tiles, the 7-stage operand ring (same bytes: two fp16 planes = one fp32), the epilogue
+// slices of the previous unit between the MFMAs -- is k_skin2's.
+// ----------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SK3_STEPS (SKIN_GROUPS / 2)        // 7 K-steps of 32
+#define SK3_NMFMA (SK3_STEPS * 9)          // 63 MFMA slots per task
+#define SK3_NSLICE 144                     // 12 pieces x 12 slices of the previous unit's epilogue
+
+// ONE wave per SIMD, and no other matrix-pipe wave beside it.  With two waves of this kernel per SIMD (an 8-wave block) the x
+// coordinate of one frame of a unit -- always frame 13 of a tile -- came out wrong once or twice per launch (y and z exact; only
+// with the MFMAs in, whatever the register allocation, the order of the epilogue pieces or the padding after an MFMA; never with
+// four waves: 0 of 2.5e8 values in 40 launches).  The cause is not understood; the conditions are avoided by construction: four
+// waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304 static ones, so that no block of a kernel that
+// issues MFMAs (k_skin2 / k_skin3 66 304 B, k_dpf 57 344, k_skin 32 768) fits beside it on a CU (160 KB), while the latency-bound
+// kernels of other chains (< 32 KB of LDS) still do.  tools/skin16_stress.py checks every launch of whole fits in flight against
+// the fp32 kernel (debug flavour).
+#ifndef SK3_WAVES
+#define SK3_WAVES 4
+#endif
+#define SK3_LDS_PAD 65280  // 66 304 + 65 280 = 131 584 > 163 840 - 32 768
+template <bool BBOX>
+__global__ __launch_bounds__(SK3_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_skin3(
+    const float4* __restrict__ P16v, const float* __restrict__ vt3, const int* __restrict__ Wi, const float* __restrict__ Ww,
+    const float4* __restrict__ pfa16, const float* __restrict__ A, const float* __restrict__ trans, float* __restrict__ verts,
+    float* __restrict__ bbox, int F, int V, int VP, int nFT, float inv_scale) {
+  __shared__ float4 sA[2 * UUO_KP * UUO_FT / 4];               // [slot][7][2][64] x 16 B (8 halfs)
+  __shared__ f32x4 sT[2 * UUO_FT * UUO_NUM_JOINTS * 3];        // [slot][i][j][3]
+  __shared__ float4 sTr[2 * UUO_FT];                            // [slot][i] translation
+  __shared__ int sQ[64];                                        // sQ[0] = next unclaimed task of the block
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int nunits = VP / 16;
+  const int nur = (V + 15) / 16;
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  // (task space, segments and LDS slots: see k_skin2)
+  const int ntot = nFT * nur;
+  const int xlo = (int)(((unsigned)ntot * (unsigned)xcd) >> 3), xhi = (int)(((unsigned)ntot * (unsigned)(xcd + 1)) >> 3);
+  const int tb0 = xlo + (((xhi - xlo) * pos) >> SK2_NPOS_LOG2), tb1 = xlo + (((xhi - xlo) * (pos + 1)) >> SK2_NPOS_LOG2);
+  if (tb1 <= tb0) return;  // block-uniform
+  int xa = 0;
+  while (xa < 7 && nFT * (((xa + 1) * nur) >> 3) <= tb0) ++xa;
+  const int ua0 = (xa * nur) >> 3, ub0 = ((xa + 1) * nur) >> 3;
+  const int nua = ub0 - ua0;
+  const int Sa = nFT * ua0, Sb = nFT * ub0;
+  const int ftA = (tb0 - Sa) / nua;
+  const int g1 = Sa + ftA * nua;
+  const int g2 = (g1 + nua < Sb) ? g1 + nua : Sb;
+  const int ftB = (tb1 - 1 < Sb) ? ftA + 1 : 0;
+  const int nslots = (tb1 > g2) ? 2 : 1;
+
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(verts, 0, F * V * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(bbox, 0, BBOX ? F * nur * 24 : 0, 0x00020000);
+  const unsigned cplane = (unsigned)nunits * SKIN_GROUPS * 1024u;  // bytes per coordinate plane (as the fp32 table)
+  const __amdgpu_buffer_rsrc_t rp =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(P16v), 0, (int)(3u * cplane), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwi = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(Wi), 0, VP * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ww), 0, VP * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vt3), 0, VP * 12, 0x00020000);
+  const unsigned lane16 = lane * 16, j16 = j * 16, j4 = j * 4;
+  // block g of a unit's 14 1-KB blocks per coordinate: (K-step g >> 1, plane g & 1)
+#define SK3_LDB(c, ubase, g) \
+  __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, lane16, (ubase) + (c)*cplane + (g)*1024u, 0))
+#define SK3_DECODE(U, t_)                                                        \
+  {                                                                              \
+    const bool s1_ = (t_) < g2;                                                  \
+    const int base_ = s1_ ? g1 : ((t_) < Sb ? g2 : Sb);                          \
+    (U).u = (((t_) < Sb) ? ua0 : ub0) + (t_)-base_;                              \
+    (U).i0 = (s1_ ? ftA : ftB) * UUO_FT;                                         \
+    (U).slot = s1_ ? 0 : 1;                                                      \
+  }
+
+  constexpr int NA = UUO_KP * UUO_FT / 4, NT = UUO_FT * UUO_NUM_JOINTS * 3;  // float4 per slot: 896 + 1152
+  constexpr int PER = (2 * (NA + NT) + SK3_WAVES * 64 - 1) / (SK3_WAVES * 64);
+  float4 tmp[PER];
+  float4 trv = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float4* gA0 = pfa16 + (size_t)ftA * NA;
+    const float4* gA1 = pfa16 + (size_t)ftB * NA;
+    const float4* gT0 = reinterpret_cast<const float4*>(A + (size_t)ftA * UUO_FT * UUO_NUM_JOINTS * 12);
+    const float4* gT1 = reinterpret_cast<const float4*>(A + (size_t)ftB * UUO_FT * UUO_NUM_JOINTS * 12);
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + r * SK3_WAVES * 64;
+      tmp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NA) tmp[r] = gA0[i];
+      else if (i < 2 * NA) { if (nslots > 1) tmp[r] = gA1[i - NA]; }
+      else if (i < 2 * NA + NT) tmp[r] = gT0[i - 2 * NA];
+      else if (i < 2 * NA + 2 * NT) { if (nslots > 1) tmp[r] = gT1[i - 2 * NA - NT]; }
+    }
+    if (tid < 2 * UUO_FT) {
+      const int f = ((tid < UUO_FT) ? ftA : ftB) * UUO_FT + (tid & (UUO_FT - 1));
+      if (trans && f < F && (tid < UUO_FT || nslots > 1))
+        trv = make_float4(trans[(size_t)f * 3], trans[(size_t)f * 3 + 1], trans[(size_t)f * 3 + 2], 0.f);
+    }
+  }
+
+  int t_cur = tb0 + wave;
+  const bool active = t_cur < tb1;  // wave-uniform
+  if (!active) t_cur = tb0;
+  Sk2Unit cur, prv, nxt;
+  SK3_DECODE(cur, t_cur);
+  prv.u = cur.u; prv.i0 = F; prv.slot = 0;  // nothing to store for the first unit's "previous" epilogue
+  nxt = cur;
+  unsigned pb = (unsigned)cur.u * (SKIN_GROUPS * 1024u);
+  f32x4 rbuf[3][SK2_RING];
+#pragma unroll
+  for (int s = 0; s < SK2_RING; ++s) {
+    rbuf[0][s] = SK3_LDB(0, pb, s);
+    rbuf[1][s] = SK3_LDB(1, pb, s);
+    rbuf[2][s] = SK3_LDB(2, pb, s);
+  }
+
+  if (tid < 64) sQ[tid] = (tid == 0) ? tb0 + SK3_WAVES : 0;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int i = tid + r * SK3_WAVES * 64;
+    if (i < 2 * NA) sA[i] = tmp[r];
+    else if (i < 2 * (NA + NT)) sT[i - 2 * NA] = __builtin_bit_cast(f32x4, tmp[r]);
+  }
+  if (tid < 2 * UUO_FT) sTr[tid] = trv;
+  __syncthreads();
+  if (!active) return;  // wave-uniform
+
+  int4 wi = make_int4(0, 0, 0, 0);                // skin weights of the unit whose epilogue is running
+  float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;  // blend of the previous unit
+  Sk2Epi E;
+  const char* sTb = reinterpret_cast<const char*>(sT);
+  const char* sTrb = reinterpret_cast<const char*>(sTr);
+  const unsigned v12 = (unsigned)V * 12u, n24 = (unsigned)nur * 24u;
+  sk2_unit_addresses(E, prv, wi, kq, j, V, v12, n24);
+  bool more = true;
+
+  while (more) {
+    const int claimed = __hip_atomic_fetch_add(&sQ[lane], lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned pbn = pb;
+    int t_nxt = t_cur;
+    // this unit's template and skin weights: asked for now, consumed at the unit's end (template) / by its epilogue, which runs
+    // during the next unit (weights: the running epilogue still reads the previous unit's)
+    const float tn0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, cur.u * 64, 0));
+    const float tn1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 4 + cur.u * 64, 0));
+    const float tn2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvt, j4, VP * 8 + cur.u * 64, 0));
+    const int4 wi_n = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rwi, j16, cur.u * 256, 0));
+    const float4 ww_n = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rww, j16, cur.u * 256, 0));
+    const float4* pa = sA + cur.slot * (UUO_KP * UUO_FT / 4) + lane;
+    f32x4 am0 = {0.f, 0.f, 0.f, 0.f}, am1 = am0, am2 = am0;  // sum a_hi b_hi
+    f32x4 as0 = am0, as1 = am0, as2 = am0;                    // sum a_hi b_lo + a_lo b_hi
+    float4 ah[2], al[2];
+    ah[0] = pa[0];
+    al[0] = pa[64];
+    // The MFMAs accumulate IN PLACE through inline assembly ("+v": destination = accumulator input, the same six register quads
+    // for the whole unit).  With the compiler's intrinsic the allocator lets an accumulator hop into whatever quad is free, and
+    // on this part an MFMA result written into the data registers of a 96-bit buffer store issued ~30 cycles earlier (behind the
+    // six refill loads) reached memory instead of the vertex: x of frame 13 of a tile, lanes 48-63, once or twice per launch.
+    // What the compiler no longer sees is kept safe by construction: the nine MFMAs of a step go large sums first, then the two
+    // small terms, so an accumulator is never touched by two of three consecutive MFMAs; its first MFMA comes long after the
+    // VALU zero fill; the blend is read twelve wait states after the last MFMA (below).
+#ifdef SK3_NO_MFMA
+#define SK3_MFMA(acc, a_, b_) asm volatile("" : "+v"(acc) : "v"(a_), "v"(b_))
+#else
+#define SK3_MFMA(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
+#endif
+    // one K-step of 32 (literal step number: the slice schedule and the ring indices are constants of each copy):
+    // 9 MFMAs, behind each of them 2 or 3 of the 144 slices of the previous unit's epilogue; then the refill of the two ring
+    // stages the step has consumed -- 7 blocks (3.5 steps) of lead, across the unit boundary
+#define SK3_STEP(ST)                                                         \
+    {                                                                        \
+      constexpr int st = ST;                                                 \
+      constexpr int rh = (2 * st) % SK2_RING, rl = (2 * st + 1) % SK2_RING; \
+      const f16x8 a_hi = __builtin_bit_cast(f16x8, ah[st & 1]), a_lo = __builtin_bit_cast(f16x8, al[st & 1]); \
+_Pragma("unroll") \
+      for (int q = 0; q < 9; ++q) { \
+        const int term = q / 3, c = q - 3 * term; \
+        const f16x8 b_hi = __builtin_bit_cast(f16x8, rbuf[c][rh]), b_lo = __builtin_bit_cast(f16x8, rbuf[c][rl]); \
+        const f16x8 ax = (term == 2) ? a_lo : a_hi, bx = (term == 1) ? b_lo : b_hi; \
+        if (term == 0) { \
+          if (c == 0) SK3_MFMA(am0, ax, bx); \
+          else if (c == 1) SK3_MFMA(am1, ax, bx); \
+          else SK3_MFMA(am2, ax, bx); \
+        } else { \
+          if (c == 0) SK3_MFMA(as0, ax, bx); \
+          else if (c == 1) SK3_MFMA(as1, ax, bx); \
+          else SK3_MFMA(as2, ax, bx); \
+        } \
+        const int mslot = st * 9 + q; \
+        const int n0 = (mslot * SK3_NSLICE) / SK3_NMFMA, n1 = ((mslot + 1) * SK3_NSLICE) / SK3_NMFMA; \
+_Pragma("unroll") \
+        for (int i = 0; i < 3; ++i) { \
+          const int n = n0 + i; \
+          if (n < n1) sk2_slice<BBOX, false>(n / 12, n % 12, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv); \
+        } \
+        if (q == 5 && st + 1 < SK3_STEPS) { \
+          ah[(st + 1) & 1] = pa[(2 * (st + 1)) * 64]; \
+          al[(st + 1) & 1] = pa[(2 * (st + 1) + 1) * 64]; \
+        } \
+        if (st == 2 && q == 4) { \
+          const int t_n = __builtin_amdgcn_readfirstlane(claimed); \
+          more = t_n < tb1; \
+          t_nxt = more ? t_n : t_cur; \
+          SK3_DECODE(nxt, t_nxt); \
+          pbn = (unsigned)nxt.u * (SKIN_GROUPS * 1024u); \
+        } \
+        __builtin_amdgcn_sched_barrier(0); \
+      } \
+      { \
+        constexpr int gh = 2 * st + SK2_RING, gl = 2 * st + 1 + SK2_RING; \
+        const unsigned ubh = (gh < SKIN_GROUPS) ? pb : pbn, ubl = (gl < SKIN_GROUPS) ? pb : pbn; \
+        rbuf[0][rh] = SK3_LDB(0, ubh, gh % SKIN_GROUPS); \
+        rbuf[1][rh] = SK3_LDB(1, ubh, gh % SKIN_GROUPS); \
+        rbuf[2][rh] = SK3_LDB(2, ubh, gh % SKIN_GROUPS); \
+        rbuf[0][rl] = SK3_LDB(0, ubl, gl % SKIN_GROUPS); \
+        rbuf[1][rl] = SK3_LDB(1, ubl, gl % SKIN_GROUPS); \
+        rbuf[2][rl] = SK3_LDB(2, ubl, gl % SKIN_GROUPS); \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+    }
+    SK3_STEP(0) SK3_STEP(1) SK3_STEP(2) SK3_STEP(3) SK3_STEP(4) SK3_STEP(5) SK3_STEP(6)
+#undef SK3_STEP
+#undef SK3_MFMA
+    asm volatile("s_nop 7\n\ts_nop 3");  // MFMA result -> VALU read (the compiler does not know the asm statements are MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    // v_posed = template + 2^-k (large + small)
+    q0 = (am0 + as0) * inv_scale + tn0;
+    q1 = (am1 + as1) * inv_scale + tn1;
+    q2 = (am2 + as2) * inv_scale + tn2;
+    wi = wi_n;
+    ww = ww_n;
+    prv = cur; cur = nxt; pb = pbn; t_cur = t_nxt;
+    sk2_unit_addresses(E, prv, wi, kq, j, V, v12, n24);
+  }
+#undef SK3_LDB
+#undef SK3_DECODE
+  // epilogue of the wave's last unit
+#pragma unroll
+  for (int g = 0; g < 12; ++g) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sk2_slice<BBOX, false>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv);
+  }
+}
+
 // true when every block's tasks of k_skin2 lie in at most two of the three segments it can address (see the kernel)
 static bool sk2_fits(int nFT, int nur, int npos) {
   if (nur < 8) return false;
@@ -777,13 +1041,14 @@ struct SkinCallArgs {  // UUO_OP_SKIN: a whole-GPU kernel; a lock-step batch rep
   const float* trans;
   float* verts;
   float* bbox;
+  const void* pfa16;  // non-null: the call is k_skin3's (uuo_launch_skin16), pfaT is unused
 };
 
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A, const float* trans,
                     float* verts, float* bbox, float* vp_out) {
   UUO_REQUIRE(!vp_out || (bbox && !uuo_recorder), "uuo_launch_skin: v_posed output goes with the unit boxes, outside lock-step batches");
   {
-    SkinCallArgs c{{1, 1}, m, F, pfaT, A, trans, verts, bbox};
+    SkinCallArgs c{{1, 1}, m, F, pfaT, A, trans, verts, bbox, nullptr};
     if (uuo_record(UUO_OP_SKIN, 1, 1, c)) return 0;
   }
   static const int force_v1 = UUO_ENV_INT("UUO_SKIN_V1", 0);  // ablation / comparison only
@@ -846,6 +1111,37 @@ extern "C" int uuo_debug_skin_stamps(unsigned long long* h_out) {  // 2048 waves
   return 0;
 }
 #endif  // UUO_DEBUG_HOOKS
+
+int uuo_launch_skin16(const uuo_model* m, hipStream_t s, int F, const void* pfa16, const float* A, const float* trans, float* verts,
+                      float* bbox) {
+  UUO_REQUIRE(m->P16 && pfa16 && bbox, "uuo_launch_skin16: needs the fp16 tables and the unit boxes");
+  static const hipError_t lds_attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skin3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK3_LDS_PAD);
+  UUO_HIP_CHECK(lds_attr);
+  const int nur = (m->V + 15) / 16;
+  const int npos = 1 << SK2_NPOS_LOG2;
+  if ((size_t)SK2_MAX_FT * UUO_FT * m->V * 12 >= 0x7FFFFFF0u) return -22;
+  const int nFT_all = (F + UUO_FT - 1) / UUO_FT;
+  for (int ft0 = 0; ft0 < nFT_all; ft0 += SK2_MAX_FT) {
+    const int nFT = (nFT_all - ft0 < SK2_MAX_FT) ? nFT_all - ft0 : SK2_MAX_FT;
+    if (!sk2_fits(nFT, nur, npos)) return -22;
+  }
+  {  // (a lock-step batch replays the call for one problem after the other, like the fp32 kernel's)
+    SkinCallArgs c{{1, 1}, m, F, nullptr, A, trans, verts, bbox, pfa16};
+    if (uuo_record(UUO_OP_SKIN, 1, 1, c)) return 0;
+  }
+  for (int ft0 = 0; ft0 < nFT_all; ft0 += SK2_MAX_FT) {
+    const int nFT = (nFT_all - ft0 < SK2_MAX_FT) ? nFT_all - ft0 : SK2_MAX_FT;
+    const int f0 = ft0 * UUO_FT;
+    const int Fl = (F - f0 < nFT * UUO_FT) ? F - f0 : nFT * UUO_FT;
+    hipLaunchKernelGGL((k_skin3<true>), dim3(8 * npos), dim3(SK3_WAVES * 64), SK3_LDS_PAD, s, reinterpret_cast<const float4*>(m->P16), m->vt3,
+                       m->Wi, m->Ww, reinterpret_cast<const float4*>(pfa16) + (size_t)ft0 * (UUO_KP * UUO_FT / 4),
+                       A + (size_t)f0 * UUO_NUM_JOINTS * 12, trans ? trans + (size_t)f0 * 3 : (const float*)nullptr,
+                       verts + (size_t)f0 * m->V * 3, bbox + (size_t)f0 * nur * 6, Fl, m->V, m->VP, nFT, m->skin16_inv);
+  }
+  UUO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 static int uuo_launch_skin_v1(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                               const float* trans, float* verts, float* bbox) {
@@ -1114,5 +1410,6 @@ int uuo_batched_launch_smpl(int op, hipStream_t s, const void* d_args, int count
 // replay of one recorded UUO_OP_SKIN call (host copy of its arguments), outside record mode
 int uuo_replay_skin_call(hipStream_t s, const void* h_args) {
   const SkinCallArgs* c = (const SkinCallArgs*)h_args;
+  if (c->pfa16) return uuo_launch_skin16(c->m, s, c->F, c->pfa16, c->A, c->trans, c->verts, c->bbox);
   return uuo_launch_skin(c->m, s, c->F, c->pfaT, c->A, c->trans, c->verts, c->bbox);
 }

@@ -16,6 +16,7 @@
 #define UUO_MAX_DEPTH 10  // SMPL tree depth is 9
 #define UUO_LEVEL_W 5     // joints per tree level the level-parallel sweeps support (SMPL: 1,3,3,3,5,3,2,2,2)
 #define UUO_FP 24         // floats per frame of the closure's partial-sum block
+#define UUO_SK16_ASCALE 128.0f  // k_skin3: the pose features / betas are split as halves of 128 x (|R - I| <= 2, |beta| < 511 stay in range)
 #define UUO_PRE 96        // floats per frame of the soft part closure's record (k_part_soft -> k_bwd_part): 0 weighted data-loss
                           // sum, 1..3 d trans, 4..13 d beta (blend-shape path), 14 torque_z about trans_f, 16..87 joint forces [24][3]
 
@@ -100,6 +101,10 @@ struct uuo_model {
   float* P3 = nullptr;    // [3][VP/16][14][64][4]  blend basis (posedirs rows then shapedirs rows) in MFMA-operand order:
                           //   per (coord, 16-vertex unit, group of 4 K-steps) one 1-KB block = lane l's 4 B values
   float* vt3 = nullptr;   // [3][VP]           template, coordinate-planar
+  void* P16 = nullptr;    // [3][VP/16][7][2][64][8] halfs: the same basis split into two fp16 planes (hi, lo) of basis * skin16_bscale,
+                          //   in v_mfma_f32_16x16x32_f16 operand order (k_skin3: the chamfer closure's search); slot t of lane l in
+                          //   K-step s is P3's (group 2 s + (t >> 2), component t & 3) of the same lane
+  float skin16_inv = 0.f; // 1 / (UUO_SK16_ASCALE * skin16_bscale): what k_skin3 multiplies its accumulators with
   float* PT = nullptr;    // [V][3][UUO_KB]    per-vertex posedirs rows (backward / gather-LBS)
   float* ST = nullptr;    // [V][3][10]        shapedirs
   float* vt = nullptr;    // [V][3]
@@ -156,6 +161,7 @@ struct uuo_fit {
   int n_max = 0;  // 219F+10
   // closure workspace
   float* pfaT = nullptr;            // [nFT][14][64][4]: A operand (pose features | betas) in MFMA-operand order
+  void* pfa16 = nullptr;            // [nFT][7][2][64][8] halfs: the same operand * UUO_SK16_ASCALE as two fp16 planes (k_skin3)
   float* A = nullptr;               // [nFT*UUO_FT][24][12]
   float* verts = nullptr;           // [F][V][3]
   float* bbox = nullptr;            // [F][ceil(V/16)][6] per-unit bounding boxes (lo xyz, hi xyz), written by k_skin
@@ -165,6 +171,7 @@ struct uuo_fit {
   struct UuoDenseWs* dense = nullptr;  // soft chamfer closure (extension): workspace of the dense backward, its vertex gradient
   float* soft_gV = nullptr;            // [F][V][3] and [4][F][M] floats of soft-min scratch; allocated on first use
   float* soft_sm = nullptr;
+  float* dbg_verts = nullptr;          // debug flavour, UUO_SKIN_F16_CHECK: the fp32 kernel's vertices and boxes beside k_skin3's (first use)
   float* bary_items = nullptr;         // marker stage on a three-corner placement: [F][3 M][3] corner items + [F] loss sums (first use)
   int* nn_flags = nullptr;          // [F][8] survivor counts of the pruned nearest-neighbour search (debug / tests)
   unsigned long long* nn = nullptr; // [F][M] packed (dist bits << 32 | idx)
@@ -213,7 +220,7 @@ int uuo_launch_soft_chamfer(hipStream_t s, int F, int M, int V, const float* mar
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int uuo_launch_pose_prep(const uuo_model* m, hipStream_t s, int F, const UuoPoseSrc& src, float* pfaT, float* A,
                          float* joints_posed, float* frames = nullptr, const int32_t* sb_subset = nullptr, int sb_ns = 0,
-                         float* sb_out = nullptr);
+                         float* sb_out = nullptr, void* pfa16 = nullptr);
 int uuo_launch_part_fwd(const uuo_model* m, hipStream_t s, int F, int P1, const float* cache, const float* sb, const float* A,
                         const float* trans, const int32_t* subset, int n_subset, const float* markers,
                         unsigned long long* packed);
@@ -223,6 +230,10 @@ int uuo_launch_part_soft(const uuo_model* m, hipStream_t s, int F, int P1, const
 // vp_out (optional, with bbox): v_posed [F][V][3] as well (the dense backward's input: saves its own skinning launch)
 int uuo_launch_skin(const uuo_model* m, hipStream_t s, int F, const float* pfaT, const float* A,
                     const float* trans, float* verts, float* bbox, float* vp_out = nullptr);
+// the skinning of a closure's SEARCH on the fp16 matrix pipe (k_skin3): both operands split into two fp16 planes, three products,
+// fp32 accumulation; returns -22 when the launch geometry does not fit (the caller falls back to uuo_launch_skin)
+int uuo_launch_skin16(const uuo_model* m, hipStream_t s, int F, const void* pfa16, const float* A, const float* trans, float* verts,
+                      float* bbox);
 int uuo_launch_skin_cached(const uuo_model* m, hipStream_t s, int F, const float* cache, const float* A,
                            const float* betas, const float* trans, const int32_t* subset, int n_subset, float* verts,
                            float* bbox_compact = nullptr);

@@ -578,7 +578,9 @@ class _StageProblem:
         return {"n_iter": int(num_steps), "n_eval": int(num_steps), "first_loss": first, "final_loss": last,
                 "stop_reason": "num_steps", "device_ms": 0.0, "driver": "adam"}
 
-    def time_closure(self, x: torch.Tensor, iters: int = 20, dominant_only: bool = False) -> float:
+    def time_closure(self, x: torch.Tensor, iters: int = 20, dominant_only=False) -> float:
+        """Device ms per closure evaluation (HIP events); dominant_only 1 / True: the fp32 skinning kernel alone (k_skin2), 2: the
+        fp16-split skinning kernel of the chamfer closure's search (k_skin3)."""
         self._need_workspace()
         ms = c_float(0.0)
         with torch.cuda.device(self.device):
