@@ -326,7 +326,8 @@ int uuo_copy_to_host(void* stream, const float* d_src, float* h_dst, int n);
 
 /* ---- benchmarking helpers (used by bench.py for the roofline object) -------------------------------
  * average device milliseconds per closure evaluation over `iters` back-to-back evaluations, measured with
- * HIP events on `stream`; optionally only the dominant kernel (skin + nearest-neighbour). */
+ * HIP events on `stream`; dominant_kernel_only 1: the fp32 skinning kernel alone (k_skin2), 2: the skinning kernel of the chamfer
+ * closure's search alone (k_skin3, fp16 matrix pipe on split operands), one event pair per launch. */
 int uuo_time_closure(uuo_fit_t* fit, void* stream, const uuo_problem_t* p, const float* d_x, int iters,
                      int dominant_kernel_only, float* ms_per_eval);
 
