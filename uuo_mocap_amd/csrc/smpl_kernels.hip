@@ -914,13 +914,12 @@ __global__ __launch_bounds__(SK3_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     ah[0] = pa[0];
     al[0] = pa[64];
     // The MFMAs accumulate IN PLACE through inline assembly ("+v": destination = accumulator input, the same six register quads
-    // for the whole unit).  With the compiler's intrinsic the allocator lets an accumulator hop into whatever quad is free, and
-    // on this part an MFMA result written into the data registers of a 96-bit buffer store issued ~30 cycles earlier (behind the
-    // six refill loads) reached memory instead of the vertex: x of frame 13 of a tile, lanes 48-63, once or twice per launch.
-    // What the compiler no longer sees is kept safe by construction: the nine MFMAs of a step go large sums first, then the two
-    // small terms, so an accumulator is never touched by two of three consecutive MFMAs; its first MFMA comes long after the
-    // VALU zero fill; the blend is read twelve wait states after the last MFMA (below).
-#ifdef SK3_NO_MFMA
+    // for the whole unit; with the compiler's intrinsic the allocator lets an accumulator hop into whatever quad is free, e.g. the
+    // data registers of a vertex store issued a few instructions earlier).  What the compiler no longer sees is kept safe by
+    // construction: the nine MFMAs of a step go large sums first, then the two small terms, so an accumulator is never touched by
+    // two of three consecutive MFMAs; its first MFMA comes long after the VALU zero fill; the blend is read twelve wait states
+    // after the last MFMA (below).
+#ifdef SK3_NO_MFMA  // (experiment: the kernel without its matrix instructions -- the failure described above needs them)
 #define SK3_MFMA(acc, a_, b_) asm volatile("" : "+v"(acc) : "v"(a_), "v"(b_))
 #else
 #define SK3_MFMA(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
