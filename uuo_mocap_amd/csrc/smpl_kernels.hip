@@ -423,7 +423,12 @@ struct Sk2Epi {      // registers of the epilogue that runs in the shadow of the
 // (v_pk_fma_f32 on adjacent registers), frames past F fall outside the buffers' ranges by construction and padding
 // vertices duplicate the last real one (model.hip), so neither needs a select.
 // VPOUT: also store v_posed (the blend, before skinning) in the vertices' layout -- the dense backward needs it (dense_bwd.hip)
-template <bool BBOX, bool VPOUT = false>
+// SCALAR_APPLY (k_skin3): the 3x4 transform is applied with scalar FMAs on opaque copies of its entries instead of whatever
+// the compiler packs.  Same fma chain, same bits.  The unexplained failure of k_skin3's two-waves-per-SIMD version (see k_skin3)
+// was traced to the compiler's packed form of this expression for frame register 1 -- v_mov into one half of a register pair,
+// v_pk_fma reading the pair a few instructions later -- going wrong in lanes 48-63 when another wave's MFMAs share the SIMD:
+// with this form, 0 values off in 300 launches even at two waves per SIMD (2 363 in 100 without).
+template <bool BBOX, bool VPOUT = false, bool SCALAR_APPLY = false>
 __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& E, const float4& ww, const f32x4& p0,
                                           const f32x4& p1, const f32x4& p2, const char* sTb, const char* sTrb,
                                           const unsigned v12, const unsigned n24, __amdgpu_buffer_rsrc_t rv,
@@ -468,7 +473,15 @@ __device__ __forceinline__ void sk2_slice(const int piece, const int k, Sk2Epi& 
     } else if (k >= 1 && k <= 3) {
       const int c = k - 1;
       const float px = p0[e], py = p1[e], pz = p2[e];
-      E.o[c] = fmaf(E.T[2 * c + 1][0], pz, fmaf(E.T[2 * c][1], py, E.T[2 * c][0] * px)) + E.T[2 * c + 1][1];
+      if constexpr (SCALAR_APPLY) {
+        float t0 = E.T[2 * c][0], t1 = E.T[2 * c][1], t2 = E.T[2 * c + 1][0], t3 = E.T[2 * c + 1][1];
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+        float oc = fmaf(t2, pz, fmaf(t1, py, t0 * px)) + t3;
+        asm volatile("" : "+v"(oc));
+        E.o[c] = oc;
+      } else {
+        E.o[c] = fmaf(E.T[2 * c + 1][0], pz, fmaf(E.T[2 * c][1], py, E.T[2 * c][0] * px)) + E.T[2 * c + 1][1];
+      }
     } else if (k == 4) {
       E.o[0] += E.tr.x; E.o[1] += E.tr.y; E.o[2] += E.tr.z;
       u32x3 o = {__builtin_bit_cast(unsigned, E.o[0]), __builtin_bit_cast(unsigned, E.o[1]),
@@ -773,8 +786,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ONE wave per SIMD, and no other matrix-pipe wave beside it.  With two waves of this kernel per SIMD (an 8-wave block) the x
 // coordinate of one frame of a unit -- always frame 13 of a tile -- came out wrong once or twice per launch (y and z exact; only
 // with the MFMAs in, whatever the register allocation, the order of the epilogue pieces or the padding after an MFMA; never with
-// four waves: 0 of 2.5e8 values in 40 launches).  The cause is not understood; the conditions are avoided by construction: four
-// waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304 static ones, so that no block of a kernel that
+// four waves: 0 of 2.5e8 values in 40 launches).  It was traced to the compiler's packed form of the 3x4 apply (sk2_slice,
+// SCALAR_APPLY), which k_skin3 no longer uses; why that form fails there is not understood, so the conditions stay avoided by
+// construction as well: four waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304 static ones, so that no block of a kernel that
 // issues MFMAs (k_skin2 / k_skin3 66 304 B, k_dpf 57 344, k_skin 32 768) fits beside it on a CU (160 KB), while the latency-bound
 // kernels of other chains (< 32 KB of LDS) still do.  tools/skin16_stress.py checks every launch of whole fits in flight against
 // the fp32 kernel (debug flavour).
@@ -951,7 +965,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int i = 0; i < 3; ++i) { \
           const int n = n0 + i; \
-          if (n < n1) sk2_slice<BBOX, false>(n / 12, n % 12, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv); \
+          if (n < n1) sk2_slice<BBOX, false, true>(n / 12, n % 12, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv); \
         } \
         if (q == 5 && st + 1 < SK3_STEPS) { \
           ah[(st + 1) & 1] = pa[(2 * (st + 1)) * 64]; \
@@ -998,7 +1012,7 @@ _Pragma("unroll") \
 #pragma unroll
   for (int g = 0; g < 12; ++g) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) sk2_slice<BBOX, false>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv);
+    for (int k = 0; k < 12; ++k) sk2_slice<BBOX, false, true>(g, k, E, ww, q0, q1, q2, sTb, sTrb, v12, n24, rv, rb, rv);
   }
 }
 
