@@ -1209,8 +1209,9 @@ def test_skin16_every_launch_of_fits_in_flight_against_the_fp32_kernel(tmp_path)
     """tools/skin16_stress.py on a smaller scale: whole fits of 300 x 50 sequences, two in flight, on the debug flavour with
     UUO_SKIN_F16_CHECK=1 -- every k_skin3 launch is followed by the fp32 kernel on the same operands and a device-side count of
     vertex and box values more than 1e-5 m apart.  (With two waves of k_skin3 per SIMD one frame of a unit per launch came out
-    wrong in x, cause unknown -- smpl_kernels.hip; the shipped kernel runs one wave per SIMD and keeps other MFMA blocks off its
-    CU.  This test is the watch on that.)"""
+    wrong in x -- traced to the compiler's packed form of the 3x4 apply beside another wave's MFMAs; the shipped
+    kernel applies the transform with scalar FMAs, runs one wave per SIMD and keeps other MFMA blocks off its CU.  This test is
+    the watch on that.)"""
     import os
     import subprocess
     import sys
