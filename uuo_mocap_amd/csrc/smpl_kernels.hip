@@ -789,8 +789,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // four waves: 0 of 2.5e8 values in 40 launches).  It was traced to the compiler's packed form of the 3x4 apply (sk2_slice,
 // SCALAR_APPLY), which k_skin3 no longer uses; why that form fails there is not understood, so the conditions stay avoided by
 // construction as well: four waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304 static ones, so that no block of a kernel that
-// issues MFMAs (k_skin2 / k_skin3 66 304 B, k_dpf 57 344, k_skin 32 768) fits beside it on a CU (160 KB), while the latency-bound
-// kernels of other chains (< 32 KB of LDS) still do.  tools/skin16_stress.py checks every launch of whole fits in flight against
+// issues MFMAs (k_skin2 / k_skin3 66 304 B, k_dpf 57 344, k_skin 32 768) fits beside it on a CU (160 KB); the other chains' search,
+// L-BFGS passes, k_finalize and k_pose_prep (< 32 KB of LDS) still do, k_bwd_sparse (43 KB) does not (measured neutral).  tools/skin16_stress.py checks every launch of whole fits in flight against
 // the fp32 kernel (debug flavour).
 #ifndef SK3_WAVES
 #define SK3_WAVES 4
