@@ -787,15 +787,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // coordinate of one frame of a unit -- always frame 13 of a tile -- came out wrong once or twice per launch (y and z exact; only
 // with the MFMAs in, whatever the register allocation, the order of the epilogue pieces or the padding after an MFMA; never with
 // four waves: 0 of 2.5e8 values in 40 launches).  It was traced to the compiler's packed form of the 3x4 apply (sk2_slice,
-// SCALAR_APPLY), which k_skin3 no longer uses; why that form fails there is not understood, so the conditions stay avoided by
-// construction as well: four waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304 static ones, so that no block of a kernel that
-// issues MFMAs (k_skin2 / k_skin3 66 304 B, k_dpf 57 344, k_skin 32 768) fits beside it on a CU (160 KB); the other chains' search,
-// L-BFGS passes, k_finalize and k_pose_prep (< 32 KB of LDS) still do, k_bwd_sparse (43 KB) does not (measured neutral).  tools/skin16_stress.py checks every launch of whole fits in flight against
-// the fp32 kernel (debug flavour).
+// SCALAR_APPLY), which k_skin3 no longer uses -- that took the failure from about one unit per launch to ONE unit in 60 000
+// launches of fits in flight when two k_skin3 blocks may share a CU (no LDS pad), so it is not the whole story, and the
+// conditions stay avoided by construction: four waves per block, and SK3_LDS_PAD bytes of dynamic LDS on top of the 66 304
+// static ones, so that no block of a kernel that issues MFMAs fits beside it on a CU (160 KB): k_skin2 / k_skin3 66 304 B and
+// k_dpf 57 344 by LDS, k_skin (32 768 B, 2 x 170 registers per SIMD) by registers.  The other chains' search, backward, L-BFGS
+// passes, k_finalize and k_pose_prep (<= 43 KB) still fit -- with a pad that kept k_bwd_sparse out the fit in flight was 2.4 %
+// slower.  With this pad: 184 009 launches of fits in flight checked against the fp32 kernel, 0 values off
+// (tools/skin16_stress.py, debug flavour).
 #ifndef SK3_WAVES
 #define SK3_WAVES 4
 #endif
-#define SK3_LDS_PAD 65280  // 66 304 + 65 280 = 131 584 > 163 840 - 32 768
+#ifndef SK3_LDS_PAD
+#define SK3_LDS_PAD 44288  // 66 304 + 44 288 = 110 592; + 57 344 (k_dpf) > 163 840
+#endif
 template <bool BBOX>
 __global__ __launch_bounds__(SK3_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_skin3(
     const float4* __restrict__ P16v, const float* __restrict__ vt3, const int* __restrict__ Wi, const float* __restrict__ Ww,
